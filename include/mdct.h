@@ -1,0 +1,145 @@
+/*
+ * mdct.h -- C-ABI of the MI355X-native 8x8 block-DCT engine (libmdct_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.
+ * Every entry point names the reference interface it replaces
+ * (file:line under rainerzufalldererste/simd_dct `src/`).
+ *
+ * Pointers `from` / `to` are DEVICE pointers (HBM) unless a function says otherwise;
+ * quantisation tables (`lut`) are always HOST pointers to 64 floats, indexed v*8+u.
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls are
+ * asynchronous on that stream; nothing is allocated or synchronised inside a launch
+ * (safe for hipGraph capture), except where stated.
+ *
+ * Return value: the reference's own status enum, simd_dct.h:22-27:
+ *   0 MDCT_SUCCESS, 1 MDCT_INVALID_PARAMETER, 2 MDCT_NOT_SUPPORTED.
+ * HIP failures map to MDCT_NOT_SUPPORTED with detail in mdct_last_error().
+ */
+#ifndef MDCT_H
+#define MDCT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* simd_dct.h:22-27 (enum simdDctResult) */
+enum
+{
+  MDCT_SUCCESS = 0,
+  MDCT_INVALID_PARAMETER = 1,
+  MDCT_NOT_SUPPORTED = 2
+};
+
+/* Arithmetic profile of the u8 forward+quantise path: which reference tier the
+ * bytes must be identical to (behaviours B1..B5). */
+enum
+{
+  MDCT_PROFILE_REF_AVX = 0,    /* B1: simd_dct.cpp:2064-2262 (AVX2 == AVX-512VL)        */
+  MDCT_PROFILE_REF_SSE = 1,    /* B2/B3: simd_dct.cpp:896-1103, :1540-1704 (SSE tiers)  */
+  MDCT_PROFILE_REF_SCALAR = 2  /* B4/B5: simd_dct.cpp:177-298, :300-395 (scalar tiers)  */
+};
+
+/* Output layout of the u8 forward+quantise path. */
+enum
+{
+  MDCT_LAYOUT_Q32 = 0,        /* 8 blocks interleaved: to[group*512 + coef*8 + blk], simd_dct.cpp:2221-2230 */
+  MDCT_LAYOUT_STEREO = 1,     /* 64 coefficient planes, (block row, eye, block x) order, simd_dct.cpp:1061-1099 */
+  MDCT_LAYOUT_BLOCK = 2,      /* 64 B per block, coefficients transposed (u*8+v), simd_dct.cpp:347-362 */
+  MDCT_LAYOUT_BLOCK_SSE = 3   /* the SSE encq tiers' half-written pair layout, simd_dct.cpp:1662-1676 */
+};
+
+typedef struct mdct_device_info
+{
+  int device;             /* HIP device ordinal in use */
+  int compute_units;      /* 256 on MI355X */
+  int wavefront_size;     /* 64 */
+  int lds_bytes_per_cu;   /* 163840 */
+  int is_gfx950;          /* 1 when the device is CDNA4 */
+  size_t hbm_bytes;       /* total global memory */
+  char name[128];         /* gcnArchName */
+} mdct_device_info;
+
+/* Replaces _DetectCPUFeatures() (simd_platform.c:68-178): selects the HIP device for the
+ * calling thread and probes it.  Idempotent.  Unlike the reference's CPU flags
+ * (simd_dct.cpp:78-85 read them, nobody sets them), every entry point below calls this
+ * lazily with the current device, so forgetting it cannot downgrade the path. */
+int mdct_init(int device);
+int mdct_get_device_info(mdct_device_info *info);
+/* Thread-local detail for the last non-zero return in this thread ("" if none). */
+const char *mdct_last_error(void);
+
+/* ---- u8 plane -> u8 quantised coefficients (the reference's three products) ----------
+ * Replaces the tier functions behind simd_dct.h:29-31, i.e.
+ *   simdDCT_EncodeQuantize32ReorderBuffer_AVX2_Float        simd_dct.cpp:2064 (layout Q32,   profile REF_AVX)
+ *   simdDCT_EncodeQuantizeReorderStereoBuffer_SSE41_Float   simd_dct.cpp:896  (layout STEREO, profile REF_SSE)
+ *   simdDCT_EncodeQuantizeReorderStereoBuffer_NoSimd_Float  simd_dct.cpp:177  (layout STEREO, profile REF_SCALAR)
+ *   simdDCT_EncodeQuantizeBuffer_NoSimd_Float               simd_dct.cpp:300  (layout BLOCK,  profile REF_SCALAR)
+ *   simdDCT_EncodeQuantizeBuffer_SSE41_Float                simd_dct.cpp:1540 (layout BLOCK_SSE, profile REF_SSE)
+ * with a sane range: block rows [by0, by1) in units of 8 pixel rows.
+ *   Q32 / BLOCK / BLOCK_SSE: the plane is sizeX x sizeY, by in [0, sizeY/8).
+ *   STEREO: `from` holds two stacked sizeX x sizeY/2 images; by in [0, sizeY/16) and
+ *           each block row is transformed for both eyes.
+ * `pitch_in` is the input row pitch in bytes (>= sizeX; the reference has pitch == sizeX).
+ * The output buffer is sizeX*sizeY bytes with the reference's addressing; bytes the
+ * reference would not write are not written.
+ * Constraints: sizeX % 64 == 0 for Q32, sizeX % 16 == 0 for STEREO / BLOCK_SSE,
+ * sizeX % 8 == 0 for BLOCK; sizeY % 8 == 0 (STEREO: % 16).  `from` must be 8-byte aligned
+ * and pitch_in % 8 == 0 (HBM allocations are; the reference took any alignment).        */
+int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const float *lut,
+                      size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                      int layout, int profile, void *stream);
+
+/* ---- engine-own variants (no reference counterpart; BASELINE.json configs 2-5) --------
+ * Planes are row-major, pitches in ELEMENTS, coefficient (v,u) of block (by,bx) lives
+ * at (by*8+v, bx*8+u).  Arithmetic: float32 K_OWN butterflies (correct DCT-II signs,
+ * pairwise association, no FMA), orthonormal.  `lut` may be NULL (no quantisation):
+ *   fwd:       coef = sat_i16(rne(f * (1.0f/lut[i])))
+ *   inv:       f    = (float)coef * lut[i]
+ *   roundtrip: fwd -> (quantise -> dequantise when lut) -> inv, fused, one pass over HBM.
+ * Rows must be 16-byte aligned (pitch*sizeof(elem) % 16 == 0, base 16-byte aligned).    */
+int mdct_fwd_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
+                 size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
+int mdct_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
+                 size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
+int mdct_roundtrip_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
+                       size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
+int mdct_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
+                 size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
+int mdct_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
+                 size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
+
+/* Multi-plane batch (config 3: Y + Cb + Cr with per-plane tables) in ONE launch.
+ * `planes` is a HOST array; descriptors are copied into a per-call slot of a small
+ * device-side ring before the launch (no allocation, no sync). */
+typedef struct mdct_plane_i16
+{
+  const int16_t *from;
+  int16_t *to;
+  size_t pitch_in, pitch_out; /* elements */
+  size_t sizeX, sizeY;
+  const float *lut;           /* HOST pointer to 64 floats, or NULL */
+} mdct_plane_i16;
+int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *stream);
+
+/* Measured-roofline helper for bench tools: a read-N/write-N 16 B/lane stream copy on
+ * the same stream (what "HBM roofline" means on this box). */
+int mdct_stream_copy(const void *from, void *to, size_t bytes, void *stream);
+
+/* Timing helpers so callers without a HIP binding (ctypes, cgo, JNI) can time the stream the
+ * kernels run on with HIP events.  mdct_timer_* are NOT capture-safe. */
+typedef struct mdct_timer mdct_timer;
+mdct_timer *mdct_timer_create(void);
+void mdct_timer_destroy(mdct_timer *t);
+int mdct_timer_start(mdct_timer *t, void *stream);
+int mdct_timer_stop(mdct_timer *t, void *stream);
+/* blocks until the stop event has completed; returns elapsed milliseconds (< 0 on error) */
+double mdct_timer_elapsed_ms(mdct_timer *t);
+int mdct_stream_synchronize(void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDCT_H */

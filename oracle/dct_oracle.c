@@ -1,0 +1,561 @@
+/*
+ * dct_oracle.c -- CPU restatement of the reference's 8x8 block-DCT hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see dct_oracle.h).  Plain C, scalar, one rounding per
+ * written float operation: build with `-O2 -ffp-contract=off`, never -ffast-math.
+ * Each function cites the reference lines (under /root/reference/src/) it restates.
+ * It was written from the behaviour of those lines, not translated from them: the
+ * reference is SIMD-intrinsic code, this is a per-block scalar description.
+ */
+#include "dct_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+/* simd_dct.cpp:140-146 (same literals in every tier: :2076-2082, :436-442). */
+static const float Ca = 1.3870398453221474618216191915664f;  /* sqrt2*cos(1*pi/16) */
+static const float Cb = 1.3065629648763765278566431734272f;  /* sqrt2*cos(2*pi/16) */
+static const float Cc = 1.1758756024193587169744671046113f;  /* sqrt2*cos(3*pi/16) */
+static const float Cd = 0.78569495838710218127789736765722f; /* sqrt2*cos(5*pi/16) */
+static const float Ce = 0.54119610014619698439972320536639f; /* sqrt2*cos(6*pi/16) */
+static const float Cf = 0.27589937928294301233595756366937f; /* sqrt2*cos(7*pi/16) */
+static const float Cn = 0.35355339059327376220042218105242f; /* 1/sqrt(8) */
+
+enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2, K_OWN = 3 };
+
+void orc_dct8(float *p, ptrdiff_t s, int which)
+{
+  const float p0 = p[0], p1 = p[s], p2 = p[2 * s], p3 = p[3 * s];
+  const float p4 = p[4 * s], p5 = p[5 * s], p6 = p[6 * s], p7 = p[7 * s];
+
+  /* first two butterfly stages are identical in all tiers
+   * (simd_dct.cpp:148-161, :2160-2173; the SSE tier builds x61m / x43m as
+   * (-p1)+p6 and (-p3)+p4 at :470-484, which is the same IEEE value). */
+  const float x07p = p0 + p7, x16p = p1 + p6, x25p = p2 + p5, x34p = p3 + p4;
+  const float x07m = p0 - p7, x61m = p6 - p1, x25m = p2 - p5, x43m = p4 - p3;
+  const float pp = x07p + x34p, pm = x07p - x34p;
+  const float qp = x16p + x25p, qm = x16p - x25p;
+
+  float o0, o1, o2, o3, o4, o5, o6, o7;
+
+  o0 = pp + qp;
+  o4 = pp - qp;
+
+  switch (which)
+  {
+  case K_TRUE: /* simd_dct.cpp:163-171, C left-to-right association */
+    o2 = Cb * pm + Ce * qm;
+    o6 = Ce * pm - Cb * qm;
+    o1 = ((Ca * x07m - Cc * x61m) + Cd * x25m) - Cf * x43m;
+    o3 = ((Cc * x07m + Cf * x61m) - Ca * x25m) + Cd * x43m;
+    o5 = ((Cd * x07m + Ca * x61m) + Cf * x25m) - Cc * x43m;
+    o7 = ((Cf * x07m + Cd * x61m) + Cc * x25m) + Ca * x43m;
+    break;
+
+  case K_SSE: /* simd_dct.cpp:547-577 (factor rows :547-550, pairwise sum :576-577,
+               * even part :585-608).  Lane 0 of xf_7_factors is +C_f: k=1 sign quirk. */
+    o2 = (Cb * pm) + (Ce * qm);
+    o6 = (Ce * pm) + ((-Cb) * qm);
+    o1 = ((Ca * x07m) + ((-Cc) * x61m)) + ((Cd * x25m) + (Cf * x43m));
+    o3 = ((Cc * x07m) + (Cf * x61m)) + (((-Ca) * x25m) + (Cd * x43m));
+    o5 = ((Cd * x07m) + (Ca * x61m)) + ((Cf * x25m) + ((-Cc) * x43m));
+    o7 = ((Cf * x07m) + (Cd * x61m)) + ((Cc * x25m) + (Ca * x43m));
+    break;
+
+  case K_OWN: /* engine-own: correct signs (as :163-171), pairwise association (as :2176-2183) */
+    o2 = (Cb * pm) + (Ce * qm);
+    o6 = (Ce * pm) - (Cb * qm);
+    o1 = ((Ca * x07m) - (Cc * x61m)) + ((Cd * x25m) - (Cf * x43m));
+    o3 = ((Cc * x07m) + (Cf * x61m)) - ((Ca * x25m) - (Cd * x43m));
+    o5 = ((Cd * x07m) + (Ca * x61m)) + ((Cf * x25m) - (Cc * x43m));
+    o7 = ((Cf * x07m) + (Cd * x61m)) + ((Cc * x25m) + (Ca * x43m));
+    break;
+
+  default: /* K_AVX: simd_dct.cpp:2176-2183 (== :1972-1979, AVX-512VL).
+            * o3 subtracts (Ca*x25m + Cd*x43m): k=3 sign quirk. */
+    o2 = (Cb * pm) + (Ce * qm);
+    o6 = (Ce * pm) - (Cb * qm);
+    o1 = ((Ca * x07m) - (Cc * x61m)) + ((Cd * x25m) - (Cf * x43m));
+    o3 = ((Cc * x07m) + (Cf * x61m)) - ((Ca * x25m) + (Cd * x43m));
+    o5 = ((Cd * x07m) + (Ca * x61m)) + ((Cf * x25m) - (Cc * x43m));
+    o7 = ((Cf * x07m) + (Cd * x61m)) + ((Cc * x25m) + (Ca * x43m));
+    break;
+  }
+
+  p[0] = Cn * o0;     p[s] = Cn * o1;     p[2 * s] = Cn * o2; p[3 * s] = Cn * o3;
+  p[4 * s] = Cn * o4; p[5 * s] = Cn * o5; p[6 * s] = Cn * o6; p[7 * s] = Cn * o7;
+}
+
+/* Inverse of K_OWN: x_n = Cn*(e_n + d_n), x_{7-n} = Cn*(e_n - d_n)  [unpinned]. */
+void orc_idct8_own(float *p, ptrdiff_t s)
+{
+  const float X0 = p[0], X1 = p[s], X2 = p[2 * s], X3 = p[3 * s];
+  const float X4 = p[4 * s], X5 = p[5 * s], X6 = p[6 * s], X7 = p[7 * s];
+
+  const float a0 = X0 + X4, a1 = X0 - X4;
+  const float b0 = (Cb * X2) + (Ce * X6);
+  const float b1 = (Ce * X2) - (Cb * X6);
+  const float e0 = a0 + b0, e1 = a1 + b1, e2 = a1 - b1, e3 = a0 - b0;
+
+  const float d0 = ((Ca * X1) + (Cc * X3)) + ((Cd * X5) + (Cf * X7));
+  const float d1 = ((Cc * X1) - (Cf * X3)) - ((Ca * X5) + (Cd * X7));
+  const float d2 = ((Cd * X1) - (Ca * X3)) + ((Cf * X5) + (Cc * X7));
+  const float d3 = ((Cf * X1) - (Cd * X3)) + ((Cc * X5) - (Ca * X7));
+
+  p[0] = Cn * (e0 + d0);     p[7 * s] = Cn * (e0 - d0);
+  p[s] = Cn * (e1 + d1);     p[6 * s] = Cn * (e1 - d1);
+  p[2 * s] = Cn * (e2 + d2); p[5 * s] = Cn * (e2 - d2);
+  p[3 * s] = Cn * (e3 + d3); p[4 * s] = Cn * (e3 - d3);
+}
+
+/* x86 cvtps_epi32 under default MXCSR: round-to-nearest-even; out of range or NaN
+ * gives the "integer indefinite" 0x80000000 (simd_dct.cpp:2224, :1020). */
+static int32_t cvtps_epi32(float v)
+{
+  if (!(fabsf(v) < 2147483648.0f))
+    return INT32_MIN;
+  return (int32_t)rintf(v);
+}
+
+static int32_t clamp_0_255(int32_t v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+static void rows(float *blk, int which) { for (int r = 0; r < 8; r++) orc_dct8(blk + r * 8, 1, which); }
+static void cols(float *blk, int which) { for (int c = 0; c < 8; c++) orc_dct8(blk + c, 8, which); }
+static void transpose(float *blk)
+{
+  for (int i = 0; i < 8; i++)
+    for (int j = i + 1; j < 8; j++)
+    {
+      const float t = blk[i * 8 + j];
+      blk[i * 8 + j] = blk[j * 8 + i];
+      blk[j * 8 + i] = t;
+    }
+}
+
+static int check_args(const void *from, const void *to, size_t sizeX, size_t sizeY, size_t xmul)
+{
+  if (from == NULL || to == NULL)
+    return 1; /* sdr_InvalidParameter, simd_dct.cpp:75, :97, :117 */
+  if (sizeX % xmul != 0 || sizeY % 8 != 0)
+    return 2; /* sdr_NotSupported, simd_dct.cpp:76, :98, :118 */
+  return 0;
+}
+
+/* ------------------------------------------------------------------ B1 ---- */
+/* simd_dct.cpp:2064-2262.  (float)px, K_AVX rows then K_AVX columns, i = v*8+u,
+ * q[i] = 255.0f/(lut[i]*0.95f) (:2239), byte = clamp(127 + rne(f*q[i]), 0, 255) (:2224),
+ * stored at pTo[y*W + g*512 + i*8 + b] (:2227-2230). */
+static void q32_block(const uint8_t *src, size_t pitch, const float *q, uint8_t *dst /* stride 8 */)
+{
+  float blk[64];
+  for (int r = 0; r < 8; r++)
+    for (int c = 0; c < 8; c++)
+      blk[r * 8 + c] = (float)src[r * pitch + c];
+  rows(blk, K_AVX);
+  cols(blk, K_AVX);
+  for (int i = 0; i < 64; i++)
+    dst[i * 8] = (uint8_t)clamp_0_255(127 + cvtps_epi32(blk[i] * q[i]));
+}
+
+static void make_q255(const float *lut, float *q)
+{
+  for (int i = 0; i < 64; i++)
+    q[i] = 255.0f / (lut[i] * 0.95f);
+}
+
+int orc_q32_avx(const uint8_t *from, uint8_t *to, const float *lut, size_t W, size_t H, size_t startY, size_t endY)
+{
+  const int e = check_args(from, to, W, H, 64);
+  if (e)
+    return e;
+  float q[64];
+  make_q255(lut, q);
+  /* row loop :2243-2261: y < H/2, processed iff startY <= 2y <= endY */
+  for (size_t y = 0; y < H / 2; y += 8)
+  {
+    if (y * 2 < startY)
+      continue;
+    if (y * 2 > endY)
+      break;
+    for (size_t g = 0; g < W / 64; g++)
+      for (size_t b = 0; b < 8; b++)
+        q32_block(from + y * W + g * 64 + b * 8, W, q, to + y * W + g * 512 + b);
+  }
+  return 0;
+}
+
+int orc_q32_native(const uint8_t *from, uint8_t *to, size_t pitch_in, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = check_args(from, to, W, H, 64);
+  if (e)
+    return e;
+  if (by1 > H / 8 || by0 > by1 || pitch_in < W)
+    return 1;
+  float q[64];
+  make_q255(lut, q);
+  for (size_t by = by0; by < by1; by++)
+    for (size_t g = 0; g < W / 64; g++)
+      for (size_t b = 0; b < 8; b++)
+        q32_block(from + by * 8 * pitch_in + g * 64 + b * 8, pitch_in, q, to + by * 8 * W + g * 512 + b);
+  return 0;
+}
+
+/* ------------------------------------------------------------ B2 / B3 ----- */
+/* shared SSE block arithmetic: px*(1/255) (:949-957), quantise
+ * clamp(rne(f*q + 127.0f), 0, 255) with max(0,.) then min(255,.) on int32 (:1020). */
+static uint8_t sse_quant(float f, float q) { return (uint8_t)clamp_0_255(cvtps_epi32((f * q) + 127.0f)); }
+
+static void sse_load(const uint8_t *src, size_t pitch, float *blk)
+{
+  const float inv255 = 1.f / (float)0xFF;
+  for (int r = 0; r < 8; r++)
+    for (int c = 0; c < 8; c++)
+      blk[r * 8 + c] = inv255 * (float)src[r * pitch + c];
+}
+
+/* simd_dct.cpp:896-1103 (SSE4.1), == :1106-1327 (SSE2), :1330-1536 (SSSE3).
+ * T, K_SSE rows, T, K_SSE rows (:961-1004): i = v*8+u.  Output coefficient-planar:
+ * plane i at to + (W*H/64)*i, position advances one byte per block in the order
+ * (block row, eye, block x) (:1061-1099); skipped block rows still advance the
+ * position by W/4 (:1075-1081). */
+int orc_stereo_sse(const uint8_t *from, uint8_t *to, const float *lut, size_t W, size_t H, size_t startY, size_t endY)
+{
+  const int e = check_args(from, to, W, H, 8);
+  if (e)
+    return e;
+  if (W % 16 != 0)
+    return 2; /* the reference walks 16 px at a time and over-reads otherwise (:945) */
+  float q[64];
+  make_q255(lut, q);
+  const size_t plane = (W * H) / 64;
+  size_t pos = 0;
+  for (size_t y = 0; y < H / 2; y += 8)
+  {
+    if (y * 2 < startY)
+    {
+      pos += W / 4;
+      continue;
+    }
+    if (y * 2 > endY)
+      break;
+    for (int eye = 0; eye < 2; eye++)
+      for (size_t bx = 0; bx < W / 8; bx++)
+      {
+        float blk[64];
+        sse_load(from + (size_t)eye * (W * H / 2) + y * W + bx * 8, W, blk);
+        transpose(blk); rows(blk, K_SSE); transpose(blk); rows(blk, K_SSE);
+        for (int i = 0; i < 64; i++)
+          to[plane * i + pos] = sse_quant(blk[i], q[i]);
+        pos++;
+      }
+  }
+  return 0;
+}
+
+/* simd_dct.cpp:1540-1704 (SSE4.1) == :1707-1864 (SSSE3).  K_SSE rows, T, K_SSE rows:
+ * result[i8][j] with i8 = u, j = v, quantised with q[i8*8+j] (:1651-1655).  The store
+ * (:1662-1676) writes, per 16-px block pair (A,B) and coefficient row i8, the bytes
+ * {A[i8][0],A[i8][1],A[i8][4],A[i8][5],B[..same..]} at pair*128 + i8*8, and columns
+ * {2,3,6,7} 128 bytes further on, where the NEXT pair (or next line) overwrites them;
+ * only the spill of the last pair of the last processed line survives. */
+int orc_encq_sse(const uint8_t *from, uint8_t *to, const float *lut, size_t W, size_t H, size_t startY, size_t endY)
+{
+  const int e = check_args(from, to, W, H, 8);
+  if (e)
+    return e;
+  if (W % 16 != 0)
+    return 2;
+  float q[64];
+  make_q255(lut, q);
+  static const int lo_cols[4] = {0, 1, 4, 5}, hi_cols[4] = {2, 3, 6, 7};
+  for (size_t y = 0; y < H / 2; y += 8)
+  {
+    if (y * 2 < startY)
+      continue;
+    if (y * 2 > endY)
+      break;
+    for (size_t pr = 0; pr < W / 16; pr++)
+    {
+      uint8_t *base = to + y * W + pr * 128;
+      for (int ab = 0; ab < 2; ab++)
+      {
+        float blk[64];
+        sse_load(from + y * W + pr * 16 + ab * 8, W, blk);
+        rows(blk, K_SSE); transpose(blk); rows(blk, K_SSE);
+        for (int i8 = 0; i8 < 8; i8++)
+          for (int k = 0; k < 4; k++)
+          {
+            base[i8 * 8 + ab * 4 + k] = sse_quant(blk[i8 * 8 + lo_cols[k]], q[i8 * 8 + lo_cols[k]]);
+            /* the reference has no bounds check here; the oracle refuses to write
+             * outside the W*H buffer (only reachable when H == 8). */
+            if ((size_t)(base + 128 + i8 * 8 + ab * 4 + k - to) < W * H)
+              base[128 + i8 * 8 + ab * 4 + k] = sse_quant(blk[i8 * 8 + hi_cols[k]], q[i8 * 8 + hi_cols[k]]);
+          }
+      }
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------ B4 / B5 ----- */
+/* scalar tiers: px / 255.f (:222, :343), K_TRUE, qs[i] = 1.f/(lut[i]*0.95f) (:192-209),
+ * byte = (uint8_t)roundf(clamp(f*qs[i] + 127.0f/255.0f, 0, 1) * 255.f) (:245, :362),
+ * _clamp(v,min,max) = v > min ? (v < max ? v : max) : min (:50-54). */
+static uint8_t scalar_quant(float f, float qs)
+{
+  const float subtract = 127.0f / 255.0f;
+  float v = (f * qs) + subtract;
+  v = v > 0.f ? (v < 1.f ? v : 1.f) : 0.f;
+  return (uint8_t)roundf(v * 255.f);
+}
+
+static void scalar_load(const uint8_t *src, size_t pitch, float *blk)
+{
+  for (int r = 0; r < 8; r++)
+    for (int c = 0; c < 8; c++)
+      blk[r * 8 + c] = (float)src[r * pitch + c] / 255.f;
+}
+
+static void make_qs(const float *lut, float *qs)
+{
+  for (int i = 0; i < 64; i++)
+    qs[i] = 1.f / (lut[i] * 0.95f);
+}
+
+/* simd_dct.cpp:177-298: T, K_TRUE rows, T, K_TRUE rows; layout as B2. */
+int orc_stereo_scalar(const uint8_t *from, uint8_t *to, const float *lut, size_t W, size_t H, size_t startY, size_t endY)
+{
+  const int e = check_args(from, to, W, H, 8);
+  if (e)
+    return e;
+  float qs[64];
+  make_qs(lut, qs);
+  const size_t plane = (W * H) / 64;
+  size_t pos = 0;
+  for (size_t y = 0; y < H / 2; y += 8)
+  {
+    if (y * 2 < startY)
+    {
+      pos += W / 4;
+      continue;
+    }
+    if (y * 2 > endY)
+      break;
+    for (int eye = 0; eye < 2; eye++)
+      for (size_t bx = 0; bx < W / 8; bx++)
+      {
+        float blk[64];
+        scalar_load(from + (size_t)eye * (W * H / 2) + y * W + bx * 8, W, blk);
+        transpose(blk); rows(blk, K_TRUE); transpose(blk); rows(blk, K_TRUE);
+        for (int i = 0; i < 64; i++)
+          to[plane * i + pos] = scalar_quant(blk[i], qs[i]);
+        pos++;
+      }
+  }
+  return 0;
+}
+
+/* simd_dct.cpp:300-395: K_TRUE rows, T, K_TRUE rows (stored transposed, u*8+v);
+ * 64 bytes per block at y*W + bx*64; range test WITHOUT the x2 (:377-384). */
+int orc_encq_scalar(const uint8_t *from, uint8_t *to, const float *lut, size_t W, size_t H, size_t startY, size_t endY)
+{
+  const int e = check_args(from, to, W, H, 8);
+  if (e)
+    return e;
+  float qs[64];
+  make_qs(lut, qs);
+  for (size_t y = 0; y < H / 2; y += 8)
+  {
+    if (y < startY)
+      continue;
+    if (y > endY)
+      break;
+    for (size_t bx = 0; bx < W / 8; bx++)
+    {
+      float blk[64];
+      scalar_load(from + y * W + bx * 8, W, blk);
+      rows(blk, K_TRUE); transpose(blk); rows(blk, K_TRUE);
+      for (int i = 0; i < 64; i++)
+        to[y * W + bx * 64 + i] = scalar_quant(blk[i], qs[i]);
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------- engine-own [unpinned] -- */
+static int16_t sat_i16_rne(float v)
+{
+  const float r = rintf(v);
+  if (r != r)
+    return 0;
+  if (r <= -32768.f)
+    return INT16_MIN;
+  if (r >= 32767.f)
+    return INT16_MAX;
+  return (int16_t)r;
+}
+
+static int own_args(const void *from, const void *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
+{
+  if (from == NULL || to == NULL)
+    return 1;
+  if (W % 8 != 0 || H % 8 != 0)
+    return 2;
+  if (pi < W || po < W || by0 > by1 || by1 > H / 8)
+    return 1;
+  return 0;
+}
+
+int orc_fwd_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = own_args(from, to, pi, po, W, H, by0, by1);
+  if (e)
+    return e;
+  float rq[64];
+  for (int i = 0; i < 64; i++)
+    rq[i] = lut ? 1.0f / lut[i] : 1.0f;
+  for (size_t by = by0; by < by1; by++)
+    for (size_t bx = 0; bx < W / 8; bx++)
+    {
+      float blk[64];
+      for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++)
+          blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c];
+      rows(blk, K_OWN);
+      cols(blk, K_OWN);
+      for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++)
+          to[(by * 8 + r) * po + bx * 8 + c] = sat_i16_rne(lut ? blk[r * 8 + c] * rq[r * 8 + c] : blk[r * 8 + c]);
+    }
+  return 0;
+}
+
+static void inv_block(float *blk)
+{
+  for (int c = 0; c < 8; c++)
+    orc_idct8_own(blk + c, 8);
+  for (int r = 0; r < 8; r++)
+    orc_idct8_own(blk + r * 8, 1);
+}
+
+int orc_inv_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = own_args(from, to, pi, po, W, H, by0, by1);
+  if (e)
+    return e;
+  for (size_t by = by0; by < by1; by++)
+    for (size_t bx = 0; bx < W / 8; bx++)
+    {
+      float blk[64];
+      for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++)
+        {
+          const float f = (float)from[(by * 8 + r) * pi + bx * 8 + c];
+          blk[r * 8 + c] = lut ? f * lut[r * 8 + c] : f;
+        }
+      inv_block(blk);
+      for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++)
+          to[(by * 8 + r) * po + bx * 8 + c] = sat_i16_rne(blk[r * 8 + c]);
+    }
+  return 0;
+}
+
+int orc_roundtrip_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = own_args(from, to, pi, po, W, H, by0, by1);
+  if (e)
+    return e;
+  float rq[64];
+  for (int i = 0; i < 64; i++)
+    rq[i] = lut ? 1.0f / lut[i] : 1.0f;
+  for (size_t by = by0; by < by1; by++)
+    for (size_t bx = 0; bx < W / 8; bx++)
+    {
+      float blk[64];
+      for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++)
+          blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c];
+      rows(blk, K_OWN);
+      cols(blk, K_OWN);
+      if (lut)
+        for (int i = 0; i < 64; i++)
+          blk[i] = (float)sat_i16_rne(blk[i] * rq[i]) * lut[i];
+      inv_block(blk);
+      for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++)
+          to[(by * 8 + r) * po + bx * 8 + c] = sat_i16_rne(blk[r * 8 + c]);
+    }
+  return 0;
+}
+
+int orc_fwd_f32(const float *from, float *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = own_args(from, to, pi, po, W, H, by0, by1);
+  if (e)
+    return e;
+  for (size_t by = by0; by < by1; by++)
+    for (size_t bx = 0; bx < W / 8; bx++)
+    {
+      float blk[64];
+      for (int r = 0; r < 8; r++)
+        memcpy(blk + r * 8, from + (by * 8 + r) * pi + bx * 8, 8 * sizeof(float));
+      rows(blk, K_OWN);
+      cols(blk, K_OWN);
+      for (int r = 0; r < 8; r++)
+        memcpy(to + (by * 8 + r) * po + bx * 8, blk + r * 8, 8 * sizeof(float));
+    }
+  return 0;
+}
+
+int orc_inv_f32(const float *from, float *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = own_args(from, to, pi, po, W, H, by0, by1);
+  if (e)
+    return e;
+  for (size_t by = by0; by < by1; by++)
+    for (size_t bx = 0; bx < W / 8; bx++)
+    {
+      float blk[64];
+      for (int r = 0; r < 8; r++)
+        memcpy(blk + r * 8, from + (by * 8 + r) * pi + bx * 8, 8 * sizeof(float));
+      inv_block(blk);
+      for (int r = 0; r < 8; r++)
+        memcpy(to + (by * 8 + r) * po + bx * 8, blk + r * 8, 8 * sizeof(float));
+    }
+  return 0;
+}
+
+int orc_fwd_f64ref(const float *from, double *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = own_args(from, to, pi, po, W, H, by0, by1);
+  if (e)
+    return e;
+  double c[8][8]; /* c[k][n] = s_k cos((2n+1) k pi / 16), orthonormal DCT-II */
+  const double pi_ = 3.14159265358979323846264338327950288;
+  for (int k = 0; k < 8; k++)
+    for (int n = 0; n < 8; n++)
+      c[k][n] = (k == 0 ? sqrt(1.0 / 8.0) : 0.5) * cos((2 * n + 1) * k * pi_ / 16.0);
+  for (size_t by = by0; by < by1; by++)
+    for (size_t bx = 0; bx < W / 8; bx++)
+    {
+      double t[8][8];
+      for (int r = 0; r < 8; r++)
+        for (int u = 0; u < 8; u++)
+        {
+          double s = 0;
+          for (int n = 0; n < 8; n++)
+            s += c[u][n] * (double)from[(by * 8 + r) * pi + bx * 8 + n];
+          t[r][u] = s;
+        }
+      for (int v = 0; v < 8; v++)
+        for (int u = 0; u < 8; u++)
+        {
+          double s = 0;
+          for (int n = 0; n < 8; n++)
+            s += c[v][n] * t[n][u];
+          to[(by * 8 + v) * po + bx * 8 + u] = s;
+        }
+    }
+  return 0;
+}

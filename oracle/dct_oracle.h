@@ -1,0 +1,81 @@
+/*
+ * dct_oracle.h -- CPU restatement of the reference's 8x8 block-DCT hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (simd_dct_amd/, include/,
+ * the C-ABI library or the shim) may include, link or call this.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * Parity status
+ *   PINNED   (bit-exact vs the reference built from /root/reference with
+ *             `-O2 -ffp-contract=off`, see oracle/Makefile target `ref`, and vs the
+ *             SHA-256 known answers of SURVEY.md 8(c) / Appendix B):
+ *               orc_q32_avx            B1  simd_dct.cpp:2064-2262 (AVX2 == AVX-512VL tier)
+ *               orc_stereo_sse         B2  simd_dct.cpp:896-1103  (SSE4.1 == SSSE3 == SSE2 tier)
+ *               orc_encq_sse           B3  simd_dct.cpp:1540-1704 (SSE4.1 == SSSE3 tier)
+ *               orc_stereo_scalar      B4  simd_dct.cpp:177-298
+ *               orc_encq_scalar        B5  simd_dct.cpp:300-395
+ *   UNPINNED ("parity unpinned": the reference has no int16 / float32-out / inverse
+ *             path at all; these restate the engine's OWN arithmetic definition):
+ *               orc_fwd_i16, orc_inv_i16, orc_roundtrip_i16, orc_fwd_f32, orc_fwd_f64ref
+ *
+ * All arithmetic is IEEE-754 binary32, one rounding per written operation, no FMA
+ * (compile with -ffp-contract=off, never -ffast-math).
+ */
+#ifndef DCT_ORACLE_H
+#define DCT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 1-D 8-point kernels, in place on p[0], p[stride], ... p[7*stride].
+ * which: 0 = K_AVX  (simd_dct.cpp:2158-2184, k=3 sign quirk, pairwise association)
+ *        1 = K_SSE  (simd_dct.cpp:434-654 / 672-892, k=1 sign quirk)
+ *        2 = K_TRUE (simd_dct.cpp:138-172, left-to-right association, correct DCT-II)
+ *        3 = K_OWN  (engine's own: K_TRUE signs, K_AVX association)  [unpinned]        */
+void orc_dct8(float *p, ptrdiff_t stride, int which);
+/* inverse of K_OWN (transposed flow graph) [unpinned] */
+void orc_idct8_own(float *p, ptrdiff_t stride);
+
+/* The five reference behaviours, with the reference's exact call semantics
+ * (top-half loop, inclusive endY, untouched output bytes stay untouched).
+ * Return 0 = sdr_Success, 1 = sdr_InvalidParameter, 2 = sdr_NotSupported. */
+int orc_q32_avx(const uint8_t *from, uint8_t *to, const float *lut, size_t sizeX, size_t sizeY, size_t startY, size_t endY);
+int orc_stereo_sse(const uint8_t *from, uint8_t *to, const float *lut, size_t sizeX, size_t sizeY, size_t startY, size_t endY);
+int orc_encq_sse(const uint8_t *from, uint8_t *to, const float *lut, size_t sizeX, size_t sizeY, size_t startY, size_t endY);
+int orc_stereo_scalar(const uint8_t *from, uint8_t *to, const float *lut, size_t sizeX, size_t sizeY, size_t startY, size_t endY);
+int orc_encq_scalar(const uint8_t *from, uint8_t *to, const float *lut, size_t sizeX, size_t sizeY, size_t startY, size_t endY);
+
+/* Engine-own variants [unpinned].  Planes are row-major with pitches in ELEMENTS,
+ * block rows [by0, by1) (units of 8 pixel rows) over the FULL plane, coefficient (v,u)
+ * of block (by,bx) stored in place at (by*8+v, bx*8+u).
+ * lut == NULL: no quantisation.  Otherwise q[i] = 1/(lut[i]) style scaling:
+ *   fwd:  c = rne(f * rq[i]),  rq[i] = 1.0f / lut[i]    (saturated to int16)
+ *   inv:  f = (float)c * lut[i]                                              */
+int orc_fwd_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
+                size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+int orc_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
+                size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+int orc_roundtrip_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
+                      size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+int orc_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
+                size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+int orc_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
+                size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+/* double-precision orthonormal DCT-II by the defining cosine sum (config 5 yardstick) */
+int orc_fwd_f64ref(const float *from, double *to, size_t pitch_in, size_t pitch_out,
+                   size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+
+/* u8 forward+quantise with the engine's full-plane, half-open block-row range and
+ * explicit pitches -- same arithmetic as B1 (profile 0) -- used to check the native
+ * C-ABI (mdct_fwd_quant_u8) rather than the reference-semantics shim. */
+int orc_q32_native(const uint8_t *from, uint8_t *to, size_t pitch_in, const float *lut,
+                   size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

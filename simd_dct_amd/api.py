@@ -1,0 +1,201 @@
+"""Host-side mirror of the reference's operator interface, on device tensors.
+
+Two levels, both thin wrappers over the C-ABI (include/mdct.h):
+
+* the reference's own three functions, same names / argument order / result codes
+  (simd_dct.h:22-31) -- ``simdDCT_EncodeQuantize32ReorderBuffer`` etc.  They accept torch
+  uint8 tensors on ``cuda`` (zero-copy) or on the CPU / numpy arrays (staged by the shim).
+* the engine's native entry points with half-open block-row ranges and pitches.
+
+torch is used for device memory and streams only.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+sdr_Success, sdr_InvalidParameter, sdr_NotSupported = 0, 1, 2  # simd_dct.h:22-27
+
+PROFILE_REF_AVX, PROFILE_REF_SSE, PROFILE_REF_SCALAR = 0, 1, 2
+LAYOUT_Q32, LAYOUT_STEREO, LAYOUT_BLOCK, LAYOUT_BLOCK_SSE = 0, 1, 2, 3
+
+# main.cpp:179-189, the harness's base quantisation table (data, index v*8+u)
+QUANTIZE_BASE = np.array(
+    [.17, .11, .10, .16, .24, .40, .51, .61, .12, .12, .14, .19, .26, .58, .60, .55,
+     .14, .13, .16, .24, .40, .57, .69, .56, .14, .17, .22, .29, .51, .87, .80, .62,
+     .18, .22, .37, .56, .68, 1.09, 1.03, .77, .24, .35, .55, .64, .81, 1.04, 1.13, .92,
+     .49, .64, .78, .87, 1.03, 1.21, 1.20, 1.01, .72, .92, .95, .98, 1.12, 1.00, 1.03, .99],
+    dtype=np.float32)
+
+
+class MdctError(RuntimeError):
+    pass
+
+
+def last_error():
+    return _lib.load().mdct_last_error().decode()
+
+
+def _check(rc):
+    if rc != 0:
+        raise MdctError(f"mdct status {rc}: {last_error()}")
+
+
+def _lut_ptr(lut):
+    if lut is None:
+        return None, None
+    a = np.ascontiguousarray(np.asarray(lut, dtype=np.float32).reshape(64))
+    return a, a.ctypes.data_as(_lib.f32p)
+
+
+def _ptr(t):
+    """address of a torch tensor (any device) or numpy array"""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        return t.ctypes.data
+    return t.data_ptr()
+
+
+def _stream(stream=None):
+    if stream is not None:
+        return ctypes.c_void_p(int(stream))
+    import torch
+
+    if torch.cuda.is_available():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return None
+
+
+def init(device=0):
+    """mdct_init: replaces _DetectCPUFeatures() (simd_platform.c:68)."""
+    _check(_lib.load().mdct_init(int(device)))
+
+
+def device_info():
+    info = _lib.DeviceInfo()
+    _check(_lib.load().mdct_get_device_info(ctypes.byref(info)))
+    return {
+        "device": info.device, "compute_units": info.compute_units, "wavefront_size": info.wavefront_size,
+        "lds_bytes_per_cu": info.lds_bytes_per_cu, "is_gfx950": bool(info.is_gfx950),
+        "hbm_bytes": info.hbm_bytes, "name": info.name.decode(),
+    }
+
+
+# ----------------------------------------------------------------------------- reference API
+def _ref_call(which, pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY):
+    keep, lp = _lut_ptr(pQuantizeLUT)
+    return _lib.load().mdct_shim_call(which, _ptr(pFrom), _ptr(pTo), lp, sizeX, sizeY, startY, endY)
+
+
+def simdDCT_EncodeQuantize32ReorderBuffer(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY):
+    """simd_dct.h:31 / simd_dct.cpp:113-133.  Returns the simdDctResult value."""
+    return _ref_call(0, pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY)
+
+
+def simdDCT_EncodeQuantizeReorderStereoBuffer(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY):
+    """simd_dct.h:30 / simd_dct.cpp:71-91."""
+    return _ref_call(1, pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY)
+
+
+def simdDCT_EncodeQuantizeBuffer(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY):
+    """simd_dct.h:29 / simd_dct.cpp:93-111."""
+    return _ref_call(2, pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY)
+
+
+def set_max_simd(level):
+    """Counterpart of `--max-simd` (main.cpp:283-438): 0 none/scalar, 1 SSE, 2 AVX2 (default)."""
+    _lib.load().mdct_shim_set_max_simd(int(level))
+
+
+# -------------------------------------------------------------------------------- native API
+def fwd_quant_u8(src, dst, lut, sizeX, sizeY, by0, by1, layout=LAYOUT_Q32, profile=PROFILE_REF_AVX, pitch_in=None, stream=None, check=True):
+    keep, lp = _lut_ptr(lut)
+    rc = _lib.load().mdct_fwd_quant_u8(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, lp, sizeX, sizeY, by0, by1, layout, profile, _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+def _plane(fn, src, dst, lut, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check):
+    keep, lp = _lut_ptr(lut)
+    by1 = sizeY // 8 if by1 is None else by1
+    rc = fn(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, sizeX if pitch_out is None else pitch_out, lp, sizeX, sizeY, by0, by1, _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+def fwd_i16(src, dst, sizeX, sizeY, lut=None, by0=0, by1=None, pitch_in=None, pitch_out=None, stream=None, check=True):
+    return _plane(_lib.load().mdct_fwd_i16, src, dst, lut, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check)
+
+
+def inv_i16(src, dst, sizeX, sizeY, lut=None, by0=0, by1=None, pitch_in=None, pitch_out=None, stream=None, check=True):
+    return _plane(_lib.load().mdct_inv_i16, src, dst, lut, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check)
+
+
+def roundtrip_i16(src, dst, sizeX, sizeY, lut=None, by0=0, by1=None, pitch_in=None, pitch_out=None, stream=None, check=True):
+    return _plane(_lib.load().mdct_roundtrip_i16, src, dst, lut, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check)
+
+
+def _plane_f32(fn, src, dst, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check):
+    by1 = sizeY // 8 if by1 is None else by1
+    rc = fn(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, sizeX if pitch_out is None else pitch_out, sizeX, sizeY, by0, by1, _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+def fwd_f32(src, dst, sizeX, sizeY, by0=0, by1=None, pitch_in=None, pitch_out=None, stream=None, check=True):
+    return _plane_f32(_lib.load().mdct_fwd_f32, src, dst, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check)
+
+
+def inv_f32(src, dst, sizeX, sizeY, by0=0, by1=None, pitch_in=None, pitch_out=None, stream=None, check=True):
+    return _plane_f32(_lib.load().mdct_inv_f32, src, dst, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check)
+
+
+def roundtrip_i16_planes(planes, stream=None, check=True):
+    """planes: list of (src, dst, sizeX, sizeY, lut-or-None); one launch per 4 planes."""
+    arr = (_lib.PlaneI16 * len(planes))()
+    keep = []
+    for i, (src, dst, sx, sy, lut) in enumerate(planes):
+        k, lp = _lut_ptr(lut)
+        keep.append(k)
+        arr[i] = _lib.PlaneI16(_ptr(src), _ptr(dst), sx, sx, sx, sy, lp)
+    rc = _lib.load().mdct_roundtrip_i16_planes(arr, len(planes), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+def stream_copy(src, dst, nbytes, stream=None):
+    _check(_lib.load().mdct_stream_copy(_ptr(src), _ptr(dst), nbytes, _stream(stream)))
+
+
+class Timer:
+    """HIP-event timer on the stream the kernels are launched on (mdct_timer_*)."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self._t = self._lib.mdct_timer_create()
+        if not self._t:
+            raise MdctError(last_error())
+
+    def start(self, stream=None):
+        _check(self._lib.mdct_timer_start(self._t, _stream(stream)))
+
+    def stop(self, stream=None):
+        _check(self._lib.mdct_timer_stop(self._t, _stream(stream)))
+
+    def elapsed_ms(self):
+        ms = self._lib.mdct_timer_elapsed_ms(self._t)
+        if ms < 0:
+            raise MdctError(last_error())
+        return ms
+
+    def __del__(self):
+        try:
+            self._lib.mdct_timer_destroy(self._t)
+        except Exception:
+            pass

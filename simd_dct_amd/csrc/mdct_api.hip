@@ -1,0 +1,398 @@
+// mdct_api.hip -- the extern "C" boundary of libmdct_hip.so (declared in include/mdct.h).
+//
+// Thin by design: validate like the reference's dispatchers (simd_dct.cpp:71-133), build the
+// 64-entry multiplier table on the host with the reference's exact float expression,
+// fill a by-value argument block and launch.  No allocation, no synchronisation and no
+// host<->device copy on any launch path (hipGraph-capturable).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "mdct.h"
+#include "mdct_kernels.h"
+
+namespace
+{
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+  return fail(MDCT_NOT_SUPPORTED, "%s: %s", what, hipGetErrorString(e));
+}
+
+constexpr int kMaxDevices = 64;
+std::mutex g_mu;
+mdct_device_info g_info[kMaxDevices];
+bool g_have[kMaxDevices];
+
+// Replaces the x86 CPUID probe (simd_platform.c:68-178) with a HIP device probe.
+int probe(int device, const mdct_device_info **out)
+{
+  if (device < 0 || device >= kMaxDevices)
+    return fail(MDCT_INVALID_PARAMETER, "device ordinal %d out of range", device);
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_have[device])
+  {
+    hipDeviceProp_t p;
+    const hipError_t e = hipGetDeviceProperties(&p, device);
+    if (e != hipSuccess)
+      return hip_fail(e, "hipGetDeviceProperties");
+    mdct_device_info &i = g_info[device];
+    memset(&i, 0, sizeof(i));
+    i.device = device;
+    i.compute_units = p.multiProcessorCount;
+    i.wavefront_size = p.warpSize;
+    i.lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+    i.hbm_bytes = p.totalGlobalMem;
+    snprintf(i.name, sizeof(i.name), "%s", p.gcnArchName);
+    i.is_gfx950 = strncmp(p.gcnArchName, "gfx950", 6) == 0;
+    g_have[device] = true;
+  }
+  if (out)
+    *out = &g_info[device];
+  return MDCT_SUCCESS;
+}
+
+int current(const mdct_device_info **out)
+{
+  int dev = 0;
+  const hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return hip_fail(e, "hipGetDevice (is a HIP device visible?)");
+  const int r = probe(dev, out);
+  if (r != MDCT_SUCCESS)
+    return r;
+  if (!(*out)->is_gfx950 || (*out)->wavefront_size != 64)
+    return fail(MDCT_NOT_SUPPORTED, "device %d is %s; this library contains gfx950 (wave64) code only", dev, (*out)->name);
+  return MDCT_SUCCESS;
+}
+
+// blocks in [by0,by1) x bpr must fit the kernels' 32-bit linear block index
+int count_blocks(size_t bpr, size_t rows, uint32_t *n)
+{
+  const size_t total = bpr * rows;
+  if (bpr > 0xFFFFFFFFull || (rows != 0 && total / rows != bpr) || total > 0x7FFFFFFFull)
+    return fail(MDCT_NOT_SUPPORTED, "launch of %zu x %zu blocks exceeds the 2^31 block limit; split the row range", bpr, rows);
+  *n = (uint32_t)total;
+  return MDCT_SUCCESS;
+}
+
+bool table_needs_safe(const float *q)
+{
+  for (int i = 0; i < 64; i++)
+    if (!std::isfinite(q[i]) || std::fabs(q[i]) > 1048576.0f)
+      return true;
+  return false;
+}
+
+int own_plane_args(const void *from, const void *to, size_t esz, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1)
+{
+  if (from == nullptr || to == nullptr)
+    return fail(MDCT_INVALID_PARAMETER, "null plane pointer");
+  if (sizeX % 8 != 0 || sizeY % 8 != 0)
+    return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu is not a multiple of 8x8", sizeX, sizeY);
+  if (pitch_in < sizeX || pitch_out < sizeX || by0 > by1 || by1 > sizeY / 8)
+    return fail(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows", by0, by1, sizeY / 8);
+  if (((uintptr_t)from | (uintptr_t)to | (pitch_in * esz) | (pitch_out * esz)) & 15)
+    return fail(MDCT_INVALID_PARAMETER, "plane rows must be 16-byte aligned");
+  return MDCT_SUCCESS;
+}
+
+void make_lut_pair(const float *lut, mdct::LutPair &lp)
+{
+  for (int i = 0; i < 64; i++)
+  {
+    lp.lut[i] = lut ? lut[i] : 1.0f;
+    lp.rq[i] = lut ? 1.0f / lut[i] : 1.0f;
+  }
+}
+
+int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  // arguments first (like the reference's dispatchers), device second
+  int r = own_plane_args(from, to, sizeof(int16_t), pitch_in, pitch_out, sizeX, sizeY, by0, by1);
+  if (r)
+    return r;
+  const mdct_device_info *di;
+  if ((r = current(&di)))
+    return r;
+  mdct::I16Args a;
+  a.from = from;
+  a.to = to;
+  a.pitch_in = pitch_in;
+  a.pitch_out = pitch_out;
+  a.bpr = (uint32_t)(sizeX / 8);
+  a.by0 = (uint32_t)by0;
+  if ((r = count_blocks(sizeX / 8, by1 - by0, &a.nblocks)))
+    return r;
+  make_lut_pair(lut, a.lp);
+  const hipError_t e = mdct::launch_i16(a, mode, lut != nullptr, (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "i16 kernel launch");
+}
+
+int run_f32(int mode, const float *from, float *to, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  int r = own_plane_args(from, to, sizeof(float), pitch_in, pitch_out, sizeX, sizeY, by0, by1);
+  if (r)
+    return r;
+  const mdct_device_info *di;
+  if ((r = current(&di)))
+    return r;
+  mdct::F32Args a;
+  a.from = from;
+  a.to = to;
+  a.pitch_in = pitch_in;
+  a.pitch_out = pitch_out;
+  a.bpr = (uint32_t)(sizeX / 8);
+  a.by0 = (uint32_t)by0;
+  if ((r = count_blocks(sizeX / 8, by1 - by0, &a.nblocks)))
+    return r;
+  const hipError_t e = mdct::launch_f32(a, mode, (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "f32 kernel launch");
+}
+
+} // namespace
+
+extern "C" {
+
+int mdct_init(int device)
+{
+  const hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess)
+    return hip_fail(e, "hipSetDevice");
+  const mdct_device_info *di;
+  return current(&di);
+}
+
+int mdct_get_device_info(mdct_device_info *info)
+{
+  if (!info)
+    return fail(MDCT_INVALID_PARAMETER, "null info");
+  int dev = 0;
+  const hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return hip_fail(e, "hipGetDevice");
+  const mdct_device_info *di;
+  const int r = probe(dev, &di);
+  if (r)
+    return r;
+  *info = *di;
+  return MDCT_SUCCESS;
+}
+
+const char *mdct_last_error(void) { return g_err; }
+
+int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int layout, int profile, void *stream)
+{
+  // argument checks in the order of the reference dispatchers: null -> 1, shape -> 2
+  // (simd_dct.cpp:75-76, :97-98, :117-118); the table is not null-checked there, here it is.
+  if (from == nullptr || to == nullptr || lut == nullptr)
+    return fail(MDCT_INVALID_PARAMETER, "null pointer");
+  const bool combo = (layout == MDCT_LAYOUT_Q32 && profile == MDCT_PROFILE_REF_AVX) || (layout == MDCT_LAYOUT_STEREO && (profile == MDCT_PROFILE_REF_SSE || profile == MDCT_PROFILE_REF_SCALAR)) ||
+                     (layout == MDCT_LAYOUT_BLOCK && profile == MDCT_PROFILE_REF_SCALAR) || (layout == MDCT_LAYOUT_BLOCK_SSE && profile == MDCT_PROFILE_REF_SSE);
+  if (!combo)
+    return fail(MDCT_NOT_SUPPORTED, "layout %d with profile %d is not a reference tier", layout, profile);
+  const size_t xmul = layout == MDCT_LAYOUT_Q32 ? 64 : ((profile == MDCT_PROFILE_REF_SSE) ? 16 : 8);
+  const size_t ymul = layout == MDCT_LAYOUT_STEREO ? 16 : 8;
+  if (sizeX == 0 || sizeX % xmul != 0 || sizeY % ymul != 0)
+    return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu: width must be a multiple of %zu and height of %zu for this layout", sizeX, sizeY, xmul, ymul);
+  if (pitch_in < sizeX || by0 > by1 || by1 > sizeY / ymul)
+    return fail(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows", by0, by1, sizeY / ymul);
+
+  const mdct_device_info *di;
+  int r = current(&di);
+  if (r)
+    return r;
+
+  mdct::U8Args a;
+  memset(&a, 0, sizeof(a));
+  a.from = from;
+  a.to = to;
+  constexpr float vr = .95f;
+  for (int i = 0; i < 64; i++) // simd_dct.cpp:2239, :910 (x255 tiers) / :192 (scalar tiers)
+    a.qt.q[i] = profile == MDCT_PROFILE_REF_SCALAR ? 1.f / (lut[i] * vr) : 255.0f / (lut[i] * vr);
+  a.pitch = pitch_in;
+  a.sizeX = sizeX;
+  a.eye_offset = pitch_in * (sizeY / 2);
+  a.plane_stride = (sizeX * sizeY) / 64;
+  a.bpr = (uint32_t)(sizeX / 8);
+  a.by0 = (uint32_t)by0;
+  a.by_last = by1 > by0 ? (uint32_t)(by1 - 1) : 0;
+  const size_t rows = (by1 - by0) * (layout == MDCT_LAYOUT_STEREO ? 2 : 1);
+  if ((r = count_blocks(sizeX / 8, rows, &a.nblocks)))
+    return r;
+  a.aligned8 = ((((uintptr_t)from) | pitch_in) & 7) == 0;
+  a.spill_ok = by1 * 8 * sizeX + 64 <= sizeX * sizeY;
+  const bool safe = profile != MDCT_PROFILE_REF_SCALAR && table_needs_safe(a.qt.q);
+  const hipError_t e = mdct::launch_fwd_quant_u8(a, layout, profile, safe, (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "u8 kernel launch");
+}
+
+int mdct_fwd_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  return run_i16(mdct::MODE_FWD, from, to, pitch_in, pitch_out, lut, sizeX, sizeY, by0, by1, stream);
+}
+
+int mdct_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  return run_i16(mdct::MODE_INV, from, to, pitch_in, pitch_out, lut, sizeX, sizeY, by0, by1, stream);
+}
+
+int mdct_roundtrip_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  return run_i16(mdct::MODE_ROUNDTRIP, from, to, pitch_in, pitch_out, lut, sizeX, sizeY, by0, by1, stream);
+}
+
+int mdct_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  return run_f32(mdct::MODE_FWD, from, to, pitch_in, pitch_out, sizeX, sizeY, by0, by1, stream);
+}
+
+int mdct_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  return run_f32(mdct::MODE_INV, from, to, pitch_in, pitch_out, sizeX, sizeY, by0, by1, stream);
+}
+
+int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *stream)
+{
+  if (planes == nullptr || n_planes < 0)
+    return fail(MDCT_INVALID_PARAMETER, "null plane list");
+  // validate everything before launching anything
+  int r = MDCT_SUCCESS;
+  for (int i = 0; i < n_planes; i++)
+  {
+    const mdct_plane_i16 &p = planes[i];
+    if ((r = own_plane_args(p.from, p.to, sizeof(int16_t), p.pitch_in, p.pitch_out, p.sizeX, p.sizeY, 0, p.sizeY / 8)))
+      return r;
+  }
+  const mdct_device_info *di;
+  if ((r = current(&di)))
+    return r;
+  for (int base = 0; base < n_planes; base += mdct::kMaxPlanes)
+  {
+    mdct::PlaneBatchArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n_planes - base < mdct::kMaxPlanes ? n_planes - base : mdct::kMaxPlanes;
+    uint64_t run = 0;
+    for (int i = 0; i < a.n; i++)
+    {
+      const mdct_plane_i16 &p = planes[base + i];
+      a.from[i] = p.from;
+      a.to[i] = p.to;
+      a.pitch_in[i] = p.pitch_in;
+      a.pitch_out[i] = p.pitch_out;
+      a.bpr[i] = (uint32_t)(p.sizeX / 8);
+      if ((r = count_blocks(p.sizeX / 8, p.sizeY / 8, &a.nblk[i])))
+        return r;
+      a.prefix[i] = (uint32_t)run;
+      run += ((uint64_t)a.nblk[i] + 63) / 64 * 64;
+      if (run > 0x7FFFFFFFull)
+        return fail(MDCT_NOT_SUPPORTED, "plane batch exceeds the 2^31 block limit");
+      a.has_lut[i] = p.lut != nullptr;
+      make_lut_pair(p.lut, a.lp[i]);
+    }
+    a.prefix[a.n] = (uint32_t)run;
+    const hipError_t e = mdct::launch_i16_planes(a, (hipStream_t)stream);
+    if (e != hipSuccess)
+      return hip_fail(e, "plane batch launch");
+  }
+  return MDCT_SUCCESS;
+}
+
+int mdct_stream_copy(const void *from, void *to, size_t bytes, void *stream)
+{
+  if (from == nullptr || to == nullptr)
+    return fail(MDCT_INVALID_PARAMETER, "null pointer");
+  if ((((uintptr_t)from | (uintptr_t)to | bytes) & 15) != 0)
+    return fail(MDCT_INVALID_PARAMETER, "stream copy needs 16-byte aligned pointers and size");
+  const mdct_device_info *di;
+  const int r = current(&di);
+  if (r)
+    return r;
+  const hipError_t e = mdct::launch_stream_copy(from, to, bytes, di->compute_units, (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "stream copy launch");
+}
+
+struct mdct_timer
+{
+  hipEvent_t t0, t1;
+};
+
+mdct_timer *mdct_timer_create(void)
+{
+  mdct_timer *t = new mdct_timer;
+  if (hipEventCreate(&t->t0) != hipSuccess || hipEventCreate(&t->t1) != hipSuccess)
+  {
+    fail(MDCT_NOT_SUPPORTED, "hipEventCreate failed");
+    delete t;
+    return nullptr;
+  }
+  return t;
+}
+
+void mdct_timer_destroy(mdct_timer *t)
+{
+  if (!t)
+    return;
+  (void)hipEventDestroy(t->t0);
+  (void)hipEventDestroy(t->t1);
+  delete t;
+}
+
+int mdct_timer_start(mdct_timer *t, void *stream)
+{
+  if (!t)
+    return fail(MDCT_INVALID_PARAMETER, "null timer");
+  const hipError_t e = hipEventRecord(t->t0, (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "hipEventRecord");
+}
+
+int mdct_timer_stop(mdct_timer *t, void *stream)
+{
+  if (!t)
+    return fail(MDCT_INVALID_PARAMETER, "null timer");
+  const hipError_t e = hipEventRecord(t->t1, (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "hipEventRecord");
+}
+
+double mdct_timer_elapsed_ms(mdct_timer *t)
+{
+  if (!t)
+    return -1.0;
+  hipError_t e = hipEventSynchronize(t->t1);
+  if (e != hipSuccess)
+  {
+    hip_fail(e, "hipEventSynchronize");
+    return -1.0;
+  }
+  float ms = 0.f;
+  e = hipEventElapsedTime(&ms, t->t0, t->t1);
+  if (e != hipSuccess)
+  {
+    hip_fail(e, "hipEventElapsedTime");
+    return -1.0;
+  }
+  return (double)ms;
+}
+
+int mdct_stream_synchronize(void *stream)
+{
+  const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "hipStreamSynchronize");
+}
+
+} // extern "C"

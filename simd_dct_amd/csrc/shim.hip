@@ -1,0 +1,216 @@
+// shim.hip -- the reference's three public functions (simd_dct.h:29-31) on top of the C-ABI.
+//
+// Translates the reference's call semantics (top-half loop, inclusive endY, tier choice)
+// into the engine's half-open block-row ranges, and serves host pointers by staging
+// the touched rows through HBM.  Re-entrant: staging buffers are per thread.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstring>
+
+#include "mdct.h"
+#include "simd_dct_shim.h"
+
+namespace
+{
+
+std::atomic<int> g_max_simd{2};
+std::atomic<void *> g_stream{nullptr};
+std::atomic<int> g_async{0};
+
+struct Staging
+{
+  uint8_t *in = nullptr, *out = nullptr;
+  size_t in_cap = 0, out_cap = 0;
+  int device = -1;
+};
+thread_local Staging tl_stage;
+
+void release(Staging &s)
+{
+  if (s.in)
+    (void)hipFree(s.in);
+  if (s.out)
+    (void)hipFree(s.out);
+  s = Staging();
+}
+
+bool reserve(uint8_t *&p, size_t &cap, size_t need)
+{
+  if (cap >= need)
+    return true;
+  if (p)
+    (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+  // grow-only with slack so that a loop over similar sizes allocates once
+  const size_t want = need + need / 8 + 4096;
+  if (hipMalloc((void **)&p, want) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return false;
+  }
+  cap = want;
+  return true;
+}
+
+bool is_device_ptr(const void *p)
+{
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess)
+  {
+    (void)hipGetLastError(); // plain malloc memory on older runtimes
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// Block rows the reference's loop `for (y = 0; y < sizeY/2; y += 8)` processes
+// (simd_dct.cpp:2243-2261): step = 16 for the `y*2` tiers, 8 for the scalar encq tier (:375-387).
+void ref_range(size_t sizeY, size_t startY, size_t endY, size_t step, size_t *b0, size_t *b1)
+{
+  const size_t rows = ceil_div(sizeY / 2, 8);
+  *b0 = ceil_div(startY, step);
+  const size_t last = endY / step + 1;
+  *b1 = last < rows ? last : rows;
+  if (*b0 > *b1)
+    *b0 = *b1;
+}
+
+simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t sizeX, size_t sizeY, size_t b0, size_t b1, int layout, int profile)
+{
+  if (b0 >= b1)
+    return sdr_Success;
+  const bool dev_in = is_device_ptr(pFrom), dev_out = is_device_ptr(pTo);
+  void *stream = g_stream.load();
+
+  if (dev_in && dev_out)
+  {
+    int r = mdct_fwd_quant_u8(pFrom, pTo, sizeX, lut, sizeX, sizeY, b0, b1, layout, profile, stream);
+    if (r == MDCT_SUCCESS && !g_async.load())
+      r = mdct_stream_synchronize(stream);
+    return (simdDctResult)r;
+  }
+
+  // Host path.  Input: the touched pixel rows only.  Output: Q32/BLOCK write whole row
+  // strips; STEREO and BLOCK_SSE write scattered bytes, so their destination is first
+  // mirrored into HBM to keep untouched bytes untouched.
+  Staging &st = tl_stage;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (st.device != dev)
+  {
+    release(st);
+    st.device = dev;
+  }
+  const size_t total = sizeX * sizeY;
+  const bool scattered = layout == MDCT_LAYOUT_STEREO || layout == MDCT_LAYOUT_BLOCK_SSE;
+  const uint8_t *d_in = pFrom;
+  uint8_t *d_out = pTo;
+  hipStream_t hs = (hipStream_t)stream;
+
+  if (!dev_in)
+  {
+    // STEREO reads both halves of the plane; stage all of it.  Others: rows [b0*8, b1*8).
+    const size_t off = layout == MDCT_LAYOUT_STEREO ? 0 : b0 * 8 * sizeX;
+    const size_t len = layout == MDCT_LAYOUT_STEREO ? total : (b1 - b0) * 8 * sizeX;
+    if (!reserve(st.in, st.in_cap, total))
+      return sdr_NotSupported;
+    if (hipMemcpyAsync(st.in + off, pFrom + off, len, hipMemcpyHostToDevice, hs) != hipSuccess)
+      return sdr_NotSupported;
+    d_in = st.in;
+  }
+  if (!dev_out)
+  {
+    if (!reserve(st.out, st.out_cap, total))
+      return sdr_NotSupported;
+    if (scattered && hipMemcpyAsync(st.out, pTo, total, hipMemcpyHostToDevice, hs) != hipSuccess)
+      return sdr_NotSupported;
+    d_out = st.out;
+  }
+
+  int r = mdct_fwd_quant_u8(d_in, d_out, sizeX, lut, sizeX, sizeY, b0, b1, layout, profile, stream);
+  if (r != MDCT_SUCCESS)
+    return (simdDctResult)r;
+
+  if (!dev_out)
+  {
+    const size_t off = scattered ? 0 : b0 * 8 * sizeX;
+    const size_t len = scattered ? total : (b1 - b0) * 8 * sizeX;
+    if (hipMemcpyAsync(pTo + off, st.out + off, len, hipMemcpyDeviceToHost, hs) != hipSuccess)
+      return sdr_NotSupported;
+  }
+  if (!dev_out || !g_async.load())
+    r = mdct_stream_synchronize(stream);
+  return (simdDctResult)r;
+}
+
+} // namespace
+
+// simd_dct.cpp:113-133
+simdDctResult simdDCT_EncodeQuantize32ReorderBuffer(const uint8_t *pFrom, uint8_t *pTo, const float *pQuantizeLUT, const size_t sizeX, const size_t sizeY, const size_t startY, const size_t endY)
+{
+  if (pFrom == nullptr || pTo == nullptr)
+    return sdr_InvalidParameter;
+  if ((sizeX & ~(size_t)63) != sizeX || (sizeY & ~(size_t)7) != sizeY)
+    return sdr_NotSupported;
+  if (g_max_simd.load() < 2)
+    return sdr_NotSupported; // :127, no scalar tier exists
+  size_t b0, b1;
+  ref_range(sizeY, startY, endY, 16, &b0, &b1);
+  return run(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, b0, b1, MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX);
+}
+
+// simd_dct.cpp:71-91
+simdDctResult simdDCT_EncodeQuantizeReorderStereoBuffer(const uint8_t *pFrom, uint8_t *pTo, const float *pQuantizeLUT, const size_t sizeX, const size_t sizeY, const size_t startY, const size_t endY)
+{
+  if (pFrom == nullptr || pTo == nullptr)
+    return sdr_InvalidParameter;
+  if ((sizeX & ~(size_t)7) != sizeX || (sizeY & ~(size_t)7) != sizeY)
+    return sdr_NotSupported;
+  size_t b0, b1;
+  ref_range(sizeY, startY, endY, 16, &b0, &b1);
+  const int profile = g_max_simd.load() >= 1 ? MDCT_PROFILE_REF_SSE : MDCT_PROFILE_REF_SCALAR;
+  return run(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, b0, b1, MDCT_LAYOUT_STEREO, profile);
+}
+
+// simd_dct.cpp:93-111
+simdDctResult simdDCT_EncodeQuantizeBuffer(const uint8_t *pFrom, uint8_t *pTo, const float *pQuantizeLUT, const size_t sizeX, const size_t sizeY, const size_t startY, const size_t endY)
+{
+  if (pFrom == nullptr || pTo == nullptr)
+    return sdr_InvalidParameter;
+  if ((sizeX & ~(size_t)7) != sizeX || (sizeY & ~(size_t)7) != sizeY)
+    return sdr_NotSupported;
+  size_t b0, b1;
+  if (g_max_simd.load() >= 1)
+  {
+    ref_range(sizeY, startY, endY, 16, &b0, &b1);
+    return run(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, b0, b1, MDCT_LAYOUT_BLOCK_SSE, MDCT_PROFILE_REF_SSE);
+  }
+  ref_range(sizeY, startY, endY, 8, &b0, &b1);
+  return run(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, b0, b1, MDCT_LAYOUT_BLOCK, MDCT_PROFILE_REF_SCALAR);
+}
+
+extern "C" {
+
+void mdct_shim_set_max_simd(int level) { g_max_simd.store(level < 0 ? 0 : (level > 2 ? 2 : level)); }
+void mdct_shim_set_stream(void *stream) { g_stream.store(stream); }
+void mdct_shim_set_async(int enabled) { g_async.store(enabled != 0); }
+void mdct_shim_release(void) { release(tl_stage); }
+
+// C handles onto the C++-linkage functions above, for FFI callers (ctypes / cgo / JNI)
+// that cannot spell Itanium-mangled names.  which: 0 q32, 1 stereo, 2 encq.
+int mdct_shim_call(int which, const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t sizeX, size_t sizeY, size_t startY, size_t endY)
+{
+  switch (which)
+  {
+  case 0: return (int)simdDCT_EncodeQuantize32ReorderBuffer(pFrom, pTo, lut, sizeX, sizeY, startY, endY);
+  case 1: return (int)simdDCT_EncodeQuantizeReorderStereoBuffer(pFrom, pTo, lut, sizeX, sizeY, startY, endY);
+  case 2: return (int)simdDCT_EncodeQuantizeBuffer(pFrom, pTo, lut, sizeX, sizeY, startY, endY);
+  }
+  return MDCT_INVALID_PARAMETER;
+}
+
+} // extern "C"

@@ -1,0 +1,70 @@
+"""Generates tests/golden/ref_vectors.npz from the REAL reference (oracle/_ref, built from
+/root/reference/src by `make -C oracle ref` with the pinned flags -O2 -ffp-contract=off).
+
+Run in the build container only (the reference does not travel):
+    make -C oracle ref && python tests/golden/make_golden.py
+The .npz holds data only: synthetic inputs and the bytes the reference produced for them.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import oracle as O  # noqa: E402
+from simd_dct_amd import synth  # noqa: E402
+from simd_dct_amd.api import QUANTIZE_BASE  # noqa: E402
+
+W, H = 128, 64
+CANARY = 0xA5
+
+
+def main():
+    assert O.reference() is not None, "build oracle/_ref first: make -C oracle ref"
+    vec = {}
+    meta = {"W": W, "H": H, "canary": CANARY, "cases": []}
+    inputs = {"noise": synth.plane_u8_np(W, H, "noise"), "photo": synth.plane_u8_np(W, H, "photo")}
+    for k, v in inputs.items():
+        vec[f"in_{k}"] = v
+    scales = {"q32_avx": (2000.0, 100.0), "stereo_sse": (8.0, 1.0), "encq_sse": (8.0, 1.0), "stereo_scalar": (8.0,), "encq_scalar": (8.0,)}
+    ranges = [(0, H), (16, 32), (0, 0), (8, 40)]
+    for beh, scs in scales.items():
+        for si, sc in enumerate(scs):
+            lut = (QUANTIZE_BASE * np.float32(sc)).astype(np.float32)
+            for kind, img in inputs.items():
+                for ri, (y0, y1) in enumerate(ranges if si == 0 else ranges[:1]):
+                    out = np.full(W * H, CANARY, dtype=np.uint8)
+                    O.run_behaviour(beh, img, lut, W, H, y0, y1, out=out, use_reference=True)
+                    key = f"{beh}__{kind}__x{sc:g}__{y0}_{y1}"
+                    vec[key] = out
+                    meta["cases"].append({"key": key, "behaviour": beh, "input": kind, "scale": sc, "startY": y0, "endY": y1})
+    # q32 over the full plane through the sizeY = 2H call trick; the
+    # buffers are W*H, the reference is told 2H rows.
+    lut = (QUANTIZE_BASE * np.float32(2000.0)).astype(np.float32)
+    for kind, img in inputs.items():
+        out = np.full(W * H, CANARY, dtype=np.uint8)
+        O.run_behaviour("q32_avx", img, lut, W, 2 * H, 0, 2 * H, out=out, use_reference=True)
+        vec[f"q32_full__{kind}"] = out
+    # larger planes as hashes only
+    big = {}
+    for (bw, bh) in ((1024, 512),):
+        for kind in ("noise", "photo"):
+            img = synth.plane_u8_np(bw, bh, kind)
+            for beh, scs in scales.items():
+                lut = (QUANTIZE_BASE * np.float32(scs[0])).astype(np.float32)
+                rc, out = O.run_behaviour(beh, img, lut, bw, bh, 0, bh, use_reference=True)
+                big[f"{beh}__{kind}__{bw}x{bh}__x{scs[0]:g}"] = hashlib.sha256(out.tobytes()).hexdigest()
+    meta["sha256_zero_prefilled"] = big
+    np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **vec)
+    with open(os.path.join(HERE, "ref_vectors.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote", len(vec), "arrays,", len(big), "hashes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""ctypes access to the CHECKER: oracle/liboracle.so (the repo's plain-C restatement) and,
+when it has been built in the container that holds /root/reference, oracle/_ref/ (the real
+reference).  Test infrastructure -- never imported by the package."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libsimd_dct_ref.so")
+
+sz = ctypes.c_size_t
+vp = ctypes.c_void_p
+f32p = ctypes.POINTER(ctypes.c_float)
+
+_orc = None
+_ref = None
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def oracle():
+    global _orc
+    if _orc is None:
+        src_m = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("dct_oracle.c", "dct_oracle.h"))
+        if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < src_m:
+            build_oracle()
+        lib = ctypes.CDLL(ORACLE_SO)
+        for n in ("orc_q32_avx", "orc_stereo_sse", "orc_encq_sse", "orc_stereo_scalar", "orc_encq_scalar"):
+            getattr(lib, n).argtypes = [vp, vp, f32p, sz, sz, sz, sz]
+        lib.orc_q32_native.argtypes = [vp, vp, sz, f32p, sz, sz, sz, sz]
+        for n in ("orc_fwd_i16", "orc_inv_i16", "orc_roundtrip_i16"):
+            getattr(lib, n).argtypes = [vp, vp, sz, sz, f32p, sz, sz, sz, sz]
+        for n in ("orc_fwd_f32", "orc_inv_f32", "orc_fwd_f64ref"):
+            getattr(lib, n).argtypes = [vp, vp, sz, sz, sz, sz, sz, sz]
+        lib.orc_dct8.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_int]
+        lib.orc_idct8_own.argtypes = [vp, ctypes.c_ssize_t]
+        _orc = lib
+    return _orc
+
+
+def reference():
+    """the real reference build, or None (it exists only where oracle/Makefile `ref` ran)"""
+    global _ref
+    if _ref is None and os.path.exists(REF_SO):
+        lib = ctypes.CDLL(REF_SO)
+        lib.ref_call_tier.argtypes = [ctypes.c_int, vp, vp, f32p, sz, sz, sz, sz]
+        lib.ref_call_public.argtypes = [ctypes.c_int, vp, vp, f32p, sz, sz, sz, sz]
+        _ref = lib
+    return _ref
+
+
+def _lut(lut):
+    a = np.ascontiguousarray(np.asarray(lut, dtype=np.float32).reshape(64))
+    return a, a.ctypes.data_as(f32p)
+
+
+REF_FUNCS = {  # behaviour -> (oracle symbol, reference tier id in oracle/ref_driver.cpp)
+    "q32_avx": ("orc_q32_avx", 0),
+    "stereo_sse": ("orc_stereo_sse", 2),
+    "encq_sse": ("orc_encq_sse", 6),
+    "stereo_scalar": ("orc_stereo_scalar", 5),
+    "encq_scalar": ("orc_encq_scalar", 8),
+}
+
+
+def run_behaviour(name, img, lut, W, H, y0, y1, out=None, use_reference=False):
+    """img: uint8 array of W*H bytes.  out: pre-filled W*H buffer (canary) or None (zeros)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8).reshape(-1)
+    out = np.zeros(W * H, dtype=np.uint8) if out is None else out
+    keep, lp = _lut(lut)
+    sym, tier = REF_FUNCS[name]
+    if use_reference:
+        rc = reference().ref_call_tier(tier, img.ctypes.data, out.ctypes.data, lp, W, H, y0, y1)
+    else:
+        rc = getattr(oracle(), sym)(img.ctypes.data, out.ctypes.data, lp, W, H, y0, y1)
+    return rc, out
+
+
+def q32_native(img, lut, W, H, by0, by1, pitch=None, out=None):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.zeros(W * H, dtype=np.uint8) if out is None else out
+    keep, lp = _lut(lut)
+    rc = oracle().orc_q32_native(img.ctypes.data, out.ctypes.data, W if pitch is None else pitch, lp, W, H, by0, by1)
+    return rc, out
+
+
+def i16(mode, src, W, H, lut=None, by0=0, by1=None, out=None):
+    src = np.ascontiguousarray(src, dtype=np.int16)
+    out = np.zeros((H, W), dtype=np.int16) if out is None else out
+    lp = None
+    if lut is not None:
+        keep, lp = _lut(lut)
+    fn = getattr(oracle(), {"fwd": "orc_fwd_i16", "inv": "orc_inv_i16", "roundtrip": "orc_roundtrip_i16"}[mode])
+    rc = fn(src.ctypes.data, out.ctypes.data, W, W, lp, W, H, by0, H // 8 if by1 is None else by1)
+    assert rc == 0, rc
+    return out
+
+
+def f32(mode, src, W, H, by0=0, by1=None):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    out = np.zeros((H, W), dtype=np.float64 if mode == "f64ref" else np.float32)
+    fn = getattr(oracle(), {"fwd": "orc_fwd_f32", "inv": "orc_inv_f32", "f64ref": "orc_fwd_f64ref"}[mode])
+    rc = fn(src.ctypes.data, out.ctypes.data, W, W, W, H, by0, H // 8 if by1 is None else by1)
+    assert rc == 0, rc
+    return out

@@ -1,0 +1,272 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the oracle on
+the same seeded inputs, against the fixtures the real reference produced, and -- at
+BASELINE.json's full sizes -- through size-independent properties.  Bit-exact everywhere
+(u8 / int16 / float32 are all compared with array_equal); the only tolerance is config 5's
+float32-vs-double bound, stated where it is used."""
+import numpy as np
+import pytest
+
+import oracle as O
+import simd_dct_amd as M
+from simd_dct_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+CANARY = 0xA5
+BEHAVIOURS = {  # behaviour -> (reference-API function, --max-simd level, native layout, native profile)
+    "q32_avx": (M.simdDCT_EncodeQuantize32ReorderBuffer, 2, M.LAYOUT_Q32, M.PROFILE_REF_AVX),
+    "stereo_sse": (M.simdDCT_EncodeQuantizeReorderStereoBuffer, 2, M.LAYOUT_STEREO, M.PROFILE_REF_SSE),
+    "encq_sse": (M.simdDCT_EncodeQuantizeBuffer, 2, M.LAYOUT_BLOCK_SSE, M.PROFILE_REF_SSE),
+    "stereo_scalar": (M.simdDCT_EncodeQuantizeReorderStereoBuffer, 0, M.LAYOUT_STEREO, M.PROFILE_REF_SCALAR),
+    "encq_scalar": (M.simdDCT_EncodeQuantizeBuffer, 0, M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR),
+}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    torch.cuda.set_device(0)
+    M.init(0)
+    info = M.device_info()
+    assert info["is_gfx950"] and info["wavefront_size"] == 64, info
+    yield info
+    M.set_max_simd(2)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def lut_x(scale):
+    return (M.QUANTIZE_BASE * np.float32(scale)).astype(np.float32)
+
+
+def run_ref_api(beh, img_np, lut, W, H, y0, y1, host=False):
+    fn, level, _, _ = BEHAVIOURS[beh]
+    M.set_max_simd(level)
+    try:
+        if host:
+            out = np.full(W * H, CANARY, dtype=np.uint8)
+            rc = fn(np.ascontiguousarray(img_np).reshape(-1), out, lut, W, H, y0, y1)
+            return rc, out
+        src = dev(img_np.reshape(-1))
+        out = torch.full((W * H,), CANARY, dtype=torch.uint8, device="cuda")
+        rc = fn(src, out, lut, W, H, y0, y1)
+        torch.cuda.synchronize()
+        return rc, out.cpu().numpy()
+    finally:
+        M.set_max_simd(2)
+
+
+# ------------------------------------------------------------------ reference fixtures
+def test_reference_fixtures_through_the_drop_in_api(golden):
+    """the bytes the REAL reference wrote (tests/golden, incl. untouched canary bytes)"""
+    meta, vec = golden
+    W, H = meta["W"], meta["H"]
+    for c in meta["cases"]:
+        rc, out = run_ref_api(c["behaviour"], vec["in_" + c["input"]], lut_x(c["scale"]), W, H, c["startY"], c["endY"])
+        assert rc == 0, (c, M.last_error())
+        assert np.array_equal(out, vec[c["key"]]), c["key"]
+    for kind in ("noise", "photo"):  # sizeY = 2H call trick: full plane through the reference API
+        src = dev(vec["in_" + kind].reshape(-1))
+        out = torch.full((W * H,), CANARY, dtype=torch.uint8, device="cuda")
+        assert M.simdDCT_EncodeQuantize32ReorderBuffer(src, out, lut_x(2000), W, 2 * H, 0, 2 * H) == 0
+        assert np.array_equal(out.cpu().numpy(), vec[f"q32_full__{kind}"])
+
+
+def test_reference_fixtures_host_pointers(golden):
+    """same, with plain host memory in and out (the reference's only calling mode)"""
+    meta, vec = golden
+    W, H = meta["W"], meta["H"]
+    for c in meta["cases"]:
+        if c["scale"] not in (2000.0, 8.0):
+            continue
+        rc, out = run_ref_api(c["behaviour"], vec["in_" + c["input"]], lut_x(c["scale"]), W, H, c["startY"], c["endY"], host=True)
+        assert rc == 0, (c, M.last_error())
+        assert np.array_equal(out, vec[c["key"]]), c["key"]
+
+
+# ------------------------------------------------------------------ oracle, seeded inputs
+@pytest.mark.parametrize("beh", list(BEHAVIOURS))
+def test_reference_api_matches_oracle(beh):
+    rng = np.random.default_rng(2026)
+    for (W, H) in ((64, 16), (192, 48), (448, 80), (1024, 256)):
+        if "stereo" in beh and H % 16:
+            continue
+        for kind, scale in (("noise", 2000.0 if beh == "q32_avx" else 8.0), ("photo", 100.0 if beh == "q32_avx" else 1.0)):
+            img = synth.plane_u8_np(W, H, kind, seed=synth.SEED + W)
+            lut = (lut_x(scale) * rng.uniform(0.5, 2.0, 64).astype(np.float32)).astype(np.float32)
+            for (y0, y1) in ((0, H), (16, 32), (0, 0), (8, H // 2), (H, H)):
+                rc, got = run_ref_api(beh, img, lut, W, H, y0, y1)
+                want = np.full(W * H, CANARY, dtype=np.uint8)
+                rc2, want = O.run_behaviour(beh, img, lut, W, H, y0, y1, out=want)
+                assert rc == rc2 == 0
+                assert np.array_equal(got, want), (beh, W, H, kind, y0, y1, int((got != want).sum()))
+
+
+def test_q32_native_ranges_pitch_and_tails():
+    """native C-ABI: half-open full-plane ranges, input pitch > width, partial last wave,
+    untouched rows keep the canary, and disjoint ranges add up (the multi-GPU shard property)"""
+    for (W, H) in ((64, 8), (64, 24), (320, 40), (1984, 72), (4096, 64)):
+        pitch = W + 64
+        img = synth.plane_u8_np(pitch, H, "photo")  # a wider plane; the engine sees a W-wide window
+        lut = lut_x(2000)
+        src = dev(img)
+        rows = H // 8
+        for (b0, b1) in ((0, rows), (rows // 2, rows), (0, 1), (rows - 1, rows), (1, 1)):
+            out = torch.full((W * H,), CANARY, dtype=torch.uint8, device="cuda")
+            M.fwd_quant_u8(src, out, lut, W, H, b0, b1, pitch_in=pitch)
+            want = np.full(W * H, CANARY, dtype=np.uint8)
+            O.q32_native(img, lut, W, H, b0, b1, pitch=pitch, out=want)
+            assert np.array_equal(out.cpu().numpy(), want), (W, H, b0, b1)
+        parts = torch.full((W * H,), CANARY, dtype=torch.uint8, device="cuda")
+        cuts = sorted({0, rows // 3, rows // 2, rows})
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            M.fwd_quant_u8(src, parts, lut, W, H, a, b, pitch_in=pitch)
+        full = np.zeros(W * H, dtype=np.uint8)
+        O.q32_native(img, lut, W, H, 0, rows, pitch=pitch, out=full)
+        assert np.array_equal(parts.cpu().numpy(), full)
+
+
+def test_unaligned_input_pointer():
+    """the reference takes any alignment (unaligned loads, simd_dct.cpp:2109)"""
+    W, H = 128, 32
+    img = synth.plane_u8_np(W, H, "noise")
+    buf = torch.zeros(W * H + 16, dtype=torch.uint8, device="cuda")
+    for off in (1, 3, 4):
+        buf[off:off + W * H] = dev(img.reshape(-1))
+        out = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
+        assert M.simdDCT_EncodeQuantize32ReorderBuffer(buf[off:], out, lut_x(2000), W, 2 * H, 0, 2 * H) == 0
+        rc, want = O.q32_native(img, lut_x(2000), W, H, 0, H // 8)
+        assert np.array_equal(out.cpu().numpy(), want), off
+
+
+def test_extreme_tables_integer_indefinite_corner():
+    """cvtps_epi32 returns 0x80000000 for NaN / out-of-range: exercised with
+    zero, tiny, negative, infinite and NaN table entries (the SAFE kernel variant)"""
+    W, H = 64, 32
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, W * H, dtype=np.uint8)
+    img[: W * 8] = 0
+    for special in (1e-4, 1e-7, 0.0, -0.3, np.inf, np.nan, 1e-30, 3e38):
+        lut = M.QUANTIZE_BASE.copy()
+        lut[::3] = special
+        for beh in BEHAVIOURS:
+            rc, got = run_ref_api(beh, img, lut, W, H, 0, H)
+            want = np.full(W * H, CANARY, dtype=np.uint8)
+            O.run_behaviour(beh, img, lut, W, H, 0, H, out=want)
+            assert rc == 0 and np.array_equal(got, want), (beh, special, int((got != want).sum()))
+
+
+def test_status_codes_on_device():
+    a = torch.zeros(64 * 16, dtype=torch.uint8, device="cuda")
+    assert M.simdDCT_EncodeQuantize32ReorderBuffer(a, a, M.QUANTIZE_BASE, 56, 16, 0, 16) == M.sdr_NotSupported
+    assert M.simdDCT_EncodeQuantizeReorderStereoBuffer(a, a, M.QUANTIZE_BASE, 64, 8, 0, 8) == M.sdr_NotSupported  # documented: needs H % 16
+    assert M.simdDCT_EncodeQuantize32ReorderBuffer(None, a, M.QUANTIZE_BASE, 64, 16, 0, 16) == M.sdr_InvalidParameter
+
+
+# ------------------------------------------------------------------ engine-own variants
+@pytest.mark.parametrize("bits", [8, 12])
+def test_i16_fwd_inv_roundtrip_match_oracle(bits):
+    lut = lut_x(40)
+    for (W, H) in ((8, 8), (64, 16), (200, 40), (1024, 128)):
+        src = synth.plane_i16_np(W, H, "photo", bits=bits)
+        d = dev(src)
+        for table in (None, lut):
+            for mode, fn in (("fwd", M.fwd_i16), ("inv", M.inv_i16), ("roundtrip", M.roundtrip_i16)):
+                out = torch.full((H, W), -21846, dtype=torch.int16, device="cuda")
+                fn(d, out, W, H, lut=table)
+                want = O.i16(mode, src, W, H, lut=table)
+                assert np.array_equal(out.cpu().numpy(), want), (mode, W, H, bits, table is not None)
+        # bit-exact round trip (config 2) and fwd -> inv through HBM
+        rt = torch.empty_like(d)
+        M.roundtrip_i16(d, rt, W, H)
+        assert torch.equal(rt, d)
+
+
+def test_i16_saturation_pitch_and_ranges():
+    W, H, pitch = 64, 32, 96
+    rng = np.random.default_rng(5)
+    src = rng.integers(-32768, 32768, (H, pitch), dtype=np.int16)
+    src[:8, :8] = 32767
+    src[8:16, :8] = -32768
+    d = dev(src)
+    for mode, fn in (("fwd", M.fwd_i16), ("inv", M.inv_i16), ("roundtrip", M.roundtrip_i16)):
+        out = torch.full((H, pitch), 77, dtype=torch.int16, device="cuda")
+        fn(d, out, W, H, by0=1, by1=3, pitch_in=pitch, pitch_out=pitch)
+        want = np.full((H, pitch), 77, dtype=np.int16)
+        o = O.oracle()
+        f = getattr(o, {"fwd": "orc_fwd_i16", "inv": "orc_inv_i16", "roundtrip": "orc_roundtrip_i16"}[mode])
+        assert f(src.ctypes.data, want.ctypes.data, pitch, pitch, None, W, H, 1, 3) == 0
+        assert np.array_equal(out.cpu().numpy(), want), mode
+
+
+def test_f32_matches_oracle_and_double():
+    for (W, H) in ((8, 8), (256, 64), (1000, 24)):
+        src = synth.plane_u8_np(W, H, "photo").astype(np.float32) - 100.5
+        d = dev(src)
+        out = torch.empty_like(d)
+        M.fwd_f32(d, out, W, H)
+        got = out.cpu().numpy()
+        assert np.array_equal(got, O.f32("fwd", src, W, H))  # bit-exact vs the oracle
+        want = O.f32("f64ref", src, W, H)
+        blk = lambda a: a.reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+        # config 5 tolerance: 1e-5 relative to the block's max-abs coefficient
+        rel = np.abs(blk(got.astype(np.float64)) - blk(want)).max(1) / np.abs(blk(want)).max(1)
+        assert rel.max() < 1e-5
+        back = torch.empty_like(d)
+        M.inv_f32(out, back, W, H)
+        assert np.array_equal(back.cpu().numpy(), O.f32("inv", got, W, H))
+
+
+def test_plane_batch_420_one_call():
+    """config 3 in miniature: Y + Cb + Cr with per-plane tables, plus a batch > 4 planes"""
+    shapes = [(256, 128), (128, 64), (128, 64), (64, 8), (72, 24)]
+    luts = [lut_x(30), lut_x(60), lut_x(60) * np.float32(1.5), None, lut_x(10)]
+    srcs = [synth.plane_i16_np(w, h, "photo", seed=synth.SEED + i) for i, (w, h) in enumerate(shapes)]
+    d_in = [dev(s) for s in srcs]
+    d_out = [torch.empty_like(t) for t in d_in]
+    M.roundtrip_i16_planes([(a, b, w, h, l) for a, b, (w, h), l in zip(d_in, d_out, shapes, luts)])
+    for s, o, (w, h), l in zip(srcs, d_out, shapes, luts):
+        assert np.array_equal(o.cpu().numpy(), O.i16("roundtrip", s, w, h, lut=l)), (w, h)
+
+
+# ------------------------------------------------------------------ BASELINE.json sizes
+def test_full_size_properties_8192():
+    """8192x8192 (configs 1/2): properties that need no CPU pass over 64 Mpx, plus exact
+    oracle checks on sampled block rows."""
+    W = H = 8192
+    # config 2: fused fwd -> inv of an int16 plane is a bit-exact round trip
+    src = synth.plane_i16_torch(W, H, "photo")
+    dst = torch.empty_like(src)
+    M.roundtrip_i16(src, dst, W, H)
+    assert torch.equal(src, dst)
+    # forward: sampled block rows bit-exact vs the oracle, and DC plane == block sums / 8 (rounded)
+    coef = torch.empty_like(src)
+    M.fwd_i16(src, coef, W, H)
+    host = synth.plane_i16_np(W, H, "photo")
+    for by in (0, 511, 1023):
+        want = O.i16("fwd", host[by * 8:(by + 1) * 8], W, 8)
+        assert np.array_equal(coef[by * 8:(by + 1) * 8].cpu().numpy(), want), by
+    dc = coef[::8, ::8].to(torch.float64)
+    sums = src.to(torch.float64).reshape(H // 8, 8, W // 8, 8).sum(dim=(1, 3)) / 8.0
+    assert (dc - sums).abs().max().item() <= 0.5 + 1e-3
+    del coef, dst
+    # config 1: u8 q32 over the full plane == sum of two half-range calls (linearity of sharding),
+    # sampled groups bit-exact vs the oracle, through the reference API's sizeY = 2H form
+    img = synth.plane_u8_torch(W, H, "photo")
+    lut = lut_x(2000)
+    full = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
+    assert M.simdDCT_EncodeQuantize32ReorderBuffer(img, full, lut, W, 2 * H, 0, 2 * H) == 0
+    halves = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
+    M.fwd_quant_u8(img, halves, lut, W, H, 0, 400)
+    M.fwd_quant_u8(img, halves, lut, W, H, 400, 1024)
+    assert torch.equal(full, halves)
+    himg = synth.plane_u8_np(W, H, "photo")
+    for by in (0, 400, 1023):
+        rc, want = O.q32_native(himg[by * 8:(by + 1) * 8], lut, W, 8, 0, 1)
+        assert np.array_equal(full[by * 8 * W:(by + 1) * 8 * W].cpu().numpy(), want), by
+    # a checksum of checksums that any dropped or duplicated group would change
+    assert int(full.to(torch.int64).sum().item()) == int(halves.to(torch.int64).sum().item())

@@ -1,0 +1,193 @@
+"""CPU tests: the oracle is pinned against (i) fixtures produced by the real reference,
+(ii) the survey's SHA-256 known answers, (iii) the real reference itself when oracle/_ref
+exists (build container only), and its engine-own parts against a double-precision DCT."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from simd_dct_amd import synth
+from simd_dct_amd.api import QUANTIZE_BASE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_matches_reference_fixtures(golden):
+    meta, vec = golden
+    W, H = meta["W"], meta["H"]
+    for c in meta["cases"]:
+        lut = (QUANTIZE_BASE * np.float32(c["scale"])).astype(np.float32)
+        out = np.full(W * H, meta["canary"], dtype=np.uint8)
+        rc, out = O.run_behaviour(c["behaviour"], vec["in_" + c["input"]], lut, W, H, c["startY"], c["endY"], out=out)
+        assert rc == 0
+        assert np.array_equal(out, vec[c["key"]]), c["key"]
+
+
+def test_oracle_full_plane_trick(golden):
+    meta, vec = golden
+    W, H = meta["W"], meta["H"]
+    lut = (QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
+    for kind in ("noise", "photo"):
+        out = np.full(W * H, meta["canary"], dtype=np.uint8)
+        O.run_behaviour("q32_avx", vec["in_" + kind], lut, W, 2 * H, 0, 2 * H, out=out)
+        assert np.array_equal(out, vec[f"q32_full__{kind}"])
+        # and the engine's native full-plane range is the same thing
+        rc, nat = O.q32_native(vec["in_" + kind], lut, W, H, 0, H // 8)
+        assert rc == 0 and np.array_equal(nat, out)
+
+
+def test_oracle_large_plane_hashes(golden):
+    meta, _ = golden
+    for key, sha in meta["sha256_zero_prefilled"].items():
+        beh, kind, dims, sc = key.split("__")
+        w, h = map(int, dims.split("x"))
+        lut = (QUANTIZE_BASE * np.float32(float(sc[1:]))).astype(np.float32)
+        rc, out = O.run_behaviour(beh, synth.plane_u8_np(w, h, kind), lut, w, h, 0, h)
+        assert hashlib.sha256(out.tobytes()).hexdigest() == sha, key
+
+
+def test_oracle_survey_known_answers():
+    with open(os.path.join(ROOT, "tests", "golden", "survey_known_answers.json")) as f:
+        ka = json.load(f)
+    W, H = ka["W"], ka["H"]
+    i = np.arange(W * H, dtype=np.uint64)
+    g0 = ((((i * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)) >> np.uint64(24))).astype(np.uint8)
+    assert hashlib.sha256(g0.tobytes()).hexdigest() == ka["input_g0"]
+    for c in ka["cases"]:
+        lut = (QUANTIZE_BASE * np.float32(c["scale"])).astype(np.float32)
+        out = np.zeros(W * H, dtype=np.uint8)  # buffers stay W*H even for the sizeY = 2H call trick
+        rc, out = O.run_behaviour(c["behaviour"], g0, lut, W, c["sizeY"], c["startY"], c["endY"], out=out)
+        assert hashlib.sha256(out.tobytes()).hexdigest() == c["sha256"], c
+
+
+@pytest.mark.skipif(O.reference() is None, reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("beh", list(O.REF_FUNCS))
+def test_oracle_equals_real_reference_random(beh):
+    rng = np.random.default_rng(7)
+    for (W, H) in ((64, 16), (192, 48), (256, 64)):
+        for scale in (0.05, 1.0, 8.0, 100.0, 2000.0):
+            img = rng.integers(0, 256, W * H, dtype=np.uint8)
+            lut = (QUANTIZE_BASE * np.float32(scale) * rng.uniform(0.5, 2.0, 64).astype(np.float32)).astype(np.float32)
+            for (y0, y1) in ((0, H), (16, 16), (8, H // 2)):
+                a = np.full(W * H, 0x5A, dtype=np.uint8)
+                b = a.copy()
+                O.run_behaviour(beh, img, lut, W, H, y0, y1, out=a)
+                O.run_behaviour(beh, img, lut, W, H, y0, y1, out=b, use_reference=True)
+                assert np.array_equal(a, b), (beh, W, H, scale, y0, y1)
+
+
+@pytest.mark.skipif(O.reference() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_equals_real_reference_extreme_tables():
+    """cvtps_epi32 'integer indefinite' corner: tiny, zero, negative, inf, NaN table entries."""
+    rng = np.random.default_rng(11)
+    W, H = 64, 16
+    img = rng.integers(0, 256, W * H, dtype=np.uint8)
+    img[:64] = 0  # exact-zero coefficients make 0*inf = NaN reachable
+    for special in (1e-4, 1e-7, 0.0, -0.3, np.inf, np.nan, 1e-30, 3e38):
+        lut = QUANTIZE_BASE.copy()
+        lut[::3] = special
+        for beh in O.REF_FUNCS:
+            a = np.zeros(W * H, dtype=np.uint8)
+            b = a.copy()
+            O.run_behaviour(beh, img, lut, W, H, 0, H, out=a)
+            O.run_behaviour(beh, img, lut, W, H, 0, H, out=b, use_reference=True)
+            assert np.array_equal(a, b), (beh, special)
+
+
+def test_argument_errors_match_reference_codes():
+    img = np.zeros(64 * 16, dtype=np.uint8)
+    lut = QUANTIZE_BASE
+    keep, lp = O._lut(lut)
+    o = O.oracle()
+    assert o.orc_q32_avx(None, img.ctypes.data, lp, 64, 16, 0, 16) == 1  # simd_dct.cpp:117
+    assert o.orc_q32_avx(img.ctypes.data, None, lp, 64, 16, 0, 16) == 1
+    assert o.orc_q32_avx(img.ctypes.data, img.ctypes.data, lp, 56, 16, 0, 16) == 2  # :118, sizeX % 64
+    assert o.orc_q32_avx(img.ctypes.data, img.ctypes.data, lp, 64, 12, 0, 16) == 2
+    assert o.orc_encq_scalar(img.ctypes.data, img.ctypes.data, lp, 60, 16, 0, 16) == 2  # :98
+
+
+def test_true_dct_kernels_against_double():
+    """K_TRUE (the reference's scalar kernel) and K_OWN are the orthonormal DCT-II; K_AVX / K_SSE
+    carry the documented sign quirks on k=3 / k=1 only."""
+    rng = np.random.default_rng(3)
+    n = np.arange(8)
+    C = np.array([[(np.sqrt(1 / 8) if k == 0 else 0.5) * np.cos((2 * nn + 1) * k * np.pi / 16) for nn in n] for k in range(8)])
+    o = O.oracle()
+    for _ in range(50):
+        x = rng.integers(0, 256, 8).astype(np.float32)
+        want = C @ x.astype(np.float64)
+        for which, bad in ((2, None), (3, None), (0, 3), (1, 1)):
+            y = x.copy()
+            o.orc_dct8(y.ctypes.data, 1, which)
+            err = np.abs(y - want)
+            ok = np.ones(8, bool)
+            if bad is not None:
+                ok[bad] = False
+            assert err[ok].max() < 2e-4, (which, err)
+    # survey probe row: scalar k1 = -75.0306 (true), SSE k1 = -64.8859
+    row = np.array([10, 200, 33, 47, 99, 150, 7, 250], dtype=np.float32)
+    a, b = row.copy(), row.copy()
+    o.orc_dct8(a.ctypes.data, 1, 2)
+    o.orc_dct8(b.ctypes.data, 1, 1)
+    assert abs(a[1] + 75.0306) < 1e-3 and abs(b[1] + 64.8859) < 1e-3
+
+
+def test_own_inverse_inverts_forward():
+    rng = np.random.default_rng(5)
+    o = O.oracle()
+    for _ in range(100):
+        x = rng.integers(-2048, 2048, 8).astype(np.float32)
+        y = x.copy()
+        o.orc_dct8(y.ctypes.data, 1, 3)
+        o.orc_idct8_own(y.ctypes.data, 1)
+        assert np.abs(y - x).max() < 2e-3
+
+
+def test_own_planes_against_double_and_roundtrip():
+    W, H = 128, 64
+    for bits in (8, 12):
+        src = synth.plane_i16_np(W, H, "photo", bits=bits)
+        # fused fwd->inv returns the input bit-exactly (config 2's "bit-exact round-trip")
+        assert np.array_equal(O.i16("roundtrip", src, W, H), src)
+        coef = O.i16("fwd", src, W, H)
+        ref = np.rint(O.f32("f64ref", src.astype(np.float32), W, H))
+        assert np.abs(coef - ref).max() <= 1  # rounding of a value within 1e-3 of a tie
+        assert (coef != ref).mean() < 1e-2  # exact .5 ties (DC = sum/8) fall either side in double
+        # unfused fwd -> inv: integer coefficients cost at most a couple of grey levels
+        back = O.i16("inv", coef, W, H)
+        assert np.abs(back.astype(np.int32) - src).max() <= 2
+    # quantised round trip equals the composition of its unfused parts
+    lut = (QUANTIZE_BASE * np.float32(40)).astype(np.float32)
+    src = synth.plane_i16_np(W, H, "photo")
+    rt = O.i16("roundtrip", src, W, H, lut=lut)
+    assert np.array_equal(rt, O.i16("inv", O.i16("fwd", src, W, H, lut=lut), W, H, lut=lut))
+    assert 0 < np.abs(rt.astype(np.int32) - src).mean() < 12
+
+
+def test_f32_against_double_tolerance():
+    """config 5: 1e-5 relative to the block's max-abs coefficient (element-wise
+    relative error is unattainable near zero for ANY float32 DCT)."""
+    W, H = 256, 64
+    src = synth.plane_u8_np(W, H, "photo").astype(np.float32)
+    got = O.f32("fwd", src, W, H).astype(np.float64)
+    want = O.f32("f64ref", src, W, H)
+    blk = lambda a: a.reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+    rel = np.abs(blk(got) - blk(want)).max(1) / np.abs(blk(want)).max(1)
+    assert rel.max() < 1e-5
+    back = O.f32("inv", got.astype(np.float32), W, H)
+    assert np.abs(back - src).max() < 1e-3
+
+
+def test_row_range_is_additive():
+    """fake ranks: disjoint block-row ranges into one buffer == one full range"""
+    W, H = 128, 64
+    img = synth.plane_u8_np(W, H, "noise")
+    lut = (QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
+    rc, full = O.q32_native(img, lut, W, H, 0, H // 8)
+    parts = np.zeros(W * H, dtype=np.uint8)
+    for (a, b) in ((0, 3), (3, 4), (4, 8)):
+        O.q32_native(img, lut, W, H, a, b, out=parts)
+    assert np.array_equal(parts, full)
