@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (configs[1]): one 8192x8192 int16 plane per GPU per step, forward + inverse 8x8 DCT
+in ONE fused kernel (4 algorithmic bytes per pixel: 2 in + 2 out).  Four distinct plane
+pairs (1 GiB) are rotated so that no step can be served from the 256 MiB Infinity Cache.
+Inputs are resident in HBM before the timed region.  N > 1: one process per GPU
+(torch.distributed / RCCL), every rank transforms its own planes -- the path shards by
+independent planes / block rows with no data-path collective ("weak" scaling); an
+all-gather of the outputs (north_star's whole-node run) is timed separately and reported
+under "allgather", never inside `value`.
+
+One JSON line on rank 0.  `roofline` is for the fused round-trip kernel, timed with HIP
+events on the launch stream; `cpu_baseline` times the oracle (a scalar C port, all host
+threads) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W = H = 8192
+NSETS = 4
+ALG_BYTES_PER_PX = 4  # int16 in + int16 out
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def host_threads():
+    """threads this process may really use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(budget_s=12.0):
+    """oracle/ (the CPU port) on a bounded sample of the same workload, all host threads."""
+    import numpy as np
+
+    import oracle as O
+    from simd_dct_amd import synth
+
+    threads = host_threads()
+    rows_per_thread = 64  # 8192 x 64 px stripe = 0.5 Mpx per call
+    src = synth.plane_i16_np(W, rows_per_thread, "photo")
+    bufs = [(src.copy(), np.empty_like(src)) for _ in range(threads)]
+    O.i16("roundtrip", src, W, rows_per_thread, out=bufs[0][1])  # warm (builds/loads the oracle)
+    counts = [0] * threads
+    deadline = time.perf_counter() + budget_s
+
+    def work(i):
+        a, b = bufs[i]
+        while time.perf_counter() < deadline:  # bounded by time, whatever the host's core share is
+            O.i16("roundtrip", a, W, rows_per_thread, out=b)
+            counts[i] += 1
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    reps = sum(counts)
+    px = reps * W * rows_per_thread
+    assert np.array_equal(bufs[0][0], bufs[0][1])
+    out = {
+        "value": round(px / dt / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+        "sample": f"oracle/dct_oracle.c orc_roundtrip_i16 (scalar C, -O2 -ffp-contract=off), {threads} threads x {reps} x "
+                  f"{W}x{rows_per_thread} int16 stripes = {px / 1e6:.0f} Mpx in {dt:.1f} s",
+    }
+    # the reference's own fastest path (u8 q32, AVX2) for orientation, when its build travelled
+    try:
+        if O.reference() is not None:
+            from simd_dct_amd.api import QUANTIZE_BASE
+
+            img = synth.plane_u8_np(W, 512, "photo").reshape(-1)
+            lut = (QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
+            o = np.zeros(W * 512, dtype=np.uint8)
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter()
+                O.run_behaviour("q32_avx", img, lut, W, 1024, 0, 1024, out=o, use_reference=True)  # sizeY = 2H: whole stripe
+                best = min(best, time.perf_counter() - t0)
+            out["reference_q32_avx2_1core_Mpx_s"] = round(W * 512 / best / 1e6, 1)
+    except Exception as e:  # orientation only
+        out["reference_q32_error"] = str(e)[:120]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import simd_dct_amd as M
+    from simd_dct_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    M.init(local)
+    info = M.device_info()
+    t_start = time.perf_counter()
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    # ---- inputs resident in HBM before anything is timed
+    srcs = [synth.plane_i16_torch(W, H, "photo", seed=synth.SEED + rank * NSETS + i) for i in range(NSETS)]
+    dsts = [torch.empty_like(s) for s in srcs]
+    torch.cuda.synchronize()
+    log("inputs resident")
+
+    def step(i):
+        M.roundtrip_i16(srcs[i % NSETS], dsts[i % NSETS], W, H)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    verified = all(torch.equal(s, d) for s, d in zip(srcs, dsts)) if args.warmup >= NSETS else None
+
+    timer = M.Timer()
+    barrier()
+    t0 = time.perf_counter()
+    timer.start()
+    for i in range(args.steps):
+        step(i)
+    timer.stop()
+    barrier()
+    wall = time.perf_counter() - t0
+    kernel_ms = timer.elapsed_ms() / args.steps  # HIP events on the launch stream, avg per launch
+    if dist is not None:
+        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, kernel_ms = t.tolist()
+
+    log(f"timed region done: {wall / args.steps * 1e3:.4f} ms/step")
+    px_per_step = W * H
+    value = world * px_per_step * args.steps / wall / 1e6
+    achieved = px_per_step * ALG_BYTES_PER_PX / (kernel_ms * 1e-3) / 1e9
+
+    extras, allgather = {}, None
+    if not args.no_extras:
+        def rate(fn, bytes_per_launch, n=50):
+            for i in range(5):
+                fn(i)
+            torch.cuda.synchronize()
+            timer.start()
+            for i in range(n):
+                fn(i)
+            timer.stop()
+            ms = timer.elapsed_ms() / n
+            return {"ms": round(ms, 4), "GBps": round(bytes_per_launch / (ms * 1e-3) / 1e9, 1)}
+
+        nbytes = W * H * 2
+        extras["stream_copy_roofline"] = rate(lambda i: M.stream_copy(srcs[i % NSETS], dsts[i % NSETS], nbytes), 2 * nbytes)
+        extras["fwd_i16"] = rate(lambda i: M.fwd_i16(srcs[i % NSETS], dsts[i % NSETS], W, H), 2 * nbytes)
+        extras["inv_i16"] = rate(lambda i: M.inv_i16(srcs[i % NSETS], dsts[i % NSETS], W, H), 2 * nbytes)
+        lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
+        u8s = [s.view(torch.uint8).reshape(-1)[: W * H] for s in srcs]  # any bytes will do for timing
+        u8d = [d.view(torch.uint8).reshape(-1)[: W * H] for d in dsts]
+        extras["fwd_quant_u8_q32"] = rate(lambda i: M.fwd_quant_u8(u8s[i % NSETS], u8d[i % NSETS], lut, W, H, 0, H // 8), 2 * W * H)
+        extras["fwd_quant_u8_q32"]["Mpx_s"] = round(W * H / (extras["fwd_quant_u8_q32"]["ms"] * 1e-3) / 1e6, 0)
+        extras["roundtrip_frac_of_measured_copy"] = round(achieved / extras["stream_copy_roofline"]["GBps"], 3)
+
+    log("extras done")
+    if dist is not None and not args.no_extras:
+        # north_star's whole-node run: block-row shards of one plane batch all-gathered over xGMI.
+        try:
+            from simd_dct_amd.sharding import shard_rows
+
+            rows = H // 8
+            b0, b1 = shard_rows(rows, world, rank)
+            full = dsts[0]
+            M.fwd_i16(srcs[0], full, W, H, by0=b0, by1=b1)
+            gath = full.view(torch.uint8).reshape(-1)
+            mine = gath[b0 * 8 * W * 2:b1 * 8 * W * 2]
+            torch.cuda.synchronize()
+            dist.barrier()
+            n = 10
+            t0 = time.perf_counter()
+            for _ in range(n):
+                M.fwd_i16(srcs[0], full, W, H, by0=b0, by1=b1)
+                dist.all_gather_into_tensor(gath, mine)
+            torch.cuda.synchronize()
+            dist.barrier()
+            dt = (time.perf_counter() - t0) / n
+            allgather = {"what": "one 8192x8192 int16 plane, block rows sharded over ranks, fwd + in-place all_gather_into_tensor",
+                         "ms": round(dt * 1e3, 3), "Mpx_s": round(W * H / dt / 1e6, 0),
+                         "busbw_GBps": round((world - 1) / world * W * H * 2 / dt / 1e9, 1)}
+        except Exception as e:
+            allgather = {"error": str(e)[:200]}
+
+    if rank == 0:
+        line = {
+            "metric": "Mpixels/s 8x8 fwd+inv int16 DCT, 8192x8192 plane",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: single 8192x8192 int16 plane per GPU, forward+inverse 8x8 DCT fused in one kernel",
+                       "plane": [W, H], "io": "int16", "planes_per_step_per_gpu": 1, "rotating_plane_sets": NSETS,
+                       "parallelism": f"independent planes x{world}" if world > 1 else "single GPU", "device": info["name"]},
+            "roofline": {"bound": "hbm", "kernel": "mdct::k_i16<MODE_ROUNDTRIP, no table>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": px_per_step * ALG_BYTES_PER_PX, "avg_launch_ms": round(kernel_ms, 4)},
+            "bit_exact_roundtrip_verified": verified,
+        }
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                line["roofline"]["traffic"] = json.load(open(tr)).get("k_i16_roundtrip_bytes_per_launch")
+            except Exception:
+                pass
+        if extras:
+            line["extras"] = extras
+        if allgather:
+            line["allgather"] = allgather
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle port) ...")
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
