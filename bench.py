@@ -142,8 +142,12 @@ def main():
     torch.cuda.synchronize()
     log("inputs resident")
 
+    # launches with their arguments marshalled once (the kernel runs ~45 us; re-deriving
+    # pointers, table and stream in Python per call costs ~10 us and would starve the queue)
+    steps = [M.prepare_plane_i16("roundtrip", srcs[i], dsts[i], W, H) for i in range(NSETS)]
+
     def step(i):
-        M.roundtrip_i16(srcs[i % NSETS], dsts[i % NSETS], W, H)
+        steps[i % NSETS]()
 
     def barrier():
         torch.cuda.synchronize()
@@ -190,13 +194,17 @@ def main():
             return {"ms": round(ms, 4), "GBps": round(bytes_per_launch / (ms * 1e-3) / 1e9, 1)}
 
         nbytes = W * H * 2
-        extras["stream_copy_roofline"] = rate(lambda i: M.stream_copy(srcs[i % NSETS], dsts[i % NSETS], nbytes), 2 * nbytes)
-        extras["fwd_i16"] = rate(lambda i: M.fwd_i16(srcs[i % NSETS], dsts[i % NSETS], W, H), 2 * nbytes)
-        extras["inv_i16"] = rate(lambda i: M.inv_i16(srcs[i % NSETS], dsts[i % NSETS], W, H), 2 * nbytes)
+        def prepared(make):
+            calls = [make(i) for i in range(NSETS)]
+            return lambda i: calls[i % NSETS]()
+
+        extras["stream_copy_roofline"] = rate(prepared(lambda i: M.prepare_stream_copy(srcs[i], dsts[i], nbytes)), 2 * nbytes)
+        extras["fwd_i16"] = rate(prepared(lambda i: M.prepare_plane_i16("fwd", srcs[i], dsts[i], W, H)), 2 * nbytes)
+        extras["inv_i16"] = rate(prepared(lambda i: M.prepare_plane_i16("inv", srcs[i], dsts[i], W, H)), 2 * nbytes)
         lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
         u8s = [s.view(torch.uint8).reshape(-1)[: W * H] for s in srcs]  # any bytes will do for timing
         u8d = [d.view(torch.uint8).reshape(-1)[: W * H] for d in dsts]
-        extras["fwd_quant_u8_q32"] = rate(lambda i: M.fwd_quant_u8(u8s[i % NSETS], u8d[i % NSETS], lut, W, H, 0, H // 8), 2 * W * H)
+        extras["fwd_quant_u8_q32"] = rate(prepared(lambda i: M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, H // 8)), 2 * W * H)
         extras["fwd_quant_u8_q32"]["Mpx_s"] = round(W * H / (extras["fwd_quant_u8_q32"]["ms"] * 1e-3) / 1e6, 0)
         extras["roundtrip_frac_of_measured_copy"] = round(achieved / extras["stream_copy_roofline"]["GBps"], 3)
 

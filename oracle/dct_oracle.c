@@ -23,8 +23,104 @@ static const float Cn = 0.35355339059327376220042218105242f; /* 1/sqrt(8) */
 
 enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2, K_OWN = 3 };
 
+
+/* ------------------------------------------------------------------------------------------
+ * Engine-own 1-D kernels [unpinned]: the Arai-Agui-Nakajima scaled DCT (5 multiplies and 29
+ * additions per 8 points, as popularised by the IJG float DCT), chosen because VALU issue
+ * -- not HBM -- bounds these kernels on gfx950 and neither FMA nor packed fp32 ops are
+ * cheaper there than separate mul/add.  Every operation is individually rounded.
+ *   forward:  y_k = sqrt(8) * a_k * X_k      (X = orthonormal DCT-II, a_0 = 1, a_k = sqrt2*cos(k*pi/16))
+ *   inverse:  takes z_k = a_k * X_k / sqrt(8) ... per dimension; the 2-D tables below carry
+ *             the factors so that forward-table * inverse-table == 1/64 exactly.
+ * ---------------------------------------------------------------------------------------- */
+const double orc_aan_scale[8] = {1.0, 1.387039845322148, 1.306562964876377, 1.175875602419359,
+                                 1.0, 0.785694958387102, 0.541196100146197, 0.275899379282943};
+
+static const float A_707 = 0.707106781186547524f;  /* cos(pi/4)            */
+static const float A_382 = 0.382683432365089772f;  /* cos(3pi/8)           */
+static const float A_541 = 0.541196100146196985f;  /* cos(pi/8)-cos(3pi/8) */
+static const float A_1306 = 1.306562964876376528f; /* cos(pi/8)+cos(3pi/8) */
+static const float A_1414 = 1.414213562373095049f; /* sqrt(2)              */
+static const float A_1847 = 1.847759065022573512f; /* 2*cos(pi/8)          */
+static const float A_1082 = 1.082392200292393968f; /* 2*(cos(pi/8)-cos(3pi/8)) */
+static const float A_2613 = 2.613125929752753056f; /* 2*(cos(pi/8)+cos(3pi/8)) */
+
+void orc_aan_fwd8(float *p, ptrdiff_t s)
+{
+  const float d0 = p[0], d1 = p[s], d2 = p[2 * s], d3 = p[3 * s], d4 = p[4 * s], d5 = p[5 * s], d6 = p[6 * s], d7 = p[7 * s];
+  const float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
+  const float t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+  /* even part */
+  const float e10 = t0 + t3, e13 = t0 - t3, e11 = t1 + t2, e12 = t1 - t2;
+  const float z1 = (e12 + e13) * A_707;
+  /* odd part */
+  const float o10 = t4 + t5, o11 = t5 + t6, o12 = t6 + t7;
+  const float z5 = (o10 - o12) * A_382;
+  const float z2 = (A_541 * o10) + z5;
+  const float z4 = (A_1306 * o12) + z5;
+  const float z3 = o11 * A_707;
+  const float z11 = t7 + z3, z13 = t7 - z3;
+  p[0] = e10 + e11;
+  p[4 * s] = e10 - e11;
+  p[2 * s] = e13 + z1;
+  p[6 * s] = e13 - z1;
+  p[5 * s] = z13 + z2;
+  p[3 * s] = z13 - z2;
+  p[s] = z11 + z4;
+  p[7 * s] = z11 - z4;
+}
+
+void orc_aan_inv8(float *p, ptrdiff_t s)
+{
+  const float i0 = p[0], i1 = p[s], i2 = p[2 * s], i3 = p[3 * s], i4 = p[4 * s], i5 = p[5 * s], i6 = p[6 * s], i7 = p[7 * s];
+  /* even part */
+  const float e10 = i0 + i4, e11 = i0 - i4;
+  const float e13 = i2 + i6;
+  const float e12 = ((i2 - i6) * A_1414) - e13;
+  const float t0 = e10 + e13, t3 = e10 - e13, t1 = e11 + e12, t2 = e11 - e12;
+  /* odd part */
+  const float z13 = i5 + i3, z10 = i5 - i3, z11 = i1 + i7, z12 = i1 - i7;
+  const float t7 = z11 + z13;
+  const float o11 = (z11 - z13) * A_1414;
+  const float z5 = (z10 + z12) * A_1847;
+  const float o10 = (A_1082 * z12) - z5;
+  const float o12 = z5 - (A_2613 * z10);
+  const float t6 = o12 - t7;
+  const float t5 = o11 - t6;
+  const float t4 = o10 + t5;
+  p[0] = t0 + t7;
+  p[7 * s] = t0 - t7;
+  p[s] = t1 + t6;
+  p[6 * s] = t1 - t6;
+  p[2 * s] = t2 + t5;
+  p[5 * s] = t2 - t5;
+  p[4 * s] = t3 + t4;
+  p[3 * s] = t3 - t4;
+}
+
+/* 2-D tables, index v*8+u.  fwd: raw AAN output -> orthonormal coefficient; inv: orthonormal
+ * coefficient -> AAN inverse input (includes the 1/8 of the two inverse passes).  Products of
+ * doubles rounded once to float, so host (product) and oracle agree bit for bit. */
+void orc_aan_tables(float *fwd, float *inv)
+{
+  for (int v = 0; v < 8; v++)
+    for (int u = 0; u < 8; u++)
+    {
+      const double a = orc_aan_scale[v] * orc_aan_scale[u];
+      fwd[v * 8 + u] = (float)(1.0 / (8.0 * a));
+      inv[v * 8 + u] = (float)(a / 8.0);
+    }
+}
+
 void orc_dct8(float *p, ptrdiff_t s, int which)
 {
+  if (which == K_OWN)
+  { /* engine-own: scaled AAN butterfly followed by the 1-D scale factors */
+    orc_aan_fwd8(p, s);
+    for (int k = 0; k < 8; k++)
+      p[k * s] = p[k * s] * (float)(1.0 / (2.8284271247461900976 * orc_aan_scale[k]));
+    return;
+  }
   const float p0 = p[0], p1 = p[s], p2 = p[2 * s], p3 = p[3 * s];
   const float p4 = p[4 * s], p5 = p[5 * s], p6 = p[6 * s], p7 = p[7 * s];
 
@@ -62,15 +158,6 @@ void orc_dct8(float *p, ptrdiff_t s, int which)
     o7 = ((Cf * x07m) + (Cd * x61m)) + ((Cc * x25m) + (Ca * x43m));
     break;
 
-  case K_OWN: /* engine-own: correct signs (as :163-171), pairwise association (as :2176-2183) */
-    o2 = (Cb * pm) + (Ce * qm);
-    o6 = (Ce * pm) - (Cb * qm);
-    o1 = ((Ca * x07m) - (Cc * x61m)) + ((Cd * x25m) - (Cf * x43m));
-    o3 = ((Cc * x07m) + (Cf * x61m)) - ((Ca * x25m) - (Cd * x43m));
-    o5 = ((Cd * x07m) + (Ca * x61m)) + ((Cf * x25m) - (Cc * x43m));
-    o7 = ((Cf * x07m) + (Cd * x61m)) + ((Cc * x25m) + (Ca * x43m));
-    break;
-
   default: /* K_AVX: simd_dct.cpp:2176-2183 (== :1972-1979, AVX-512VL).
             * o3 subtracts (Ca*x25m + Cd*x43m): k=3 sign quirk. */
     o2 = (Cb * pm) + (Ce * qm);
@@ -86,26 +173,12 @@ void orc_dct8(float *p, ptrdiff_t s, int which)
   p[4 * s] = Cn * o4; p[5 * s] = Cn * o5; p[6 * s] = Cn * o6; p[7 * s] = Cn * o7;
 }
 
-/* Inverse of K_OWN: x_n = Cn*(e_n + d_n), x_{7-n} = Cn*(e_n - d_n)  [unpinned]. */
+/* 1-D inverse of K_OWN (for the unit tests): orthonormal coefficients in, samples out. */
 void orc_idct8_own(float *p, ptrdiff_t s)
 {
-  const float X0 = p[0], X1 = p[s], X2 = p[2 * s], X3 = p[3 * s];
-  const float X4 = p[4 * s], X5 = p[5 * s], X6 = p[6 * s], X7 = p[7 * s];
-
-  const float a0 = X0 + X4, a1 = X0 - X4;
-  const float b0 = (Cb * X2) + (Ce * X6);
-  const float b1 = (Ce * X2) - (Cb * X6);
-  const float e0 = a0 + b0, e1 = a1 + b1, e2 = a1 - b1, e3 = a0 - b0;
-
-  const float d0 = ((Ca * X1) + (Cc * X3)) + ((Cd * X5) + (Cf * X7));
-  const float d1 = ((Cc * X1) - (Cf * X3)) - ((Ca * X5) + (Cd * X7));
-  const float d2 = ((Cd * X1) - (Ca * X3)) + ((Cf * X5) + (Cc * X7));
-  const float d3 = ((Cf * X1) - (Cd * X3)) + ((Cc * X5) - (Ca * X7));
-
-  p[0] = Cn * (e0 + d0);     p[7 * s] = Cn * (e0 - d0);
-  p[s] = Cn * (e1 + d1);     p[6 * s] = Cn * (e1 - d1);
-  p[2 * s] = Cn * (e2 + d2); p[5 * s] = Cn * (e2 - d2);
-  p[3 * s] = Cn * (e3 + d3); p[4 * s] = Cn * (e3 - d3);
+  for (int k = 0; k < 8; k++)
+    p[k * s] = p[k * s] * (float)(orc_aan_scale[k] / 2.8284271247461900976);
+  orc_aan_inv8(p, s);
 }
 
 /* x86 cvtps_epi32 under default MXCSR: round-to-nearest-even; out of range or NaN
@@ -383,6 +456,17 @@ int orc_encq_scalar(const uint8_t *from, uint8_t *to, const float *lut, size_t W
 }
 
 /* ------------------------------------------------- engine-own [unpinned] -- */
+/* Definition of the engine's own transforms (what simd_dct_amd/csrc implements):
+ *   raw forward  R = AANcols(AANrows(x))                      (no scaling inside)
+ *   fwd  i16 : c[i] = sat_i16(rne(R[i] * QF[i])),  QF[i] = fwdtab[i]            (no table)
+ *                                                   QF[i] = (1.0f/lut[i]) * fwdtab[i]  (table)
+ *   inv  i16 : z[i] = (float)c[i] * DQ[i],          DQ[i] = invtab[i] | lut[i] * invtab[i]
+ *              x = sat_i16(rne(AANrows^-1(AANcols^-1(z))))
+ *   roundtrip, no table : x' = sat_i16(rne(AANinv(R) * (1/64)))   (fwdtab*invtab == 1/64; a power
+ *              of two commutes with every rounding, so it is applied once at the end)
+ *   roundtrip, table    : z[i] = (float)sat_i16(rne(R[i]*QF[i])) * DQ[i], then as inv
+ *   f32      : fwd out = R[i]*fwdtab[i];  inv z = in[i]*invtab[i]
+ */
 static int16_t sat_i16_rne(float v)
 {
   const float r = rintf(v);
@@ -406,36 +490,53 @@ static int own_args(const void *from, const void *to, size_t pi, size_t po, size
   return 0;
 }
 
+static void own_tables(const float *lut, float *qf, float *dq)
+{
+  float ft[64], it[64];
+  orc_aan_tables(ft, it);
+  for (int i = 0; i < 64; i++)
+  {
+    qf[i] = lut ? (1.0f / lut[i]) * ft[i] : ft[i];
+    dq[i] = lut ? lut[i] * it[i] : it[i];
+  }
+}
+
+static void raw_fwd(float *blk)
+{
+  for (int r = 0; r < 8; r++)
+    orc_aan_fwd8(blk + r * 8, 1);
+  for (int c = 0; c < 8; c++)
+    orc_aan_fwd8(blk + c, 8);
+}
+
+static void raw_inv(float *blk)
+{
+  for (int c = 0; c < 8; c++)
+    orc_aan_inv8(blk + c, 8);
+  for (int r = 0; r < 8; r++)
+    orc_aan_inv8(blk + r * 8, 1);
+}
+
+#define FOR_BLOCKS for (size_t by = by0; by < by1; by++) for (size_t bx = 0; bx < W / 8; bx++)
+#define LOAD_I16(blk) for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c]
+#define AT(r, c) to[(by * 8 + (r)) * po + bx * 8 + (c)]
+
 int orc_fwd_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
     return e;
-  float rq[64];
-  for (int i = 0; i < 64; i++)
-    rq[i] = lut ? 1.0f / lut[i] : 1.0f;
-  for (size_t by = by0; by < by1; by++)
-    for (size_t bx = 0; bx < W / 8; bx++)
-    {
-      float blk[64];
-      for (int r = 0; r < 8; r++)
-        for (int c = 0; c < 8; c++)
-          blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c];
-      rows(blk, K_OWN);
-      cols(blk, K_OWN);
-      for (int r = 0; r < 8; r++)
-        for (int c = 0; c < 8; c++)
-          to[(by * 8 + r) * po + bx * 8 + c] = sat_i16_rne(lut ? blk[r * 8 + c] * rq[r * 8 + c] : blk[r * 8 + c]);
-    }
+  float qf[64], dq[64];
+  own_tables(lut, qf, dq);
+  FOR_BLOCKS
+  {
+    float blk[64];
+    LOAD_I16(blk);
+    raw_fwd(blk);
+    for (int i = 0; i < 64; i++)
+      AT(i >> 3, i & 7) = sat_i16_rne(blk[i] * qf[i]);
+  }
   return 0;
-}
-
-static void inv_block(float *blk)
-{
-  for (int c = 0; c < 8; c++)
-    orc_idct8_own(blk + c, 8);
-  for (int r = 0; r < 8; r++)
-    orc_idct8_own(blk + r * 8, 1);
 }
 
 int orc_inv_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
@@ -443,21 +544,18 @@ int orc_inv_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const fl
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
     return e;
-  for (size_t by = by0; by < by1; by++)
-    for (size_t bx = 0; bx < W / 8; bx++)
-    {
-      float blk[64];
-      for (int r = 0; r < 8; r++)
-        for (int c = 0; c < 8; c++)
-        {
-          const float f = (float)from[(by * 8 + r) * pi + bx * 8 + c];
-          blk[r * 8 + c] = lut ? f * lut[r * 8 + c] : f;
-        }
-      inv_block(blk);
-      for (int r = 0; r < 8; r++)
-        for (int c = 0; c < 8; c++)
-          to[(by * 8 + r) * po + bx * 8 + c] = sat_i16_rne(blk[r * 8 + c]);
-    }
+  float qf[64], dq[64];
+  own_tables(lut, qf, dq);
+  FOR_BLOCKS
+  {
+    float blk[64];
+    LOAD_I16(blk);
+    for (int i = 0; i < 64; i++)
+      blk[i] = blk[i] * dq[i];
+    raw_inv(blk);
+    for (int i = 0; i < 64; i++)
+      AT(i >> 3, i & 7) = sat_i16_rne(blk[i]);
+  }
   return 0;
 }
 
@@ -466,26 +564,20 @@ int orc_roundtrip_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, co
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
     return e;
-  float rq[64];
-  for (int i = 0; i < 64; i++)
-    rq[i] = lut ? 1.0f / lut[i] : 1.0f;
-  for (size_t by = by0; by < by1; by++)
-    for (size_t bx = 0; bx < W / 8; bx++)
-    {
-      float blk[64];
-      for (int r = 0; r < 8; r++)
-        for (int c = 0; c < 8; c++)
-          blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c];
-      rows(blk, K_OWN);
-      cols(blk, K_OWN);
-      if (lut)
-        for (int i = 0; i < 64; i++)
-          blk[i] = (float)sat_i16_rne(blk[i] * rq[i]) * lut[i];
-      inv_block(blk);
-      for (int r = 0; r < 8; r++)
-        for (int c = 0; c < 8; c++)
-          to[(by * 8 + r) * po + bx * 8 + c] = sat_i16_rne(blk[r * 8 + c]);
-    }
+  float qf[64], dq[64];
+  own_tables(lut, qf, dq);
+  FOR_BLOCKS
+  {
+    float blk[64];
+    LOAD_I16(blk);
+    raw_fwd(blk);
+    if (lut)
+      for (int i = 0; i < 64; i++)
+        blk[i] = (float)sat_i16_rne(blk[i] * qf[i]) * dq[i];
+    raw_inv(blk);
+    for (int i = 0; i < 64; i++)
+      AT(i >> 3, i & 7) = sat_i16_rne(lut ? blk[i] : blk[i] * 0.015625f);
+  }
   return 0;
 }
 
@@ -494,17 +586,17 @@ int orc_fwd_f32(const float *from, float *to, size_t pi, size_t po, size_t W, si
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
     return e;
-  for (size_t by = by0; by < by1; by++)
-    for (size_t bx = 0; bx < W / 8; bx++)
-    {
-      float blk[64];
-      for (int r = 0; r < 8; r++)
-        memcpy(blk + r * 8, from + (by * 8 + r) * pi + bx * 8, 8 * sizeof(float));
-      rows(blk, K_OWN);
-      cols(blk, K_OWN);
-      for (int r = 0; r < 8; r++)
-        memcpy(to + (by * 8 + r) * po + bx * 8, blk + r * 8, 8 * sizeof(float));
-    }
+  float ft[64], it[64];
+  orc_aan_tables(ft, it);
+  FOR_BLOCKS
+  {
+    float blk[64];
+    for (int r = 0; r < 8; r++)
+      memcpy(blk + r * 8, from + (by * 8 + r) * pi + bx * 8, 8 * sizeof(float));
+    raw_fwd(blk);
+    for (int i = 0; i < 64; i++)
+      AT(i >> 3, i & 7) = blk[i] * ft[i];
+  }
   return 0;
 }
 
@@ -513,16 +605,19 @@ int orc_inv_f32(const float *from, float *to, size_t pi, size_t po, size_t W, si
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
     return e;
-  for (size_t by = by0; by < by1; by++)
-    for (size_t bx = 0; bx < W / 8; bx++)
-    {
-      float blk[64];
-      for (int r = 0; r < 8; r++)
-        memcpy(blk + r * 8, from + (by * 8 + r) * pi + bx * 8, 8 * sizeof(float));
-      inv_block(blk);
-      for (int r = 0; r < 8; r++)
-        memcpy(to + (by * 8 + r) * po + bx * 8, blk + r * 8, 8 * sizeof(float));
-    }
+  float ft[64], it[64];
+  orc_aan_tables(ft, it);
+  FOR_BLOCKS
+  {
+    float blk[64];
+    for (int r = 0; r < 8; r++)
+      memcpy(blk + r * 8, from + (by * 8 + r) * pi + bx * 8, 8 * sizeof(float));
+    for (int i = 0; i < 64; i++)
+      blk[i] = blk[i] * it[i];
+    raw_inv(blk);
+    for (int i = 0; i < 64; i++)
+      AT(i >> 3, i & 7) = blk[i];
+  }
   return 0;
 }
 

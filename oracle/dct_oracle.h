@@ -35,10 +35,15 @@ extern "C" {
  * which: 0 = K_AVX  (simd_dct.cpp:2158-2184, k=3 sign quirk, pairwise association)
  *        1 = K_SSE  (simd_dct.cpp:434-654 / 672-892, k=1 sign quirk)
  *        2 = K_TRUE (simd_dct.cpp:138-172, left-to-right association, correct DCT-II)
- *        3 = K_OWN  (engine's own: K_TRUE signs, K_AVX association)  [unpinned]        */
+ *        3 = K_OWN  (engine's own: scaled AAN butterfly + scale factors)  [unpinned]   */
 void orc_dct8(float *p, ptrdiff_t stride, int which);
-/* inverse of K_OWN (transposed flow graph) [unpinned] */
+/* inverse of K_OWN, orthonormal coefficients in [unpinned] */
 void orc_idct8_own(float *p, ptrdiff_t stride);
+/* the raw AAN butterflies (5 mul + 29 add) and their 2-D scale tables [unpinned] */
+extern const double orc_aan_scale[8];
+void orc_aan_fwd8(float *p, ptrdiff_t stride);
+void orc_aan_inv8(float *p, ptrdiff_t stride);
+void orc_aan_tables(float *fwd64, float *inv64);
 
 /* The five reference behaviours, with the reference's exact call semantics
  * (top-half loop, inclusive endY, untouched output bytes stay untouched).
@@ -52,9 +57,10 @@ int orc_encq_scalar(const uint8_t *from, uint8_t *to, const float *lut, size_t s
 /* Engine-own variants [unpinned].  Planes are row-major with pitches in ELEMENTS,
  * block rows [by0, by1) (units of 8 pixel rows) over the FULL plane, coefficient (v,u)
  * of block (by,bx) stored in place at (by*8+v, bx*8+u).
- * lut == NULL: no quantisation.  Otherwise q[i] = 1/(lut[i]) style scaling:
- *   fwd:  c = rne(f * rq[i]),  rq[i] = 1.0f / lut[i]    (saturated to int16)
- *   inv:  f = (float)c * lut[i]                                              */
+ * lut == NULL: no quantisation; otherwise coefficients are divided by lut[i] before
+ * rounding (fwd) and multiplied by it again (inv).  The exact arithmetic -- AAN butterflies,
+ * where each scale factor and each rounding sits -- is defined in dct_oracle.c next to
+ * own_tables().                                                                        */
 int orc_fwd_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
                 size_t sizeX, size_t sizeY, size_t by0, size_t by1);
 int orc_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,

@@ -91,10 +91,13 @@ int count_blocks(size_t bpr, size_t rows, uint32_t *n)
   return MDCT_SUCCESS;
 }
 
+// The fast quantiser forms are exact only while |coefficient * q| < 2^31 (see "Quantisers" in
+// mdct_kernels.hip).  |coefficient| <= 2040 for 8-bit input in every reference tier, so any
+// |q| <= 2^17 is safe; beyond that, or for inf/NaN, the exact x86-convert emulation is used.
 bool table_needs_safe(const float *q)
 {
   for (int i = 0; i < 64; i++)
-    if (!std::isfinite(q[i]) || std::fabs(q[i]) > 1048576.0f)
+    if (!std::isfinite(q[i]) || std::fabs(q[i]) > 131072.0f)
       return true;
   return false;
 }
@@ -112,13 +115,43 @@ int own_plane_args(const void *from, const void *to, size_t esz, size_t pitch_in
   return MDCT_SUCCESS;
 }
 
-void make_lut_pair(const float *lut, mdct::LutPair &lp)
+// AAN scale factors a_0 = 1, a_k = sqrt(2) cos(k pi / 16); the 2-D tables are products of
+// doubles rounded once to float (the CPU checker uses the identical expression).
+const double kAanScale[8] = {1.0, 1.387039845322148, 1.306562964876377, 1.175875602419359, 1.0, 0.785694958387102, 0.541196100146197, 0.275899379282943};
+
+void aan_tables_compute(float *fwd, float *inv)
 {
+  for (int v = 0; v < 8; v++)
+    for (int u = 0; u < 8; u++)
+    {
+      const double a = kAanScale[v] * kAanScale[u];
+      fwd[v * 8 + u] = (float)(1.0 / (8.0 * a));
+      inv[v * 8 + u] = (float)(a / 8.0);
+    }
+}
+
+void aan_tables(float *fwd, float *inv)
+{
+  static float s_fwd[64], s_inv[64];
+  static std::once_flag once;
+  std::call_once(once, [] { aan_tables_compute(s_fwd, s_inv); });
+  memcpy(fwd, s_fwd, sizeof(s_fwd));
+  memcpy(inv, s_inv, sizeof(s_inv));
+}
+
+// forward multiplier = (1/lut) * scale, inverse multiplier = lut * scale, each one float op
+int make_own_tables(const float *lut, mdct::OwnTables &tb)
+{
+  float ft[64], it[64];
+  aan_tables(ft, it);
   for (int i = 0; i < 64; i++)
   {
-    lp.lut[i] = lut ? lut[i] : 1.0f;
-    lp.rq[i] = lut ? 1.0f / lut[i] : 1.0f;
+    if (lut && !(std::isfinite(lut[i]) && lut[i] != 0.0f))
+      return fail(MDCT_INVALID_PARAMETER, "quantisation table entry %d is %g; the int16 paths need finite non-zero entries", i, (double)lut[i]);
+    tb.qf[i] = lut ? (1.0f / lut[i]) * ft[i] : ft[i];
+    tb.dq[i] = lut ? lut[i] * it[i] : it[i];
   }
+  return MDCT_SUCCESS;
 }
 
 int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
@@ -139,7 +172,8 @@ int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t 
   a.by0 = (uint32_t)by0;
   if ((r = count_blocks(sizeX / 8, by1 - by0, &a.nblocks)))
     return r;
-  make_lut_pair(lut, a.lp);
+  if ((r = make_own_tables(lut, a.tb)))
+    return r;
   const hipError_t e = mdct::launch_i16(a, mode, lut != nullptr, (hipStream_t)stream);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "i16 kernel launch");
 }
@@ -161,6 +195,11 @@ int run_f32(int mode, const float *from, float *to, size_t pitch_in, size_t pitc
   a.by0 = (uint32_t)by0;
   if ((r = count_blocks(sizeX / 8, by1 - by0, &a.nblocks)))
     return r;
+  {
+    float ft[64], it[64];
+    aan_tables(ft, it);
+    memcpy(a.scale, mode == mdct::MODE_FWD ? ft : it, sizeof(a.scale));
+  }
   const hipError_t e = mdct::launch_f32(a, mode, (hipStream_t)stream);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "f32 kernel launch");
 }
@@ -220,6 +259,7 @@ int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const f
 
   mdct::U8Args a;
   memset(&a, 0, sizeof(a));
+  a.consts = mdct::DctConsts();
   a.from = from;
   a.to = to;
   constexpr float vr = .95f;
@@ -286,6 +326,7 @@ int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *
   {
     mdct::PlaneBatchArgs a;
     memset(&a, 0, sizeof(a));
+    a.consts = mdct::DctConsts();
     a.n = n_planes - base < mdct::kMaxPlanes ? n_planes - base : mdct::kMaxPlanes;
     uint64_t run = 0;
     for (int i = 0; i < a.n; i++)
@@ -303,7 +344,8 @@ int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *
       if (run > 0x7FFFFFFFull)
         return fail(MDCT_NOT_SUPPORTED, "plane batch exceeds the 2^31 block limit");
       a.has_lut[i] = p.lut != nullptr;
-      make_lut_pair(p.lut, a.lp[i]);
+      if ((r = make_own_tables(p.lut, a.tb[i])))
+        return r;
     }
     a.prefix[a.n] = (uint32_t)run;
     const hipError_t e = mdct::launch_i16_planes(a, (hipStream_t)stream);

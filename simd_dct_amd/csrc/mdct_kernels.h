@@ -16,6 +16,29 @@ enum { MODE_FWD = 0, MODE_INV = 1, MODE_ROUNDTRIP = 2 };
 
 constexpr int kMaxPlanes = 4;
 
+// simd_dct.cpp:140-146: sqrt(2)*cos(k*pi/16) for k = 1,2,3,5,6,7 and 1/sqrt(8), as the
+// reference's float literals.  Passed by value in every argument block (see mdct_kernels.hip).
+struct DctConsts
+{
+  // engine-own AAN butterfly (the CPU checker uses the same literals): cos(pi/4), cos(3pi/8), cos(pi/8)-+cos(3pi/8),
+  // sqrt(2), 2cos(pi/8), 2(cos(pi/8)-+cos(3pi/8))
+  float c707 = 0.707106781186547524f;
+  float c382 = 0.382683432365089772f;
+  float c541 = 0.541196100146196985f;
+  float c1306 = 1.306562964876376528f;
+  float c1414 = 1.414213562373095049f;
+  float c1847 = 1.847759065022573512f;
+  float c1082 = 1.082392200292393968f;
+  float c2613 = 2.613125929752753056f;
+  float a = 1.3870398453221474618216191915664f;
+  float b = 1.3065629648763765278566431734272f;
+  float c = 1.1758756024193587169744671046113f;
+  float d = 0.78569495838710218127789736765722f;
+  float e = 0.54119610014619698439972320536639f;
+  float f = 0.27589937928294301233595756366937f;
+  float n = 0.35355339059327376220042218105242f;
+};
+
 // 64 quantiser multipliers, passed BY VALUE in the kernarg segment so the kernel reads
 // them with scalar loads (wave-uniform, no VGPR or LDS cost).
 struct QuantTable
@@ -23,10 +46,12 @@ struct QuantTable
   float q[64];
 };
 
-struct LutPair
+// engine-own paths: forward multiplier (AAN scale, times 1/lut when quantising) and
+// inverse multiplier (AAN scale, times lut when dequantising), index v*8+u
+struct OwnTables
 {
-  float rq[64];  // 1.0f / lut[i]  (forward quantise multiplier)
-  float lut[64]; // dequantise multiplier
+  float qf[64];
+  float dq[64];
 };
 
 struct U8Args
@@ -34,6 +59,7 @@ struct U8Args
   const uint8_t *from;
   uint8_t *to;
   QuantTable qt;
+  DctConsts consts;
   size_t pitch;        // input row pitch, bytes
   size_t sizeX;        // plane width, bytes (output addressing)
   size_t eye_offset;   // STEREO: byte offset of the second image
@@ -50,7 +76,8 @@ struct I16Args
 {
   const int16_t *from;
   int16_t *to;
-  LutPair lp;
+  OwnTables tb;
+  DctConsts consts;
   size_t pitch_in, pitch_out; // elements
   uint32_t bpr, by0, nblocks;
 };
@@ -59,6 +86,8 @@ struct F32Args
 {
   const float *from;
   float *to;
+  float scale[64]; // AAN forward or inverse scale table
+  DctConsts consts;
   size_t pitch_in, pitch_out; // elements
   uint32_t bpr, by0, nblocks;
 };
@@ -73,7 +102,8 @@ struct PlaneBatchArgs
   uint32_t prefix[kMaxPlanes + 1]; // exclusive scan of the block counts padded to whole waves
   uint32_t has_lut[kMaxPlanes];    // 0: plain fwd->inv, 1: quantise/dequantise in between
   int n;
-  LutPair lp[kMaxPlanes];
+  DctConsts consts;
+  OwnTables tb[kMaxPlanes];
 };
 
 hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool safe, hipStream_t s);

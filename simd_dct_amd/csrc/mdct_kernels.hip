@@ -23,14 +23,10 @@
 namespace mdct
 {
 
-// simd_dct.cpp:140-146
-__device__ constexpr float kCa = 1.3870398453221474618216191915664f;
-__device__ constexpr float kCb = 1.3065629648763765278566431734272f;
-__device__ constexpr float kCc = 1.1758756024193587169744671046113f;
-__device__ constexpr float kCd = 0.78569495838710218127789736765722f;
-__device__ constexpr float kCe = 0.54119610014619698439972320536639f;
-__device__ constexpr float kCf = 0.27589937928294301233595756366937f;
-__device__ constexpr float kCn = 0.35355339059327376220042218105242f;
+// The seven butterfly constants (simd_dct.cpp:140-146) travel in the kernarg segment
+// (DctConsts, mdct_kernels.h) and therefore live in SGPRs: a VALU op with an SGPR operand is
+// a 4-byte encoding, the same op with a 32-bit literal is 8 bytes, and these kernels are
+// ~2000 straight-line VALU instructions per wave.
 
 enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2, K_OWN = 3 };
 
@@ -38,8 +34,9 @@ enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2, K_OWN = 3 };
 // 1-D 8-point forward kernel on eight registers.
 // ---------------------------------------------------------------------------------------
 template <int K>
-__device__ __forceinline__ void dct8(float &p0, float &p1, float &p2, float &p3, float &p4, float &p5, float &p6, float &p7)
+__device__ __forceinline__ void dct8(const DctConsts &C, float &p0, float &p1, float &p2, float &p3, float &p4, float &p5, float &p6, float &p7)
 {
+  const float kCa = C.a, kCb = C.b, kCc = C.c, kCd = C.d, kCe = C.e, kCf = C.f, kCn = C.n;
   const float x07p = p0 + p7, x16p = p1 + p6, x25p = p2 + p5, x34p = p3 + p4;
   const float x07m = p0 - p7, x61m = p6 - p1, x25m = p2 - p5, x43m = p4 - p3;
   const float pp = x07p + x34p, pm = x07p - x34p;
@@ -90,91 +87,151 @@ __device__ __forceinline__ void dct8(float &p0, float &p1, float &p2, float &p3,
   p4 = kCn * o4; p5 = kCn * o5; p6 = kCn * o6; p7 = kCn * o7;
 }
 
-// Inverse of K_OWN (transposed flow graph).
-__device__ __forceinline__ void idct8(float &p0, float &p1, float &p2, float &p3, float &p4, float &p5, float &p6, float &p7)
+// ---------------------------------------------------------------------------------------
+// Engine-own 1-D kernels (int16 / float32 paths; no reference counterpart): the scaled
+// Arai-Agui-Nakajima butterfly, 5 mul + 29 add per 8 points instead of 24 + 32.  Measured
+// on MI355X (tools/valubench, tools/exp_roundtrip): these kernels are bound by VALU ISSUE,
+// v_add/v_mul_f32 issue at ~2-3 cycles per wave64, v_fma_f32 and v_pk_*_f32 at ~4-5, so
+// neither fusing nor packing buys anything -- only fewer operations do.  The scale factors
+// live in 64-entry tables applied where a multiply exists anyway (quantise / dequantise),
+// and for the fused round trip they cancel to exactly 1/64, which the final rounding step
+// absorbs (see store_i16x8).  Same operation order as the CPU checker (orc_aan_*).
+// ---------------------------------------------------------------------------------------
+struct AanK
 {
-  const float a0 = p0 + p4, a1 = p0 - p4;
-  const float b0 = (kCb * p2) + (kCe * p6);
-  const float b1 = (kCe * p2) - (kCb * p6);
-  const float e0 = a0 + b0, e1 = a1 + b1, e2 = a1 - b1, e3 = a0 - b0;
+  float c707, c382, c541, c1306, c1414, c1847, c1082, c2613;
+};
 
-  const float d0 = ((kCa * p1) + (kCc * p3)) + ((kCd * p5) + (kCf * p7));
-  const float d1 = ((kCc * p1) - (kCf * p3)) - ((kCa * p5) + (kCd * p7));
-  const float d2 = ((kCd * p1) - (kCa * p3)) + ((kCf * p5) + (kCc * p7));
-  const float d3 = ((kCf * p1) - (kCd * p3)) + ((kCc * p5) - (kCa * p7));
-
-  p0 = kCn * (e0 + d0); p7 = kCn * (e0 - d0);
-  p1 = kCn * (e1 + d1); p6 = kCn * (e1 - d1);
-  p2 = kCn * (e2 + d2); p5 = kCn * (e2 - d2);
-  p3 = kCn * (e3 + d3); p4 = kCn * (e3 - d3);
+__device__ __forceinline__ void aan_fwd8(const DctConsts &C, float &p0, float &p1, float &p2, float &p3, float &p4, float &p5, float &p6, float &p7)
+{
+  const float t0 = p0 + p7, t7 = p0 - p7, t1 = p1 + p6, t6 = p1 - p6;
+  const float t2 = p2 + p5, t5 = p2 - p5, t3 = p3 + p4, t4 = p3 - p4;
+  const float e10 = t0 + t3, e13 = t0 - t3, e11 = t1 + t2, e12 = t1 - t2;
+  const float z1 = (e12 + e13) * C.c707;
+  const float o10 = t4 + t5, o11 = t5 + t6, o12 = t6 + t7;
+  const float z5 = (o10 - o12) * C.c382;
+  const float z2 = (C.c541 * o10) + z5;
+  const float z4 = (C.c1306 * o12) + z5;
+  const float z3 = o11 * C.c707;
+  const float z11 = t7 + z3, z13 = t7 - z3;
+  p0 = e10 + e11;
+  p4 = e10 - e11;
+  p2 = e13 + z1;
+  p6 = e13 - z1;
+  p5 = z13 + z2;
+  p3 = z13 - z2;
+  p1 = z11 + z4;
+  p7 = z11 - z4;
 }
 
-template <int K>
-__device__ __forceinline__ void pass_rows(float (&b)[8][8])
+__device__ __forceinline__ void aan_inv8(const DctConsts &C, float &p0, float &p1, float &p2, float &p3, float &p4, float &p5, float &p6, float &p7)
+{
+  const float e10 = p0 + p4, e11 = p0 - p4;
+  const float e13 = p2 + p6;
+  const float e12 = ((p2 - p6) * C.c1414) - e13;
+  const float t0 = e10 + e13, t3 = e10 - e13, t1 = e11 + e12, t2 = e11 - e12;
+  const float z13 = p5 + p3, z10 = p5 - p3, z11 = p1 + p7, z12 = p1 - p7;
+  const float t7 = z11 + z13;
+  const float o11 = (z11 - z13) * C.c1414;
+  const float z5 = (z10 + z12) * C.c1847;
+  const float o10 = (C.c1082 * z12) - z5;
+  const float o12 = z5 - (C.c2613 * z10);
+  const float t6 = o12 - t7;
+  const float t5 = o11 - t6;
+  const float t4 = o10 + t5;
+  p0 = t0 + t7;
+  p7 = t0 - t7;
+  p1 = t1 + t6;
+  p6 = t1 - t6;
+  p2 = t2 + t5;
+  p5 = t2 - t5;
+  p4 = t3 + t4;
+  p3 = t3 - t4;
+}
+
+__device__ __forceinline__ void raw_fwd(const DctConsts &C, float (&b)[8][8])
 {
 #pragma unroll
   for (int r = 0; r < 8; r++)
-    dct8<K>(b[r][0], b[r][1], b[r][2], b[r][3], b[r][4], b[r][5], b[r][6], b[r][7]);
+    aan_fwd8(C, b[r][0], b[r][1], b[r][2], b[r][3], b[r][4], b[r][5], b[r][6], b[r][7]);
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    aan_fwd8(C, b[0][c], b[1][c], b[2][c], b[3][c], b[4][c], b[5][c], b[6][c], b[7][c]);
+}
+
+__device__ __forceinline__ void raw_inv(const DctConsts &C, float (&b)[8][8])
+{
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    aan_inv8(C, b[0][c], b[1][c], b[2][c], b[3][c], b[4][c], b[5][c], b[6][c], b[7][c]);
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    aan_inv8(C, b[r][0], b[r][1], b[r][2], b[r][3], b[r][4], b[r][5], b[r][6], b[r][7]);
 }
 
 template <int K>
-__device__ __forceinline__ void pass_cols(float (&b)[8][8])
-{
-#pragma unroll
-  for (int c = 0; c < 8; c++)
-    dct8<K>(b[0][c], b[1][c], b[2][c], b[3][c], b[4][c], b[5][c], b[6][c], b[7][c]);
-}
-
-__device__ __forceinline__ void ipass_rows(float (&b)[8][8])
+__device__ __forceinline__ void pass_rows(const DctConsts &C, float (&b)[8][8])
 {
 #pragma unroll
   for (int r = 0; r < 8; r++)
-    idct8(b[r][0], b[r][1], b[r][2], b[r][3], b[r][4], b[r][5], b[r][6], b[r][7]);
+    dct8<K>(C, b[r][0], b[r][1], b[r][2], b[r][3], b[r][4], b[r][5], b[r][6], b[r][7]);
 }
 
-__device__ __forceinline__ void ipass_cols(float (&b)[8][8])
+template <int K>
+__device__ __forceinline__ void pass_cols(const DctConsts &C, float (&b)[8][8])
 {
 #pragma unroll
   for (int c = 0; c < 8; c++)
-    idct8(b[0][c], b[1][c], b[2][c], b[3][c], b[4][c], b[5][c], b[6][c], b[7][c]);
+    dct8<K>(C, b[0][c], b[1][c], b[2][c], b[3][c], b[4][c], b[5][c], b[6][c], b[7][c]);
 }
 
 // ---------------------------------------------------------------------------------------
-// Quantisers.  x86 cvtps_epi32 = RNE, "integer indefinite" 0x80000000 when out of range
-// or NaN.  CDNA v_cvt_i32_f32 saturates and maps NaN to 0, so the result after the
-// reference's bias+clamp differs only for NaN (x86: 0x80000000 -> clamp -> 0) and, for
-// the float-bias tiers, for +overflow; SAFE handles exactly those (reachable only with
-// non-finite or absurd quantisers -- the host picks SAFE when a table entry is not finite
-// or exceeds 2^20, see mdct_api.hip).
+// Quantisers.  They return a word whose LOW BYTE is the quantised coefficient (the upper
+// bits are not cleaned: every consumer stores or packs the low byte only).
+//
+// x86 cvtps_epi32 = RNE, "integer indefinite" 0x80000000 when out of range or NaN
+// (simd_dct.cpp:2224, :1020).  For |v| < 2^31 the reference's clamp(127 + rne(v), 0, 255)
+// equals 127 + rne(clamp(v, -127, 128)) (rne is monotone and the bounds are integers), and
+// rne of a value in that range is the low byte of the float  v + 1.5*2^23  (the add rounds
+// to nearest-even at unit granularity; 1.5*2^23 is even, so ties go the same way).  That is
+// the fast form: v_mul, v_med3_f32, v_add_f32, v_add_u32 -- no convert instructions.
+// The host selects SAFE (explicit emulation of the indefinite value) whenever a multiplier
+// is non-finite or larger than 2^17: |coefficient| <= 2040 in every tier, so below that
+// bound |v| < 2^31 always holds (mdct_api.hip).
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int32_t cvt_rne(float v) { return (int32_t)__builtin_rintf(v); } // v_rndne_f32 + v_cvt_i32_f32
 
-template <bool SAFE>
-__device__ __forceinline__ int32_t cvtps_epi32(float v)
+__device__ __forceinline__ int32_t cvtps_epi32_exact(float v)
 {
-  if constexpr (SAFE)
-  {
-    if (!(__builtin_fabsf(v) < 2147483648.0f))
-      return INT32_MIN;
-  }
+  if (!(__builtin_fabsf(v) < 2147483648.0f))
+    return INT32_MIN;
   return cvt_rne(v);
 }
 
 __device__ __forceinline__ int32_t clamp255(int32_t v) { return min(max(v, 0), 255); } // v_med3_i32
 
-// B1 :2224  clamp(127 + rne(f*q))   (wrapping int32 add, like _mm256_add_epi32)
+constexpr float kMagic23 = 12582912.0f; // 1.5 * 2^23
+
+// B1 :2224  clamp(127 + rne(f*q), 0, 255)   (wrapping int32 add, like _mm256_add_epi32)
 template <bool SAFE>
 __device__ __forceinline__ uint32_t quant_avx(float f, float q)
 {
-  const int32_t r = cvtps_epi32<SAFE>(f * q);
-  return (uint32_t)clamp255((int32_t)((uint32_t)r + 127u));
+  const float v = f * q;
+  if constexpr (SAFE)
+    return (uint32_t)clamp255((int32_t)((uint32_t)cvtps_epi32_exact(v) + 127u));
+  else
+    return __float_as_uint(__builtin_amdgcn_fmed3f(v, -127.0f, 128.0f) + kMagic23) + 127u;
 }
 
-// B2/B3 :1020  clamp(rne(f*q + 127.0f))
+// B2/B3 :1020  clamp(rne(f*q + 127.0f), 0, 255)
 template <bool SAFE>
 __device__ __forceinline__ uint32_t quant_sse(float f, float q)
 {
-  return (uint32_t)clamp255(cvtps_epi32<SAFE>((f * q) + 127.0f));
+  const float v = (f * q) + 127.0f;
+  if constexpr (SAFE)
+    return (uint32_t)clamp255(cvtps_epi32_exact(v));
+  else
+    return __float_as_uint(__builtin_amdgcn_fmed3f(v, 0.0f, 255.0f) + kMagic23);
 }
 
 // B4/B5 :245, :362  (uint8_t)roundf(_clamp(f*qs + 127/255, 0, 1) * 255)
@@ -191,7 +248,11 @@ __device__ __forceinline__ uint32_t quant_scalar(float f, float qs)
 __device__ __forceinline__ uint2 load8(const uint8_t *p, bool aligned)
 {
   if (aligned)
-    return *reinterpret_cast<const uint2 *>(p);
+  {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p)); // streamed once
+    return make_uint2(v.x, v.y);
+  }
   uint2 v;
   v.x = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
   v.y = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
@@ -214,7 +275,7 @@ __device__ __forceinline__ float px_to_float(uint32_t px)
 // quantised bytes as int values q[v][u] (natural index) for the AVX/stereo layouts or
 // q[u][v]-transposed-stored semantics handled by the caller.
 template <int PROFILE, int LAYOUT, bool SAFE>
-__device__ __forceinline__ void encode_block(const uint8_t *src, size_t pitch, bool aligned, const QuantTable &qt, uint32_t (&out)[64])
+__device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *src, size_t pitch, bool aligned, const QuantTable &qt, uint32_t (&out)[64])
 {
   float b[8][8];
 #pragma unroll
@@ -236,13 +297,13 @@ __device__ __forceinline__ void encode_block(const uint8_t *src, size_t pitch, b
   // Q32 and the encq tiers run rows then columns (:2158/:2189, :347-358, :1608-1636).
   if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
   {
-    pass_cols<K>(b);
-    pass_rows<K>(b);
+    pass_cols<K>(C, b);
+    pass_rows<K>(C, b);
   }
   else
   {
-    pass_rows<K>(b);
-    pass_cols<K>(b);
+    pass_rows<K>(C, b);
+    pass_cols<K>(C, b);
   }
 
   // Stored index s: natural v*8+u for Q32/STEREO, transposed u*8+v for the encq tiers,
@@ -259,6 +320,14 @@ __device__ __forceinline__ void encode_block(const uint8_t *src, size_t pitch, b
     else
       out[s] = quant_scalar(f, qt.q[s]);
   }
+}
+
+// four low bytes -> one dword, upper bits of the inputs ignored (3 x v_perm_b32)
+__device__ __forceinline__ uint32_t pack4_lo8(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+  const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x0c0c0400u);
+  const uint32_t cd = __builtin_amdgcn_perm(d, c, 0x0c0c0400u);
+  return __builtin_amdgcn_perm(cd, ab, 0x05040100u);
 }
 
 constexpr int kWG = 256;           // 4 waves
@@ -291,7 +360,7 @@ __global__ __launch_bounds__(kWG) void k_fwd_quant_u8(U8Args a)
     const uint8_t *src = a.from + (size_t)by * 8 * a.pitch + (size_t)bx * 8;
     if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
       src += (size_t)eye * a.eye_offset;
-    encode_block<PROFILE, LAYOUT, SAFE>(src, a.pitch, a.aligned8 != 0, a.qt, q);
+    encode_block<PROFILE, LAYOUT, SAFE>(a.consts, src, a.pitch, a.aligned8 != 0, a.qt, q);
   }
 
   if constexpr (LAYOUT == MDCT_LAYOUT_Q32)
@@ -325,7 +394,9 @@ __global__ __launch_bounds__(kWG) void k_fwd_quant_u8(U8Args a)
       {
         const uint2 lo = *reinterpret_cast<const uint2 *>(wl + c2 * kQ32RowStride + g * 8);
         const uint2 hi = *reinterpret_cast<const uint2 *>(wl + (c2 + 1) * kQ32RowStride + g * 8);
-        *reinterpret_cast<uint4 *>(outw + g * 512 + c2 * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t v = {lo.x, lo.y, hi.x, hi.y};
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(outw + g * 512 + c2 * 8));
       }
     }
   }
@@ -350,7 +421,7 @@ __global__ __launch_bounds__(kWG) void k_fwd_quant_u8(U8Args a)
         uint32_t w[4];
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          w[j] = q[k * 16 + j * 4] | (q[k * 16 + j * 4 + 1] << 8) | (q[k * 16 + j * 4 + 2] << 16) | (q[k * 16 + j * 4 + 3] << 24);
+          w[j] = pack4_lo8(q[k * 16 + j * 4], q[k * 16 + j * 4 + 1], q[k * 16 + j * 4 + 2], q[k * 16 + j * 4 + 3]);
         *reinterpret_cast<uint4 *>(dst + k * 16) = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
@@ -365,11 +436,11 @@ __global__ __launch_bounds__(kWG) void k_fwd_quant_u8(U8Args a)
 #pragma unroll
       for (int i8 = 0; i8 < 8; i8++)
       {
-        const uint32_t lo = q[i8 * 8 + 0] | (q[i8 * 8 + 1] << 8) | (q[i8 * 8 + 4] << 16) | (q[i8 * 8 + 5] << 24);
+        const uint32_t lo = pack4_lo8(q[i8 * 8 + 0], q[i8 * 8 + 1], q[i8 * 8 + 4], q[i8 * 8 + 5]);
         *reinterpret_cast<uint32_t *>(base + i8 * 8) = lo;
         if (spill)
         {
-          const uint32_t hi = q[i8 * 8 + 2] | (q[i8 * 8 + 3] << 8) | (q[i8 * 8 + 6] << 16) | (q[i8 * 8 + 7] << 24);
+          const uint32_t hi = pack4_lo8(q[i8 * 8 + 2], q[i8 * 8 + 3], q[i8 * 8 + 6], q[i8 * 8 + 7]);
           *reinterpret_cast<uint32_t *>(base + 128 + i8 * 8) = hi;
         }
       }
@@ -380,10 +451,22 @@ __global__ __launch_bounds__(kWG) void k_fwd_quant_u8(U8Args a)
 // ---------------------------------------------------------------------------------------
 // int16 / float32 engine-own kernels: plane layout in and out, 16 B per lane per row, so
 // every global access is a fully coalesced 1 KiB wave transaction and no LDS is needed.
+// The planes are streamed exactly once: loads and stores are non-temporal (measured
+// +6..10 % over plain on a read-N/write-N stream, tools/membench).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t sat_i16_rne(float v)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint4 ld_stream16(const void *p)
 {
-  return min(max(cvt_rne(v), -32768), 32767);
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ void st_stream16(void *p, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{
+  const u32x4 v = {x, y, z, w};
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
 }
 
 __device__ __forceinline__ void unpack_i16x8(const uint4 v, float (&row)[8])
@@ -394,58 +477,78 @@ __device__ __forceinline__ void unpack_i16x8(const uint4 v, float (&row)[8])
   row[6] = (float)(int16_t)(v.w & 0xFFFF); row[7] = (float)(int16_t)(v.w >> 16);
 }
 
-__device__ __forceinline__ uint32_t pack2(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+// sat_i16(rne(v * 2^-SHIFT)) without a convert: clamp in float (bounds are multiples of
+// 2^SHIFT, so clamping commutes with the rounding), then add 1.5 * 2^(23+SHIFT).  The sum's
+// ulp is 2^SHIFT, the add rounds to nearest-even in exactly those units, and because the
+// magic constant's low 16 mantissa bits are zero and its integer part is even, the low 16
+// bits of the result ARE the two's-complement int16.  SHIFT = 6 is the fused round trip's
+// 1/64.  Returns the raw bits; callers keep the low half.
+template <int SHIFT>
+__device__ __forceinline__ uint32_t rne_i16_bits(float v)
+{
+  constexpr float scale = (float)(1 << SHIFT);
+  const float m = __builtin_amdgcn_fmed3f(v, -32768.0f * scale, 32767.0f * scale);
+  return __float_as_uint(m + 12582912.0f * scale);
+}
+
+// the same rounding, result as a float integer (for quantise -> dequantise in registers)
+__device__ __forceinline__ float rne_i16_float(float v)
+{
+  const float m = __builtin_amdgcn_fmed3f(v, -32768.0f, 32767.0f);
+  return (m + 12582912.0f) - 12582912.0f;
+}
+
+__device__ __forceinline__ uint32_t pack_lo16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }
+
+template <int SHIFT>
+__device__ __forceinline__ void store_i16x8(int16_t *dst, const float (&row)[8])
+{
+  uint32_t t[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    t[c] = rne_i16_bits<SHIFT>(row[c]);
+  st_stream16(dst, pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
+}
 
 template <int MODE, bool HAS_LUT>
-__device__ __forceinline__ void i16_block(const int16_t *src, int16_t *dst, size_t pitch_in, size_t pitch_out, const LutPair &lp)
+__device__ __forceinline__ void i16_block(const DctConsts &C, const int16_t *src, int16_t *dst, size_t pitch_in, size_t pitch_out, const OwnTables &tb)
 {
   float b[8][8];
 #pragma unroll
   for (int r = 0; r < 8; r++)
-    unpack_i16x8(*reinterpret_cast<const uint4 *>(src + (size_t)r * pitch_in), b[r]);
+    unpack_i16x8(ld_stream16(src + (size_t)r * pitch_in), b[r]);
 
   if constexpr (MODE == MODE_INV)
   {
-    if constexpr (HAS_LUT)
-    {
 #pragma unroll
-      for (int i = 0; i < 64; i++)
-        b[i >> 3][i & 7] = b[i >> 3][i & 7] * lp.lut[i];
-    }
+    for (int i = 0; i < 64; i++)
+      b[i >> 3][i & 7] = b[i >> 3][i & 7] * tb.dq[i];
   }
   else
-  {
-    pass_rows<K_OWN>(b);
-    pass_cols<K_OWN>(b);
-  }
+    raw_fwd(C, b);
 
-  if constexpr (MODE == MODE_ROUNDTRIP && HAS_LUT)
+  if constexpr (MODE == MODE_FWD)
   {
 #pragma unroll
     for (int i = 0; i < 64; i++)
-      b[i >> 3][i & 7] = (float)sat_i16_rne(b[i >> 3][i & 7] * lp.rq[i]) * lp.lut[i];
+      b[i >> 3][i & 7] = b[i >> 3][i & 7] * tb.qf[i];
   }
-
-  if constexpr (MODE != MODE_FWD)
+  else
   {
-    ipass_cols(b);
-    ipass_rows(b);
+    if constexpr (MODE == MODE_ROUNDTRIP && HAS_LUT)
+    {
+#pragma unroll
+      for (int i = 0; i < 64; i++)
+        b[i >> 3][i & 7] = rne_i16_float(b[i >> 3][i & 7] * tb.qf[i]) * tb.dq[i];
+    }
+    raw_inv(C, b);
   }
 
+  // fused round trip without a table: forward-scale * inverse-scale == 1/64 exactly
+  constexpr int SHIFT = (MODE == MODE_ROUNDTRIP && !HAS_LUT) ? 6 : 0;
 #pragma unroll
   for (int r = 0; r < 8; r++)
-  {
-    int32_t o[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++)
-    {
-      float f = b[r][c];
-      if constexpr (MODE == MODE_FWD && HAS_LUT)
-        f = f * lp.rq[r * 8 + c];
-      o[c] = sat_i16_rne(f);
-    }
-    *reinterpret_cast<uint4 *>(dst + (size_t)r * pitch_out) = make_uint4(pack2(o[0], o[1]), pack2(o[2], o[3]), pack2(o[4], o[5]), pack2(o[6], o[7]));
-  }
+    store_i16x8<SHIFT>(dst + (size_t)r * pitch_out, b[r]);
 }
 
 template <int MODE, bool HAS_LUT>
@@ -457,7 +560,7 @@ __global__ __launch_bounds__(kWG) void k_i16(I16Args a)
   const uint32_t row = t / a.bpr;
   const uint32_t bx = t - row * a.bpr;
   const size_t by = a.by0 + row;
-  i16_block<MODE, HAS_LUT>(a.from + by * 8 * a.pitch_in + (size_t)bx * 8, a.to + by * 8 * a.pitch_out + (size_t)bx * 8, a.pitch_in, a.pitch_out, a.lp);
+  i16_block<MODE, HAS_LUT>(a.consts, a.from + by * 8 * a.pitch_in + (size_t)bx * 8, a.to + by * 8 * a.pitch_out + (size_t)bx * 8, a.pitch_in, a.pitch_out, a.tb);
 }
 
 // Several planes (each with its own table) in one launch: linear block index over the
@@ -484,9 +587,9 @@ __global__ __launch_bounds__(kWG) void k_i16_planes(PlaneBatchArgs a)
   const int16_t *src = a.from[p] + (size_t)row * 8 * pin + (size_t)bx * 8;
   int16_t *dst = a.to[p] + (size_t)row * 8 * pout + (size_t)bx * 8;
   if (a.has_lut[p])
-    i16_block<MODE_ROUNDTRIP, true>(src, dst, pin, pout, a.lp[p]);
+    i16_block<MODE_ROUNDTRIP, true>(a.consts, src, dst, pin, pout, a.tb[p]);
   else
-    i16_block<MODE_ROUNDTRIP, false>(src, dst, pin, pout, a.lp[p]);
+    i16_block<MODE_ROUNDTRIP, false>(a.consts, src, dst, pin, pout, a.tb[p]);
 }
 
 template <int MODE>
@@ -500,40 +603,63 @@ __global__ __launch_bounds__(kWG) void k_f32(F32Args a)
   const size_t by = a.by0 + row;
   const float *src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
   float *dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
+  const DctConsts &C = a.consts;
 
   float b[8][8];
 #pragma unroll
   for (int r = 0; r < 8; r++)
   {
-    const float4 lo = *reinterpret_cast<const float4 *>(src + (size_t)r * a.pitch_in);
-    const float4 hi = *reinterpret_cast<const float4 *>(src + (size_t)r * a.pitch_in + 4);
+    const f32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)r * a.pitch_in));
+    const f32x4 hi = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)r * a.pitch_in + 4));
     b[r][0] = lo.x; b[r][1] = lo.y; b[r][2] = lo.z; b[r][3] = lo.w;
     b[r][4] = hi.x; b[r][5] = hi.y; b[r][6] = hi.z; b[r][7] = hi.w;
   }
   if constexpr (MODE == MODE_FWD)
   {
-    pass_rows<K_OWN>(b);
-    pass_cols<K_OWN>(b);
+    raw_fwd(C, b);
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+      b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.scale[i];
   }
   else
   {
-    ipass_cols(b);
-    ipass_rows(b);
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+      b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.scale[i];
+    raw_inv(C, b);
   }
 #pragma unroll
   for (int r = 0; r < 8; r++)
   {
-    *reinterpret_cast<float4 *>(dst + (size_t)r * a.pitch_out) = make_float4(b[r][0], b[r][1], b[r][2], b[r][3]);
-    *reinterpret_cast<float4 *>(dst + (size_t)r * a.pitch_out + 4) = make_float4(b[r][4], b[r][5], b[r][6], b[r][7]);
+    const f32x4 lo = {b[r][0], b[r][1], b[r][2], b[r][3]};
+    const f32x4 hi = {b[r][4], b[r][5], b[r][6], b[r][7]};
+    __builtin_nontemporal_store(lo, reinterpret_cast<f32x4 *>(dst + (size_t)r * a.pitch_out));
+    __builtin_nontemporal_store(hi, reinterpret_cast<f32x4 *>(dst + (size_t)r * a.pitch_out + 4));
   }
 }
 
-// read-N / write-N stream copy, 16 B per lane, grid-stride: the box's measured HBM roofline.
-__global__ __launch_bounds__(kWG) void k_stream_copy(const uint4 *__restrict__ from, uint4 *__restrict__ to, size_t n16)
+// read-N / write-N stream copy, 8 x 16 B per lane, non-temporal: the box's measured HBM roofline
+// (tools/membench: this shape is the fastest of those tried, ~6.2 TB/s).
+constexpr int kCopyUnroll = 8;
+__global__ __launch_bounds__(kWG) void k_stream_copy(const u32x4 *__restrict__ from, u32x4 *__restrict__ to, size_t n16)
 {
-  const size_t stride = (size_t)gridDim.x * kWG;
-  for (size_t i = (size_t)blockIdx.x * kWG + threadIdx.x; i < n16; i += stride)
-    to[i] = from[i];
+  const size_t base = (size_t)blockIdx.x * kWG * kCopyUnroll + threadIdx.x;
+  u32x4 v[kCopyUnroll];
+  if (base + (size_t)(kCopyUnroll - 1) * kWG < n16)
+  {
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; u++)
+      v[u] = __builtin_nontemporal_load(from + base + (size_t)u * kWG);
+#pragma unroll
+    for (int u = 0; u < kCopyUnroll; u++)
+      __builtin_nontemporal_store(v[u], to + base + (size_t)u * kWG);
+  }
+  else
+  {
+    for (int u = 0; u < kCopyUnroll; u++)
+      if (base + (size_t)u * kWG < n16)
+        to[base + (size_t)u * kWG] = from[base + (size_t)u * kWG];
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -616,11 +742,10 @@ hipError_t launch_stream_copy(const void *from, void *to, size_t bytes, int cus,
   const size_t n16 = bytes / 16;
   if (n16 == 0)
     return hipSuccess;
-  size_t grid = (n16 + kWG - 1) / kWG;
-  const size_t cap = (size_t)cus * 8;
-  if (grid > cap)
-    grid = cap;
-  hipLaunchKernelGGL(k_stream_copy, dim3((uint32_t)grid), dim3(kWG), 0, s, (const uint4 *)from, (uint4 *)to, n16);
+  (void)cus;
+  const size_t per_wg = (size_t)kWG * kCopyUnroll;
+  const size_t grid = (n16 + per_wg - 1) / per_wg;
+  hipLaunchKernelGGL(k_stream_copy, dim3((uint32_t)grid), dim3(kWG), 0, s, (const u32x4 *)from, (u32x4 *)to, n16);
   return hipGetLastError();
 }
 

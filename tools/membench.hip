@@ -28,13 +28,16 @@ template <int U>
 __global__ __launch_bounds__(256) void copy_oneshot_nt(const uint4 *__restrict__ a, uint4 *__restrict__ b, size_t n)
 {
   const size_t base = (size_t)blockIdx.x * 256 * U + threadIdx.x;
-  uint4 v[U];
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  const u4 *a4 = reinterpret_cast<const u4 *>(a);
+  u4 *b4 = reinterpret_cast<u4 *>(b);
+  u4 v[U];
 #pragma unroll
   for (int u = 0; u < U; u++)
-    v[u] = __builtin_nontemporal_load(a + base + (size_t)u * 256);
+    v[u] = __builtin_nontemporal_load(a4 + base + (size_t)u * 256);
 #pragma unroll
   for (int u = 0; u < U; u++)
-    __builtin_nontemporal_store(v[u], b + base + (size_t)u * 256);
+    __builtin_nontemporal_store(v[u], b4 + base + (size_t)u * 256);
 }
 // the int16 kernels' shape: a lane owns 8 rows x 16 B of an 8192-wide int16 plane
 __global__ __launch_bounds__(256) void copy_block_rows(const uint4 *__restrict__ a, uint4 *__restrict__ b, size_t pitch16, unsigned bpr)

@@ -1,0 +1,93 @@
+// valubench2.hip -- per-instruction issue cost on gfx950 for the instructions these kernels
+// are made of: 8 waves/SIMD, 64-instruction straight-line bodies (loop overhead < 3 %).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/valubench2.hip -o tools/valubench2
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define BODY8(INS) R8(INS) R8(INS) R8(INS) R8(INS) R8(INS) R8(INS) R8(INS) R8(INS)
+
+#define DEF(NAME, ASMSTR)                                                                     \
+  __global__ __launch_bounds__(256) void NAME(float *out, int iters, unsigned *lds_dummy)      \
+  {                                                                                            \
+    __shared__ unsigned lds[256 * 8];                                                          \
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+    const float c = 1.0001f;                                                                   \
+    unsigned addr = threadIdx.x;                                                               \
+    (void)lds; (void)addr;                                                                     \
+    for (int i = 0; i < iters; i++)                                                            \
+    {                                                                                          \
+      asm volatile(ASMSTR ASMSTR ASMSTR ASMSTR ASMSTR ASMSTR ASMSTR ASMSTR                     \
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c), "v"(addr)); \
+    }                                                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)");                                                      \
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;               \
+  }
+
+#define I8(OP) OP " %0, %0, %8\n" OP " %1, %1, %8\n" OP " %2, %2, %8\n" OP " %3, %3, %8\n" OP " %4, %4, %8\n" OP " %5, %5, %8\n" OP " %6, %6, %8\n" OP " %7, %7, %8\n"
+#define U8(OP) OP " %0, %0\n" OP " %1, %1\n" OP " %2, %2\n" OP " %3, %3\n" OP " %4, %4\n" OP " %5, %5\n" OP " %6, %6\n" OP " %7, %7\n"
+#define T8(OP) OP " %0, %0, %8, %8\n" OP " %1, %1, %8, %8\n" OP " %2, %2, %8, %8\n" OP " %3, %3, %8, %8\n" OP " %4, %4, %8, %8\n" OP " %5, %5, %8, %8\n" OP " %6, %6, %8, %8\n" OP " %7, %7, %8, %8\n"
+#define S8(OP, MOD) OP " %0, %0 " MOD "\n" OP " %1, %1 " MOD "\n" OP " %2, %2 " MOD "\n" OP " %3, %3 " MOD "\n" OP " %4, %4 " MOD "\n" OP " %5, %5 " MOD "\n" OP " %6, %6 " MOD "\n" OP " %7, %7 " MOD "\n"
+#define L8 "ds_write_b8 %9, %0\n ds_write_b8 %9, %1 offset:64\n ds_write_b8 %9, %2 offset:128\n ds_write_b8 %9, %3 offset:192\n ds_write_b8 %9, %4 offset:256\n ds_write_b8 %9, %5 offset:320\n ds_write_b8 %9, %6 offset:384\n ds_write_b8 %9, %7 offset:448\n"
+#define L32 "ds_write_b32 %9, %0\n ds_write_b32 %9, %1 offset:256\n ds_write_b32 %9, %2 offset:512\n ds_write_b32 %9, %3 offset:768\n ds_write_b32 %9, %4 offset:1024\n ds_write_b32 %9, %5 offset:1280\n ds_write_b32 %9, %6 offset:1536\n ds_write_b32 %9, %7 offset:1792\n"
+#define D8 "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n" \
+           "v_mov_b32_dpp %4, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %7 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+
+DEF(k_add, I8("v_add_f32"))
+DEF(k_mul, I8("v_mul_f32"))
+DEF(k_sub, I8("v_sub_f32"))
+DEF(k_fma, T8("v_fma_f32"))
+DEF(k_addu32, I8("v_add_u32"))
+DEF(k_addu16, I8("v_add_u16"))
+DEF(k_med3f, T8("v_med3_f32"))
+DEF(k_med3i, T8("v_med3_i32"))
+DEF(k_perm, T8("v_perm_b32"))
+DEF(k_cvt_f32_i32, U8("v_cvt_f32_i32"))
+DEF(k_cvt_f32_i32_sdwa, S8("v_cvt_f32_i32_sdwa", "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"))
+DEF(k_cvt_f32_ubyte0, U8("v_cvt_f32_ubyte0"))
+DEF(k_cvt_f32_ubyte2, U8("v_cvt_f32_ubyte2"))
+DEF(k_cvt_i32_f32, U8("v_cvt_i32_f32"))
+DEF(k_rndne, U8("v_rndne_f32"))
+DEF(k_mov, U8("v_mov_b32"))
+DEF(k_lshl_or, T8("v_lshl_or_b32"))
+DEF(k_and_or, T8("v_and_or_b32"))
+DEF(k_bfe, T8("v_bfe_i32"))
+DEF(k_dpp_mov, D8)
+DEF(k_ds_write_b8, L8)
+DEF(k_ds_write_b32, L32)
+
+template <typename K>
+void run(const char *name, K kern, float *out, int per_body)
+{
+  const int iters = 2048, waves_per_simd = 8;
+  const int grid = 256 * waves_per_simd;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, out, iters, nullptr);
+  hipDeviceSynchronize();
+  float best = 1e9;
+  for (int r = 0; r < 3; r++)
+  {
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, out, iters, nullptr);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    best = ms < best ? ms : best;
+  }
+  const double instr_per_simd = (double)waves_per_simd * iters * per_body;
+  const double ns = best * 1e6 / instr_per_simd;
+  printf("%-22s %8.3f ms   %5.2f ns/instr/SIMD  = %5.2f cycles @2.4GHz (%5.2f @2.0GHz)\n", name, best, ns, ns * 2.4, ns * 2.0);
+}
+
+int main()
+{
+  float *out;
+  hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+#define RUN(K) run(#K, K, out, 64)
+  RUN(k_add); RUN(k_mul); RUN(k_sub); RUN(k_fma); RUN(k_addu32); RUN(k_addu16); RUN(k_med3f); RUN(k_med3i); RUN(k_perm);
+  RUN(k_cvt_f32_i32); RUN(k_cvt_f32_i32_sdwa); RUN(k_cvt_f32_ubyte0); RUN(k_cvt_f32_ubyte2); RUN(k_cvt_i32_f32); RUN(k_rndne);
+  RUN(k_mov); RUN(k_lshl_or); RUN(k_and_or); RUN(k_bfe); RUN(k_dpp_mov); RUN(k_ds_write_b8); RUN(k_ds_write_b32);
+  return 0;
+}
