@@ -86,8 +86,8 @@ const char *mdct_last_error(void);
  * The output buffer is sizeX*sizeY bytes with the reference's addressing; bytes the
  * reference would not write are not written.
  * Constraints: sizeX % 64 == 0 for Q32, sizeX % 16 == 0 for STEREO / BLOCK_SSE,
- * sizeX % 8 == 0 for BLOCK; sizeY % 8 == 0 (STEREO: % 16).  `from` must be 8-byte aligned
- * and pitch_in % 8 == 0 (HBM allocations are; the reference took any alignment).        */
+ * sizeX % 8 == 0 for BLOCK; sizeY % 8 == 0 (STEREO: % 16).  No alignment requirement on
+ * `from` / pitch_in (like the reference, simd_dct.cpp:2109); 8-byte aligned rows are fastest. */
 int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const float *lut,
                       size_t sizeX, size_t sizeY, size_t by0, size_t by1,
                       int layout, int profile, void *stream);

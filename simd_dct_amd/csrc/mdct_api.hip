@@ -275,7 +275,6 @@ int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const f
   const size_t rows = (by1 - by0) * (layout == MDCT_LAYOUT_STEREO ? 2 : 1);
   if ((r = count_blocks(sizeX / 8, rows, &a.nblocks)))
     return r;
-  a.aligned8 = ((((uintptr_t)from) | pitch_in) & 7) == 0;
   a.spill_ok = by1 * 8 * sizeX + 64 <= sizeX * sizeY;
   const bool safe = profile != MDCT_PROFILE_REF_SCALAR && table_needs_safe(a.qt.q);
   const hipError_t e = mdct::launch_fwd_quant_u8(a, layout, profile, safe, (hipStream_t)stream);

@@ -68,7 +68,6 @@ struct U8Args
   uint32_t by0;        // first block row of the launch
   uint32_t by_last;    // BLOCK_SSE: last block row of the launch
   uint32_t nblocks;    // blocks in the launch
-  uint32_t aligned8;   // input rows 8-byte aligned
   uint32_t spill_ok;   // BLOCK_SSE: trailing spill stays inside the buffer
 };
 

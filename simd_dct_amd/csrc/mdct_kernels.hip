@@ -245,24 +245,34 @@ __device__ __forceinline__ uint32_t quant_scalar(float f, float qs)
 // ---------------------------------------------------------------------------------------
 // u8 forward + quantise + reorder.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint2 load8(const uint8_t *p, bool aligned)
+// 8 pixels of one block row.  The reference takes any alignment (unaligned loads,
+// simd_dct.cpp:2109); so does this: gfx950 global loads are alignment-free in hardware, the
+// type below only stops the compiler from assuming 8-byte alignment.  Streamed once -> nt.
+typedef unsigned int u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
+__device__ __forceinline__ uint2 load8(const uint8_t *p)
 {
-  if (aligned)
-  {
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p)); // streamed once
-    return make_uint2(v.x, v.y);
-  }
-  uint2 v;
-  v.x = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-  v.y = (uint32_t)p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
-  return v;
+  const u32x2_unaligned v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_unaligned *>(p));
+  return make_uint2(v.x, v.y);
+}
+
+// byte N of a dword -> float in ONE instruction (v_cvt_f32_ubyteN).  Written as (pure,
+// schedulable) inline asm, not as (float)((w >> 8N) & 0xFF): from the latter LLVM rewrites the
+// first butterfly stage as integer SDWA adds followed by v_cvt_f32_i32 (exact, but ~1.6x the
+// issue cycles on gfx950, where SDWA forms and converts are half rate).
+template <int N>
+__device__ __forceinline__ float ubyte_to_float(uint32_t w)
+{
+  float f;
+  if constexpr (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w));
+  else if constexpr (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w));
+  else if constexpr (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w));
+  else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w));
+  return f;
 }
 
 template <int PROFILE>
-__device__ __forceinline__ float px_to_float(uint32_t px)
+__device__ __forceinline__ float px_to_float(float f)
 {
-  const float f = (float)px; // v_cvt_f32_ubyteN
   if constexpr (PROFILE == MDCT_PROFILE_REF_AVX)
     return f; // :2143, raw 0..255
   else if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
@@ -275,21 +285,25 @@ __device__ __forceinline__ float px_to_float(uint32_t px)
 // quantised bytes as int values q[v][u] (natural index) for the AVX/stereo layouts or
 // q[u][v]-transposed-stored semantics handled by the caller.
 template <int PROFILE, int LAYOUT, bool SAFE>
-__device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *src, size_t pitch, bool aligned, const QuantTable &qt, uint32_t (&out)[64])
+__device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *src, size_t pitch, const QuantTable &qt, uint32_t (&out)[64])
 {
+  uint2 rows[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) // all eight loads in flight before the first convert
+    rows[r] = load8(src + (size_t)r * pitch);
   float b[8][8];
 #pragma unroll
   for (int r = 0; r < 8; r++)
   {
-    const uint2 v = load8(src + (size_t)r * pitch, aligned);
-    b[r][0] = px_to_float<PROFILE>(v.x & 0xFF);
-    b[r][1] = px_to_float<PROFILE>((v.x >> 8) & 0xFF);
-    b[r][2] = px_to_float<PROFILE>((v.x >> 16) & 0xFF);
-    b[r][3] = px_to_float<PROFILE>(v.x >> 24);
-    b[r][4] = px_to_float<PROFILE>(v.y & 0xFF);
-    b[r][5] = px_to_float<PROFILE>((v.y >> 8) & 0xFF);
-    b[r][6] = px_to_float<PROFILE>((v.y >> 16) & 0xFF);
-    b[r][7] = px_to_float<PROFILE>(v.y >> 24);
+    const uint2 v = rows[r];
+    b[r][0] = px_to_float<PROFILE>(ubyte_to_float<0>(v.x));
+    b[r][1] = px_to_float<PROFILE>(ubyte_to_float<1>(v.x));
+    b[r][2] = px_to_float<PROFILE>(ubyte_to_float<2>(v.x));
+    b[r][3] = px_to_float<PROFILE>(ubyte_to_float<3>(v.x));
+    b[r][4] = px_to_float<PROFILE>(ubyte_to_float<0>(v.y));
+    b[r][5] = px_to_float<PROFILE>(ubyte_to_float<1>(v.y));
+    b[r][6] = px_to_float<PROFILE>(ubyte_to_float<2>(v.y));
+    b[r][7] = px_to_float<PROFILE>(ubyte_to_float<3>(v.y));
   }
 
   constexpr int K = PROFILE == MDCT_PROFILE_REF_AVX ? K_AVX : (PROFILE == MDCT_PROFILE_REF_SSE ? K_SSE : K_TRUE);
@@ -333,8 +347,11 @@ __device__ __forceinline__ uint32_t pack4_lo8(uint32_t a, uint32_t b, uint32_t c
 constexpr int kWG = 256;           // 4 waves
 constexpr int kQ32RowStride = 72;  // 64 lanes + 8 pad: keeps rows 8-byte aligned for ds_read_b64
 
+#ifndef MDCT_U8_MIN_WAVES
+#define MDCT_U8_MIN_WAVES 1
+#endif
 template <int PROFILE, int LAYOUT, bool SAFE>
-__global__ __launch_bounds__(kWG) void k_fwd_quant_u8(U8Args a)
+__global__ __launch_bounds__(kWG, MDCT_U8_MIN_WAVES) void k_fwd_quant_u8(U8Args a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x; // linear block index within the launch
   const bool valid = t < a.nblocks;
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(kWG) void k_fwd_quant_u8(U8Args a)
     const uint8_t *src = a.from + (size_t)by * 8 * a.pitch + (size_t)bx * 8;
     if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
       src += (size_t)eye * a.eye_offset;
-    encode_block<PROFILE, LAYOUT, SAFE>(a.consts, src, a.pitch, a.aligned8 != 0, a.qt, q);
+    encode_block<PROFILE, LAYOUT, SAFE>(a.consts, src, a.pitch, a.qt, q);
   }
 
   if constexpr (LAYOUT == MDCT_LAYOUT_Q32)
