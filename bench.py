@@ -123,7 +123,7 @@ def main():
             sys.exit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     dist = None
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run, also for one rank (exercises RCCL)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

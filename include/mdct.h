@@ -94,11 +94,15 @@ int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const f
 
 /* ---- engine-own variants (no reference counterpart; BASELINE.json configs 2-5) --------
  * Planes are row-major, pitches in ELEMENTS, coefficient (v,u) of block (by,bx) lives
- * at (by*8+v, bx*8+u).  Arithmetic: float32 K_OWN butterflies (correct DCT-II signs,
- * pairwise association, no FMA), orthonormal.  `lut` may be NULL (no quantisation):
- *   fwd:       coef = sat_i16(rne(f * (1.0f/lut[i])))
- *   inv:       f    = (float)coef * lut[i]
- *   roundtrip: fwd -> (quantise -> dequantise when lut) -> inv, fused, one pass over HBM.
+ * at (by*8+v, bx*8+u); coefficients are those of the orthonormal 2-D DCT-II.
+ * Arithmetic: float32, scaled Arai-Agui-Nakajima butterflies (5 mul + 29 add per 8 points),
+ * every operation individually rounded, no FMA; scale factors folded into the (de)quantiser
+ * multipliers.  Exact definition: DESIGN.md 4.2 (and the CPU checker under oracle/).
+ * `lut` (HOST, 64 floats, finite and non-zero) may be NULL = no quantisation:
+ *   fwd:       coef = sat_i16(rne(dct / lut[i]))
+ *   inv:       x    = sat_i16(rne(idct(coef * lut[i])))
+ *   roundtrip: fwd -> (quantise -> dequantise when lut) -> inv, fused, one pass over HBM;
+ *              without a table it returns the input bit-exactly.
  * Rows must be 16-byte aligned (pitch*sizeof(elem) % 16 == 0, base 16-byte aligned).    */
 int mdct_fwd_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
                  size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
@@ -111,9 +115,9 @@ int mdct_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out
 int mdct_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
                  size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
 
-/* Multi-plane batch (config 3: Y + Cb + Cr with per-plane tables) in ONE launch.
- * `planes` is a HOST array; descriptors are copied into a per-call slot of a small
- * device-side ring before the launch (no allocation, no sync). */
+/* Multi-plane batch (config 3: Y + Cb + Cr with per-plane tables): one launch per group of
+ * up to 4 planes, descriptors and tables by value in the kernel arguments (no allocation,
+ * no sync, capture-safe).  `planes` is a HOST array. */
 typedef struct mdct_plane_i16
 {
   const int16_t *from;

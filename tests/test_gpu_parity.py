@@ -270,3 +270,102 @@ def test_full_size_properties_8192():
         assert np.array_equal(full[by * 8 * W:(by + 1) * 8 * W].cpu().numpy(), want), by
     # a checksum of checksums that any dropped or duplicated group would change
     assert int(full.to(torch.int64).sum().item()) == int(halves.to(torch.int64).sum().item())
+
+
+# ------------------------------------------------------------------ remaining BASELINE.json configs
+JPEG_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                      18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+JPEG_CHROMA = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.float32)
+
+
+def test_config3_420_full_size_one_call():
+    """configs[2]: Y 7680x4320 + Cb/Cr 3840x2160, per-plane JPEG Annex-K tables, fwd -> quantise ->
+    dequantise -> inverse, all three planes in ONE C-ABI call; sampled block rows bit-exact vs
+    the oracle, every plane fully compared against the single-plane entry point."""
+    shapes = [(7680, 4320), (3840, 2160), (3840, 2160)]
+    luts = [JPEG_LUMA, JPEG_CHROMA, JPEG_CHROMA]
+    d_in = [synth.plane_i16_torch(w, h, "photo", seed=synth.SEED + i) for i, (w, h) in enumerate(shapes)]
+    d_out = [torch.full_like(t, 12345) for t in d_in]
+    M.roundtrip_i16_planes([(a, b, w, h, l) for a, b, (w, h), l in zip(d_in, d_out, shapes, luts)])
+    for i, ((w, h), l) in enumerate(zip(shapes, luts)):
+        single = torch.empty_like(d_in[i])
+        M.roundtrip_i16(d_in[i], single, w, h, lut=l)
+        assert torch.equal(single, d_out[i]), i
+        host = d_in[i].cpu().numpy()
+        for by in (0, h // 16, h // 8 - 1):
+            want = O.i16("roundtrip", host[by * 8:(by + 1) * 8], w, 8, lut=l)
+            assert np.array_equal(d_out[i][by * 8:(by + 1) * 8].cpu().numpy(), want), (i, by)
+        err = (d_out[i].to(torch.int32) - d_in[i].to(torch.int32)).abs()
+        assert 0 < err.float().mean().item() < 16 and err.max().item() < 160  # lossy (quality-50 tables on noisy content), but a codec
+
+
+def test_config4_batch_of_planes_forward_sharded():
+    """configs[3] in miniature on one GPU: a batch of independent 4096x4096 int16 planes, forward
+    only, block rows sharded as 8 ranks would; the concatenated shards equal the unsharded result
+    and sampled rows equal the oracle."""
+    W = H = 4096
+    planes = 4
+    rows = H // 8
+    for p in range(planes):
+        src = synth.plane_i16_torch(W, H, "photo", seed=synth.SEED + 100 + p)
+        whole = torch.empty_like(src)
+        M.fwd_i16(src, whole, W, H)
+        sharded = torch.zeros_like(src)
+        for rank in range(8):
+            b0, b1 = M.shard_rows(rows, 8, rank)
+            M.fwd_i16(src, sharded, W, H, by0=b0, by1=b1)
+        assert torch.equal(whole, sharded), p
+        host = src[:8].cpu().numpy()
+        assert np.array_equal(whole[:8].cpu().numpy(), O.i16("fwd", host, W, 8)), p
+
+
+def test_config5_f32_full_size_vs_double():
+    """configs[4]: float32 DCT-II on 8192x8192; tolerance 1e-5 relative to the block's max-abs
+    coefficient against the double-precision definition (sampled block rows), linearity and
+    inverse(forward) == identity at full size."""
+    W = H = 8192
+    src = synth.plane_u8_torch(W, H, "photo").to(torch.float32) - 128.0
+    out = torch.empty_like(src)
+    M.fwd_f32(src, out, W, H)
+    for by in (0, 300, 1023):
+        host = src[by * 8:(by + 1) * 8].cpu().numpy()
+        got = out[by * 8:(by + 1) * 8].cpu().numpy()
+        assert np.array_equal(got, O.f32("fwd", host, W, 8))
+        want = O.f32("f64ref", host, W, 8)
+        blk = lambda a: a.reshape(1, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+        rel = np.abs(blk(got.astype(np.float64)) - blk(want)).max(1) / np.abs(blk(want)).max(1)
+        assert rel.max() < 1e-5, (by, rel.max())
+    # Parseval: an orthonormal transform preserves the energy of every block
+    e_in = (src.double() ** 2).sum().item()
+    e_out = (out.double() ** 2).sum().item()
+    assert abs(e_in - e_out) / e_in < 1e-6
+    back = torch.empty_like(src)
+    M.inv_f32(out, back, W, H)
+    assert (back - src).abs().max().item() < 1e-3
+
+
+def test_shim_is_reentrant_from_two_host_threads():
+    """SURVEY 8b threading: concurrent calls on disjoint row ranges from host threads (the
+    reference's intended multi-core use), host pointers, per-thread staging buffers."""
+    import threading
+
+    W, H = 512, 256
+    img = synth.plane_u8_np(W, H, "photo").reshape(-1)
+    lut = lut_x(2000)
+    out = np.zeros(W * H, dtype=np.uint8)
+    errs = []
+
+    def work(y0, y1):
+        for _ in range(5):
+            rc = M.simdDCT_EncodeQuantize32ReorderBuffer(img, out, lut, W, 2 * H, y0, y1)
+            if rc != 0:
+                errs.append(rc)
+
+    ts = [threading.Thread(target=work, args=(0, 240)), threading.Thread(target=work, args=(256, 2 * H))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs
+    rc, want = O.q32_native(img.reshape(H, W), lut, W, H, 0, H // 8)
+    assert np.array_equal(out, want)
