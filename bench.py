@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W = H = 8192
 NSETS = 4
+PRECONDITION = 600  # untimed launches (~30 ms) before warmup, see main()
 ALG_BYTES_PER_PX = 4  # int16 in + int16 out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -103,8 +104,8 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -155,10 +156,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed pre-conditioning: for the first ~15 ms of sustained launches the chip's power
+    # management overshoots (kernel time 48 -> 61 -> 48 us, profiles/r01_sustained.log); the
+    # metric is the steady state, so settle before the W warmup steps and the K timed ones.
+    for i in range(PRECONDITION):
+        step(i)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    verified = all(torch.equal(s, d) for s, d in zip(srcs, dsts)) if args.warmup >= NSETS else None
+    verified = all(torch.equal(s, d) for s, d in zip(srcs, dsts))
 
     timer = M.Timer()
     barrier()
@@ -182,8 +188,8 @@ def main():
 
     extras, allgather = {}, None
     if not args.no_extras:
-        def rate(fn, bytes_per_launch, n=50):
-            for i in range(5):
+        def rate(fn, bytes_per_launch, n=200):
+            for i in range(300):
                 fn(i)
             torch.cuda.synchronize()
             timer.start()
@@ -202,7 +208,7 @@ def main():
         extras["fwd_i16"] = rate(prepared(lambda i: M.prepare_plane_i16("fwd", srcs[i], dsts[i], W, H)), 2 * nbytes)
         extras["inv_i16"] = rate(prepared(lambda i: M.prepare_plane_i16("inv", srcs[i], dsts[i], W, H)), 2 * nbytes)
         lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
-        u8s = [s.view(torch.uint8).reshape(-1)[: W * H] for s in srcs]  # any bytes will do for timing
+        u8s = [synth.plane_u8_torch(W, H, "photo", seed=synth.SEED + 50 + i).reshape(-1) for i in range(NSETS)]
         u8d = [d.view(torch.uint8).reshape(-1)[: W * H] for d in dsts]
         extras["fwd_quant_u8_q32"] = rate(prepared(lambda i: M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, H // 8)), 2 * W * H)
         extras["fwd_quant_u8_q32"]["Mpx_s"] = round(W * H / (extras["fwd_quant_u8_q32"]["ms"] * 1e-3) / 1e6, 0)
@@ -243,7 +249,7 @@ def main():
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: single 8192x8192 int16 plane per GPU, forward+inverse 8x8 DCT fused in one kernel",
-                       "plane": [W, H], "io": "int16", "planes_per_step_per_gpu": 1, "rotating_plane_sets": NSETS,
+                       "plane": [W, H], "io": "int16", "planes_per_step_per_gpu": 1, "rotating_plane_sets": NSETS, "untimed_preconditioning_launches": PRECONDITION,
                        "parallelism": f"independent planes x{world}" if world > 1 else "single GPU", "device": info["name"]},
             "roofline": {"bound": "hbm", "kernel": "mdct::k_i16<MODE_ROUNDTRIP, no table>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,

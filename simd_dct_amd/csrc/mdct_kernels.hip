@@ -347,11 +347,11 @@ __device__ __forceinline__ uint32_t pack4_lo8(uint32_t a, uint32_t b, uint32_t c
 constexpr int kWG = 256;           // 4 waves
 constexpr int kQ32RowStride = 72;  // 64 lanes + 8 pad: keeps rows 8-byte aligned for ds_read_b64
 
-#ifndef MDCT_U8_MIN_WAVES
-#define MDCT_U8_MIN_WAVES 1
-#endif
+// Occupancy: the Q32 instantiation is asked to fit 6 waves/SIMD (80 VGPRs, 8 B of scratch):
+// measured -6 % kernel time vs the unconstrained 98 VGPRs / 5 waves; the other layouts spill
+// badly under the same bound and are left alone (profiles/r01_occupancy_variants.log).
 template <int PROFILE, int LAYOUT, bool SAFE>
-__global__ __launch_bounds__(kWG, MDCT_U8_MIN_WAVES) void k_fwd_quant_u8(U8Args a)
+__global__ __launch_bounds__(kWG, (LAYOUT == MDCT_LAYOUT_Q32 && !SAFE) ? 6 : 1) void k_fwd_quant_u8(U8Args a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x; // linear block index within the launch
   const bool valid = t < a.nblocks;

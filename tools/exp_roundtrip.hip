@@ -106,6 +106,72 @@ __global__ __launch_bounds__(256) void v_multi(I16Args a)
   }
 }
 
+// V3: persistent waves, next tile prefetched by LDS-DMA (global_load_lds_dwordx4, no VGPRs)
+// while the current tile is computed.  One wave-private 8 KB LDS tile [8 rows][64 lanes x 16 B].
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+template <int WAVES_PER_WG>
+__global__ __launch_bounds__(WAVES_PER_WG * 64) void v_dma(I16Args a, uint32_t ntiles)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[WAVES_PER_WG][8 * 1024];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
+  uint8_t *tile = lds[wave];
+  const uint32_t total_waves = gridDim.x * WAVES_PER_WG;
+  uint32_t t = blockIdx.x * WAVES_PER_WG + wave; // tile index = 64 consecutive blocks
+  if (t >= ntiles) return;
+
+  auto issue = [&](uint32_t tt) {
+    const uint32_t blk = tt * 64 + lane;
+    const uint32_t row = blk / a.bpr, bx = blk - row * a.bpr;
+    const int16_t *src = a.from + (size_t)row * 8 * a.pitch_in + (size_t)bx * 8;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      __builtin_amdgcn_global_load_lds((gbl_void *)(src + (size_t)r * a.pitch_in), (lds_void *)(tile + r * 1024), 16, 0, 0);
+  };
+  issue(t);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (;;)
+  {
+    const uint32_t tn = t + total_waves;
+    const bool more = tn < ntiles; // wave-uniform
+    uint4 in[8], out[8];
+    {
+      // LDS reads in asm: hipcc otherwise orders every ds_read behind vmcnt(0) while an LDS-DMA
+      // is (or may be) outstanding, which would also wait for the previous tile's stores
+      const uint32_t laddr = (uint32_t)(uintptr_t)(lds_void *)(tile) + lane * 16;
+      u4 t0, t1, t2, t3, t4, t5, t6, t7;
+      asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:1024\n ds_read_b128 %2, %8 offset:2048\n ds_read_b128 %3, %8 offset:3072\n"
+                   "ds_read_b128 %4, %8 offset:4096\n ds_read_b128 %5, %8 offset:5120\n ds_read_b128 %6, %8 offset:6144\n ds_read_b128 %7, %8 offset:7168\n"
+                   "s_waitcnt lgkmcnt(0)"
+                   : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                   : "v"(laddr)
+                   : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      in[0] = make_uint4(t0.x, t0.y, t0.z, t0.w); in[1] = make_uint4(t1.x, t1.y, t1.z, t1.w);
+      in[2] = make_uint4(t2.x, t2.y, t2.z, t2.w); in[3] = make_uint4(t3.x, t3.y, t3.z, t3.w);
+      in[4] = make_uint4(t4.x, t4.y, t4.z, t4.w); in[5] = make_uint4(t5.x, t5.y, t5.z, t5.w);
+      in[6] = make_uint4(t6.x, t6.y, t6.z, t6.w); in[7] = make_uint4(t7.x, t7.y, t7.z, t7.w);
+    }
+    if (more)
+      issue(tn);
+    rt_compute(a.consts, in, out);
+    {
+      const uint32_t blk = t * 64 + lane;
+      const uint32_t row = blk / a.bpr, bx = blk - row * a.bpr;
+      int16_t *dst = a.to + (size_t)row * 8 * a.pitch_out + (size_t)bx * 8;
+#pragma unroll
+      for (int r = 0; r < 8; r++) st16<true>(dst + (size_t)r * a.pitch_out, out[r]);
+    }
+    if (!more) break;
+    // the 8 DMA pieces of the next tile are older than this tile's 8 stores: wait for all but
+    // the 8 youngest vector-memory ops, i.e. for the DMA only; the stores stay in flight
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    t = tn;
+  }
+}
+
 // compute only: load once, REPS x (fwd+inv) in registers, store once -> pure issue-rate cost
 template <int REPS>
 __global__ __launch_bounds__(256) void v_compute(I16Args a)
@@ -163,6 +229,12 @@ int main()
   vs.push_back({"multi4 NT prefetch", [&](int s) { hipLaunchKernelGGL((v_multi<true, 4>), dim3(a.nblocks / 256 / 4), dim3(256), 0, 0, args(s)); }, {}});
   vs.push_back({"multi4 plain prefetch", [&](int s) { hipLaunchKernelGGL((v_multi<false, 4>), dim3(a.nblocks / 256 / 4), dim3(256), 0, 0, args(s)); }, {}});
   vs.push_back({"multi8 NT prefetch", [&](int s) { hipLaunchKernelGGL((v_multi<true, 8>), dim3(a.nblocks / 256 / 8), dim3(256), 0, 0, args(s)); }, {}});
+  const uint32_t ntiles = a.nblocks / 64;
+  vs.push_back({"dma persist 4w x1024WG", [&](int s) { hipLaunchKernelGGL((v_dma<4>), dim3(1024), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  vs.push_back({"dma persist 4w x768WG", [&](int s) { hipLaunchKernelGGL((v_dma<4>), dim3(768), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  vs.push_back({"dma persist 4w x512WG", [&](int s) { hipLaunchKernelGGL((v_dma<4>), dim3(512), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  vs.push_back({"dma persist 4w x2048WG", [&](int s) { hipLaunchKernelGGL((v_dma<4>), dim3(2048), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  vs.push_back({"dma oneshot 4w x4096WG", [&](int s) { hipLaunchKernelGGL((v_dma<4>), dim3(4096), dim3(256), 0, 0, args(s), ntiles); }, {}});
   vs.push_back({"compute x1 (=one plain)", [&](int s) { hipLaunchKernelGGL((v_compute<1>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
   vs.push_back({"compute x3", [&](int s) { hipLaunchKernelGGL((v_compute<3>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
   vs.push_back({"compute x5", [&](int s) { hipLaunchKernelGGL((v_compute<5>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
