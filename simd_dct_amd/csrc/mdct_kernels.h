@@ -30,6 +30,9 @@ struct DctConsts
   float c1847 = 1.847759065022573512f;
   float c1082 = 1.082392200292393968f;
   float c2613 = 2.613125929752753056f;
+  // rounding constants (also kept out of the instruction stream): 1.5*2^23 and 1.5*2^29
+  float magic23 = 12582912.0f;
+  float magic29 = 805306368.0f;
   float a = 1.3870398453221474618216191915664f;
   float b = 1.3065629648763765278566431734272f;
   float c = 1.1758756024193587169744671046113f;

@@ -210,28 +210,26 @@ __device__ __forceinline__ int32_t cvtps_epi32_exact(float v)
 
 __device__ __forceinline__ int32_t clamp255(int32_t v) { return min(max(v, 0), 255); } // v_med3_i32
 
-constexpr float kMagic23 = 12582912.0f; // 1.5 * 2^23
-
 // B1 :2224  clamp(127 + rne(f*q), 0, 255)   (wrapping int32 add, like _mm256_add_epi32)
 template <bool SAFE>
-__device__ __forceinline__ uint32_t quant_avx(float f, float q)
+__device__ __forceinline__ uint32_t quant_avx(float f, float q, float magic23)
 {
   const float v = f * q;
   if constexpr (SAFE)
     return (uint32_t)clamp255((int32_t)((uint32_t)cvtps_epi32_exact(v) + 127u));
   else
-    return __float_as_uint(__builtin_amdgcn_fmed3f(v, -127.0f, 128.0f) + kMagic23) + 127u;
+    return __float_as_uint(__builtin_amdgcn_fmed3f(v, -127.0f, 128.0f) + magic23) + 127u;
 }
 
 // B2/B3 :1020  clamp(rne(f*q + 127.0f), 0, 255)
 template <bool SAFE>
-__device__ __forceinline__ uint32_t quant_sse(float f, float q)
+__device__ __forceinline__ uint32_t quant_sse(float f, float q, float magic23)
 {
   const float v = (f * q) + 127.0f;
   if constexpr (SAFE)
     return (uint32_t)clamp255(cvtps_epi32_exact(v));
   else
-    return __float_as_uint(__builtin_amdgcn_fmed3f(v, 0.0f, 255.0f) + kMagic23);
+    return __float_as_uint(__builtin_amdgcn_fmed3f(v, 0.0f, 255.0f) + magic23);
 }
 
 // B4/B5 :245, :362  (uint8_t)roundf(_clamp(f*qs + 127/255, 0, 1) * 255)
@@ -328,9 +326,9 @@ __device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *
     const int hi = s >> 3, lo = s & 7;
     const float f = (LAYOUT == MDCT_LAYOUT_BLOCK || LAYOUT == MDCT_LAYOUT_BLOCK_SSE) ? b[lo][hi] : b[hi][lo];
     if constexpr (PROFILE == MDCT_PROFILE_REF_AVX)
-      out[s] = quant_avx<SAFE>(f, qt.q[s]);
+      out[s] = quant_avx<SAFE>(f, qt.q[s], C.magic23);
     else if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
-      out[s] = quant_sse<SAFE>(f, qt.q[s]);
+      out[s] = quant_sse<SAFE>(f, qt.q[s], C.magic23);
     else
       out[s] = quant_scalar(f, qt.q[s]);
   }
@@ -501,29 +499,30 @@ __device__ __forceinline__ void unpack_i16x8(const uint4 v, float (&row)[8])
 // bits of the result ARE the two's-complement int16.  SHIFT = 6 is the fused round trip's
 // 1/64.  Returns the raw bits; callers keep the low half.
 template <int SHIFT>
-__device__ __forceinline__ uint32_t rne_i16_bits(float v)
+__device__ __forceinline__ uint32_t rne_i16_bits(const DctConsts &C, float v)
 {
   constexpr float scale = (float)(1 << SHIFT);
   const float m = __builtin_amdgcn_fmed3f(v, -32768.0f * scale, 32767.0f * scale);
-  return __float_as_uint(m + 12582912.0f * scale);
+  return __float_as_uint(m + (SHIFT == 0 ? C.magic23 : C.magic29));
 }
 
 // the same rounding, result as a float integer (for quantise -> dequantise in registers)
-__device__ __forceinline__ float rne_i16_float(float v)
+__device__ __forceinline__ float rne_i16_float(const DctConsts &C, float v)
 {
   const float m = __builtin_amdgcn_fmed3f(v, -32768.0f, 32767.0f);
-  return (m + 12582912.0f) - 12582912.0f;
+  return (m + C.magic23) - C.magic23;
 }
 
 __device__ __forceinline__ uint32_t pack_lo16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }
 
 template <int SHIFT>
-__device__ __forceinline__ void store_i16x8(int16_t *dst, const float (&row)[8])
+__device__ __forceinline__ void store_i16x8(const DctConsts &C, int16_t *dst, const float (&row)[8])
 {
+  static_assert(SHIFT == 0 || SHIFT == 6, "magic constants exist for 2^0 and 2^6 only");
   uint32_t t[8];
 #pragma unroll
   for (int c = 0; c < 8; c++)
-    t[c] = rne_i16_bits<SHIFT>(row[c]);
+    t[c] = rne_i16_bits<SHIFT>(C, row[c]);
   st_stream16(dst, pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
 }
 
@@ -556,7 +555,7 @@ __device__ __forceinline__ void i16_block(const DctConsts &C, const int16_t *src
     {
 #pragma unroll
       for (int i = 0; i < 64; i++)
-        b[i >> 3][i & 7] = rne_i16_float(b[i >> 3][i & 7] * tb.qf[i]) * tb.dq[i];
+        b[i >> 3][i & 7] = rne_i16_float(C, b[i >> 3][i & 7] * tb.qf[i]) * tb.dq[i];
     }
     raw_inv(C, b);
   }
@@ -565,7 +564,7 @@ __device__ __forceinline__ void i16_block(const DctConsts &C, const int16_t *src
   constexpr int SHIFT = (MODE == MODE_ROUNDTRIP && !HAS_LUT) ? 6 : 0;
 #pragma unroll
   for (int r = 0; r < 8; r++)
-    store_i16x8<SHIFT>(dst + (size_t)r * pitch_out, b[r]);
+    store_i16x8<SHIFT>(C, dst + (size_t)r * pitch_out, b[r]);
 }
 
 template <int MODE, bool HAS_LUT>

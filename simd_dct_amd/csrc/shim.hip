@@ -20,8 +20,12 @@ std::atomic<int> g_async{0};
 
 struct Staging
 {
-  uint8_t *in = nullptr, *out = nullptr;
+  uint8_t *in = nullptr, *out = nullptr; // HBM mirrors of the caller's planes
   size_t in_cap = 0, out_cap = 0;
+  // chunk pipeline for host pointers: two pinned bounce buffers per direction, two streams
+  uint8_t *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+  size_t pin_cap = 0;
+  hipStream_t stream[2] = {nullptr, nullptr};
   int device = -1;
 };
 thread_local Staging tl_stage;
@@ -32,7 +36,42 @@ void release(Staging &s)
     (void)hipFree(s.in);
   if (s.out)
     (void)hipFree(s.out);
+  for (int i = 0; i < 2; i++)
+  {
+    if (s.pin_in[i])
+      (void)hipHostFree(s.pin_in[i]);
+    if (s.pin_out[i])
+      (void)hipHostFree(s.pin_out[i]);
+    if (s.stream[i])
+      (void)hipStreamDestroy(s.stream[i]);
+  }
   s = Staging();
+}
+
+bool reserve_pipeline(Staging &s, size_t chunk_bytes)
+{
+  for (int i = 0; i < 2; i++)
+    if (!s.stream[i] && hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking) != hipSuccess)
+      return false;
+  if (s.pin_cap >= chunk_bytes)
+    return true;
+  for (int i = 0; i < 2; i++)
+  {
+    if (s.pin_in[i])
+      (void)hipHostFree(s.pin_in[i]);
+    if (s.pin_out[i])
+      (void)hipHostFree(s.pin_out[i]);
+    s.pin_in[i] = s.pin_out[i] = nullptr;
+  }
+  s.pin_cap = 0;
+  for (int i = 0; i < 2; i++)
+    if (hipHostMalloc((void **)&s.pin_in[i], chunk_bytes, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&s.pin_out[i], chunk_bytes, hipHostMallocDefault) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      return false;
+    }
+  s.pin_cap = chunk_bytes;
+  return true;
 }
 
 bool reserve(uint8_t *&p, size_t &cap, size_t need)
@@ -107,6 +146,50 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
   }
   const size_t total = sizeX * sizeY;
   const bool scattered = layout == MDCT_LAYOUT_STEREO || layout == MDCT_LAYOUT_BLOCK_SSE;
+
+  // Both pointers on the host and a strip layout: chunked pipeline.  Block-row strips of
+  // ~4 MiB ping-pong over two streams, so strip k's kernel and device->host copy overlap strip
+  // k+1's host->device copy (PCIe is full duplex); the caller's pageable memory is touched
+  // only by plain memcpy to/from pinned bounce buffers.
+  if (!dev_in && !dev_out && !scattered)
+  {
+    const size_t strip = 8 * sizeX; // bytes per block row, input and output alike
+    size_t rows_per_chunk = ((size_t)4 << 20) / strip;
+    rows_per_chunk = rows_per_chunk < 1 ? 1 : rows_per_chunk;
+    if (reserve(st.in, st.in_cap, total) && reserve(st.out, st.out_cap, total) && reserve_pipeline(st, rows_per_chunk * strip))
+    {
+      const size_t nchunks = ceil_div(b1 - b0, rows_per_chunk);
+      int r = MDCT_SUCCESS;
+      auto drain = [&](size_t c) { // chunk c has finished on its stream: hand its output to the caller
+        const int sl = (int)(c & 1);
+        const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
+        if (hipStreamSynchronize(st.stream[sl]) != hipSuccess)
+          return false;
+        memcpy(pTo + r0 * strip, st.pin_out[sl], (r1 - r0) * strip);
+        return true;
+      };
+      for (size_t c = 0; c < nchunks && r == MDCT_SUCCESS; c++)
+      {
+        const int sl = (int)(c & 1);
+        if (c >= 2 && !drain(c - 2))
+          return sdr_NotSupported;
+        const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
+        const size_t off = r0 * strip, len = (r1 - r0) * strip;
+        memcpy(st.pin_in[sl], pFrom + off, len);
+        if (hipMemcpyAsync(st.in + off, st.pin_in[sl], len, hipMemcpyHostToDevice, st.stream[sl]) != hipSuccess)
+          return sdr_NotSupported;
+        r = mdct_fwd_quant_u8(st.in, st.out, sizeX, lut, sizeX, sizeY, r0, r1, layout, profile, st.stream[sl]);
+        if (r == MDCT_SUCCESS && hipMemcpyAsync(st.pin_out[sl], st.out + off, len, hipMemcpyDeviceToHost, st.stream[sl]) != hipSuccess)
+          return sdr_NotSupported;
+      }
+      for (size_t c = nchunks >= 2 ? nchunks - 2 : 0; c < nchunks; c++)
+        if (!drain(c) && r == MDCT_SUCCESS)
+          return sdr_NotSupported;
+      return (simdDctResult)r;
+    }
+    (void)hipGetLastError(); // could not set the pipeline up: fall through to the plain path
+  }
+
   const uint8_t *d_in = pFrom;
   uint8_t *d_out = pTo;
   hipStream_t hs = (hipStream_t)stream;

@@ -369,3 +369,57 @@ def test_shim_is_reentrant_from_two_host_threads():
     assert not errs
     rc, want = O.q32_native(img.reshape(H, W), lut, W, H, 0, H // 8)
     assert np.array_equal(out, want)
+
+
+def test_cxx_cli_on_the_reference_api(tmp_path):
+    """the C++ host tool (counterpart of the reference's main.cpp, tools/simd_dct_cli.cpp) calls
+    the three reference symbols with host and with device pointers; its dumped output must be
+    the oracle's bytes"""
+    import subprocess
+
+    import __graft_entry__ as G
+
+    cli = G.build_cli()
+    W, H = 512, 256
+    img = synth.plane_u8_np(W, H, "photo")
+    for mode, beh, level in (("enc-quant32", "q32_avx", "avx2"), ("enc-quant-stereo", "stereo_sse", "avx2"), ("enc-quant", "encq_scalar", "none")):
+        for extra in ([], ["--resident"]):
+            dump = tmp_path / f"{mode}{len(extra)}.bin"
+            r = subprocess.run([cli, "synthetic:photo", str(W), str(H), "--mode", mode, "--quality", "8", "--runs", "3", "--max-simd", level, "--to", str(dump)] + extra,
+                               capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stdout + r.stderr
+            assert "sdr_Success" in r.stdout
+            got = np.fromfile(dump, dtype=np.uint8)
+            rc, want = O.run_behaviour(beh, img, lut_x(8), W, H, 0, H)
+            assert np.array_equal(got, want), (mode, extra)
+
+
+def test_host_pointer_pipeline_multi_chunk():
+    """plain host memory through the reference API on a plane large enough for the shim's
+    chunked two-stream pipeline (several ~4 MiB strips), full range and a partial range;
+    rows outside the range keep the caller's bytes"""
+    W, H = 4096, 2048
+    img = synth.plane_u8_np(W, H, "photo").reshape(-1)
+    lut = lut_x(2000)
+    # whole plane through the sizeY = 2H form
+    out = np.full(W * H, CANARY, dtype=np.uint8)
+    assert M.simdDCT_EncodeQuantize32ReorderBuffer(img, out, lut, W, 2 * H, 0, 2 * H) == 0
+    rc, want = O.q32_native(img.reshape(H, W), lut, W, H, 0, H // 8)
+    assert np.array_equal(out, want)
+    # reference semantics on the real geometry: top half only, and a sub-range of it
+    for (y0, y1) in ((0, H), (512, 1200)):
+        out = np.full(W * H, CANARY, dtype=np.uint8)
+        assert M.simdDCT_EncodeQuantize32ReorderBuffer(img, out, lut, W, H, y0, y1) == 0
+        want = np.full(W * H, CANARY, dtype=np.uint8)
+        O.run_behaviour("q32_avx", img, lut, W, H, y0, y1, out=want)
+        assert np.array_equal(out, want), (y0, y1)
+    # scalar encq tier (BLOCK layout) takes the same pipeline
+    M.set_max_simd(0)
+    try:
+        out = np.full(W * H, CANARY, dtype=np.uint8)
+        assert M.simdDCT_EncodeQuantizeBuffer(img, out, lut_x(8), W, H, 0, H) == 0
+        want = np.full(W * H, CANARY, dtype=np.uint8)
+        O.run_behaviour("encq_scalar", img, lut_x(8), W, H, 0, H, out=want)
+        assert np.array_equal(out, want)
+    finally:
+        M.set_max_simd(2)

@@ -1,0 +1,103 @@
+// exp_q32.hip -- where does the q32 (u8 -> u8, 8-block interleave) kernel's time go?
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -Iinclude -Isimd_dct_amd/csrc tools/exp_q32.hip -o tools/exp_q32
+#include "../simd_dct_amd/csrc/mdct_kernels.hip"
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <vector>
+#include <algorithm>
+using namespace mdct;
+
+// REPS x (convert + DCT + quantise [+ LDS reorder]) on the same registers, one load, one store
+template <int REPS, bool WITH_LDS>
+__global__ __launch_bounds__(256, 6) void v_compute(U8Args a)
+{
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t row = t / a.bpr, bx = t - row * a.bpr;
+  const uint8_t *src = a.from + (size_t)row * 8 * a.pitch + (size_t)bx * 8;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4][64 * kQ32RowStride];
+  uint8_t *wl = lds[threadIdx.x >> 6];
+  uint32_t q[64];
+  uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll 1
+  for (int i = 0; i < REPS; i++)
+  {
+    encode_block<MDCT_PROFILE_REF_AVX, MDCT_LAYOUT_Q32, false>(a.consts, src + (acc.x & 1) * 8, a.pitch, a.qt, q);
+    if (WITH_LDS)
+    {
+#pragma unroll
+      for (int c = 0; c < 64; c++)
+        wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t c2 = (lane & 31) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        const uint32_t g = 2 * k + (lane >> 5);
+        const uint2 lo = *reinterpret_cast<const uint2 *>(wl + c2 * kQ32RowStride + g * 8);
+        const uint2 hi = *reinterpret_cast<const uint2 *>(wl + (c2 + 1) * kQ32RowStride + g * 8);
+        acc.x ^= lo.x; acc.y ^= lo.y; acc.z ^= hi.x; acc.w ^= hi.y;
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int c = 0; c < 64; c += 4)
+      {
+        acc.x ^= q[c]; acc.y ^= q[c + 1]; acc.z ^= q[c + 2]; acc.w ^= q[c + 3];
+      }
+    }
+  }
+  *reinterpret_cast<uint4 *>(a.to + (size_t)t * 64) = acc;
+}
+
+int main()
+{
+  const size_t W = 8192, H = 8192, bytes = W * H;
+  const int NS = 4;
+  std::vector<uint8_t *> A(NS), B(NS);
+  std::vector<uint8_t> host(W * H);
+  for (size_t i = 0; i < W * H; i++) host[i] = (uint8_t)((i * 2654435761u) >> 24);
+  for (int i = 0; i < NS; i++)
+  {
+    hipMalloc(&A[i], bytes + 64);
+    hipMalloc(&B[i], bytes);
+    hipMemcpy(A[i], host.data(), bytes, hipMemcpyHostToDevice);
+  }
+  U8Args a;
+  memset(&a, 0, sizeof(a));
+  a.consts = DctConsts();
+  for (int i = 0; i < 64; i++) a.qt.q[i] = 255.0f / ((0.1f + 0.01f * i) * 2000 * 0.95f);
+  a.pitch = W; a.sizeX = W; a.bpr = W / 8; a.by0 = 0; a.nblocks = (uint32_t)(W / 8 * H / 8);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  struct V { const char *name; std::function<void(int)> f; std::vector<float> t; };
+  std::vector<V> vs;
+  auto args = [&](int s) { U8Args x = a; x.from = A[s]; x.to = B[s]; return x; };
+  vs.push_back({"product q32", [&](int s) { launch_fwd_quant_u8(args(s), MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX, false, 0); }, {}});
+  vs.push_back({"compute x1 +lds", [&](int s) { hipLaunchKernelGGL((v_compute<1, true>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
+  vs.push_back({"compute x3 +lds", [&](int s) { hipLaunchKernelGGL((v_compute<3, true>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
+  vs.push_back({"compute x1 nolds", [&](int s) { hipLaunchKernelGGL((v_compute<1, false>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
+  vs.push_back({"compute x3 nolds", [&](int s) { hipLaunchKernelGGL((v_compute<3, false>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
+  for (auto &v : vs) for (int i = 0; i < 300; i++) v.f(i % NS);
+  hipDeviceSynchronize();
+  for (int round = 0; round < 7; round++)
+    for (auto &v : vs)
+    {
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 40; i++) v.f(i % NS);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      v.t.push_back(ms / 40);
+    }
+  for (auto &v : vs)
+  {
+    std::sort(v.t.begin(), v.t.end());
+    printf("%-20s median %7.2f us  min %7.2f us\n", v.name, v.t[v.t.size() / 2] * 1e3, v.t[0] * 1e3);
+  }
+  return 0;
+}

@@ -47,7 +47,7 @@ __device__ __forceinline__ void rt_compute(const DctConsts &C, const uint4 (&in)
     uint32_t t[8];
 #pragma unroll
     for (int c = 0; c < 8; c++)
-      t[c] = rne_i16_bits<6>(b[r][c]);
+      t[c] = rne_i16_bits<6>(C, b[r][c]);
     out[r] = make_uint4(pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
   }
 }

@@ -1,0 +1,256 @@
+// simd_dct_cli.cpp -- benchmark / parity CLI on top of the drop-in API.
+//
+// Counterpart of the reference's harness (src/main.cpp) for the MI355X engine: same
+// positional arguments and options (main.cpp:84-102, parser :207-444), same statistics
+// (min, mean +- sigma over --runs, print_perf_info main.cpp:34-80) and the same calls
+// (simdDCT_*Buffer(in, out, table, X, Y, 0, Y), main.cpp:514/543/572) -- only the three
+// functions now come from libmdct_hip.so.  Host code stays C++; HIP is used here only to
+// place the buffers in HBM for the --resident mode.
+//
+//   simd_dct_cli <raw_grayscale_image_file | synthetic:noise | synthetic:photo> <X> <Y>
+//        [--to <file>] [--quality <n>] [--runs <n>] [--mode enc-quant|enc-quant32|enc-quant-stereo]...
+//        [--max-simd avx2|sse41|ssse3|sse2|none] [--resident] [--device <n>]
+//
+// Build: hipcc -O2 -std=c++17 -Iinclude tools/simd_dct_cli.cpp -Lsimd_dct_amd -lmdct_hip -Wl,-rpath,'$ORIGIN/../simd_dct_amd' -o tools/simd_dct_cli
+#include <hip/hip_runtime_api.h>
+
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "mdct.h"
+#include "simd_dct_shim.h"
+
+namespace
+{
+
+double now_ns()
+{
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e9 + ts.tv_nsec;
+}
+
+// deterministic planes, same generator as simd_dct_amd/synth.py
+uint32_t mix32(uint32_t x)
+{
+  x *= 0x9E3779B1u;
+  x ^= x >> 15;
+  x *= 0x85EBCA77u;
+  x ^= x >> 13;
+  return x;
+}
+
+void synth(std::vector<uint8_t> &img, size_t W, size_t H, bool photo)
+{
+  const uint32_t seed = 20261003u;
+  for (size_t i = 0; i < W * H; i++)
+  {
+    const uint32_t h = mix32((uint32_t)i ^ seed);
+    if (!photo)
+    {
+      img[i] = (uint8_t)(h >> 24);
+      continue;
+    }
+    const uint64_t x = i % W, y = i / W;
+    const int b = (int)(((x * 3 + y * 5) >> 2) & 0xFF);
+    const int tri = b < 128 ? b : 255 - b;
+    int px = 48 + tri + (int)((h >> 24) % 49) - 24;
+    img[i] = (uint8_t)(px < 0 ? 0 : (px > 255 ? 255 : px));
+  }
+}
+
+struct Stats
+{
+  double min_ns, mean_ns, sd_ns;
+};
+
+Stats stats(const std::vector<double> &ns)
+{
+  Stats s{1e300, 0, 0};
+  for (double v : ns)
+  {
+    s.min_ns = v < s.min_ns ? v : s.min_ns;
+    s.mean_ns += v;
+  }
+  s.mean_ns /= ns.size();
+  for (double v : ns)
+    s.sd_ns += (v - s.mean_ns) * (v - s.mean_ns);
+  s.sd_ns = ns.size() > 1 ? std::sqrt(s.sd_ns / (ns.size() - 1)) : 0;
+  return s;
+}
+
+const char *result_name(int r) { return r == 0 ? "sdr_Success" : (r == 1 ? "sdr_InvalidParameter" : "sdr_NotSupported"); }
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+  if (argc < 4)
+  {
+    puts("Invalid Parameter.\n\nUsage: simd_dct_cli <raw_grayscale_image_file | synthetic:noise | synthetic:photo> <resolutionX> <resolutionY>");
+    puts("\t--to <file_name>\t\tStore the last output in the specified file.");
+    puts("\t--quality <n>\t\t\tMultiplies the base quantization table (integer, as the reference parses it).");
+    puts("\t--runs <uint>\t\t\tRun the benchmark for a specified amount of times.");
+    puts("\t--max-simd <avx2 / sse41 / ssse3 / sse2 / none>\tReference tier to reproduce.");
+    puts("\t--mode <enc-quant / enc-quant32 / enc-quant-stereo>\tOnly execute a specified mode (repeatable).");
+    puts("\t--resident\t\t\tKeep input and output in HBM (device pointers through the same API).");
+    puts("\t--device <n>\t\t\tHIP device ordinal.");
+    return 1;
+  }
+  const std::string filename = argv[1];
+  const size_t X = strtoull(argv[2], nullptr, 10), Y = strtoull(argv[3], nullptr, 10);
+  if (X == 0 || Y == 0)
+  {
+    puts("Invalid Resolution Specified. Aborting.");
+    return 1;
+  }
+  const char *out_file = nullptr;
+  size_t runs = 128; // main.cpp:21
+  float quality = 1.0f;
+  bool resident = false;
+  int device = 0, max_simd = 2;
+  bool m_encq = false, m_q32 = false, m_stereo = false;
+  for (int i = 4; i < argc; i++)
+  {
+    const std::string a = argv[i];
+    auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
+    if (a == "--to") out_file = next();
+    else if (a == "--quality") quality = (float)strtoull(next(), nullptr, 10); // main.cpp:214
+    else if (a == "--runs") runs = strtoull(next(), nullptr, 10);
+    else if (a == "--resident") resident = true;
+    else if (a == "--device") device = atoi(next());
+    else if (a == "--mode")
+    {
+      const std::string m = next();
+      if (m == "enc-quant") m_encq = true;
+      else if (m == "enc-quant32") m_q32 = true;
+      else if (m == "enc-quant-stereo") m_stereo = true;
+      else { printf("Invalid Parameter '%s'. Aborting.", m.c_str()); return 1; }
+    }
+    else if (a == "--max-simd")
+    {
+      const std::string m = next();
+      max_simd = (m == "none") ? 0 : ((m == "sse2" || m == "ssse3" || m == "sse3" || m == "sse41" || m == "sse42" || m == "avx") ? 1 : 2);
+    }
+    else { printf("Invalid Parameter '%s'. Aborting.", a.c_str()); return 1; }
+  }
+  if (!m_encq && !m_q32 && !m_stereo)
+    m_encq = m_q32 = m_stereo = true;
+  if (runs == 0 || runs > 1024)
+  {
+    puts("Invalid Parameter.");
+    return 1;
+  }
+
+  const size_t fileSize = X * Y;
+  std::vector<uint8_t> in(fileSize), out(fileSize, 0);
+  if (filename.rfind("synthetic:", 0) == 0)
+    synth(in, X, Y, filename == "synthetic:photo");
+  else
+  {
+    FILE *f = fopen(filename.c_str(), "rb");
+    if (!f || fread(in.data(), 1, fileSize, f) != fileSize)
+    {
+      puts("Failed to read file.");
+      return 1;
+    }
+    fclose(f);
+  }
+
+  // main.cpp:179-189
+  float table[64] = {.17f, .11f, .10f, .16f, .24f, .40f, .51f, .61f, .12f, .12f, .14f, .19f, .26f, .58f, .60f, .55f, .14f, .13f, .16f, .24f, .40f, .57f, .69f, .56f,
+                     .14f, .17f, .22f, .29f, .51f, .87f, .80f, .62f, .18f, .22f, .37f, .56f, .68f, 1.09f, 1.03f, .77f, .24f, .35f, .55f, .64f, .81f, 1.04f, 1.13f, .92f,
+                     .49f, .64f, .78f, .87f, 1.03f, 1.21f, 1.20f, 1.01f, .72f, .92f, .95f, .98f, 1.12f, 1.00f, 1.03f, .99f};
+  for (float &t : table)
+    t *= quality;
+
+  if (mdct_init(device) != MDCT_SUCCESS)
+  {
+    printf("mdct_init failed: %s\n", mdct_last_error());
+    return 2;
+  }
+  mdct_device_info di;
+  mdct_get_device_info(&di);
+  mdct_shim_set_max_simd(max_simd);
+  printf("File: '%s' (%" PRIu64 " Bytes)\nDevice: '%s' (%d CUs, wave%d, %.0f GB HBM) via %s pointers, reference tier <= %s\n", filename.c_str(), (uint64_t)fileSize, di.name, di.compute_units,
+         di.wavefront_size, di.hbm_bytes / 1e9, resident ? "device" : "host", max_simd == 2 ? "AVX2" : (max_simd == 1 ? "SSE" : "scalar"));
+
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  const uint8_t *p_in = in.data();
+  uint8_t *p_out = out.data();
+  if (resident)
+  {
+    if (hipMalloc((void **)&d_in, fileSize) != hipSuccess || hipMalloc((void **)&d_out, fileSize) != hipSuccess || hipMemcpy(d_in, in.data(), fileSize, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(d_out, 0, fileSize) != hipSuccess)
+    {
+      puts("Memory allocation failure.");
+      return 2;
+    }
+    p_in = d_in;
+    p_out = d_out;
+  }
+
+  struct Mode
+  {
+    const char *name;
+    bool on;
+    simdDctResult (*fn)(const uint8_t *, uint8_t *, const float *, size_t, size_t, size_t, size_t);
+    double covered; // fraction of the plane the reference semantics really transform
+  };
+  const Mode modes[] = {{"enc-quant", m_encq, simdDCT_EncodeQuantizeBuffer, 0.5}, {"enc-quant32", m_q32, simdDCT_EncodeQuantize32ReorderBuffer, 0.5}, {"enc-quant-stereo", m_stereo, simdDCT_EncodeQuantizeReorderStereoBuffer, 1.0}};
+  puts("mode             | result               |   min ns/byte |  mean ns/byte (sigma) |  min MiB/s (nominal) | mean MiB/s | actual Mpx/s (min) | alg. GB/s");
+  int rc_all = 0;
+  for (const Mode &m : modes)
+  {
+    if (!m.on)
+      continue;
+    std::vector<double> ns(runs);
+    simdDctResult r = sdr_Success;
+    for (size_t i = 0; i < runs && r == sdr_Success; i++)
+    {
+      const double t0 = now_ns();
+      r = m.fn(p_in, p_out, table, X, Y, 0, Y); // main.cpp:514
+      ns[i] = now_ns() - t0;
+    }
+    if (r != sdr_Success)
+    {
+      printf("%-16s | %-20s | %s\n", m.name, result_name(r), mdct_last_error());
+      rc_all = 3;
+      continue;
+    }
+    const Stats s = stats(ns);
+    const double mib = fileSize / (1024.0 * 1024.0);
+    const double px = fileSize * m.covered;
+    printf("%-16s | %-20s | %13.5f | %10.5f (%8.5f) | %20.2f | %10.2f | %18.1f | %9.1f\n", m.name, result_name(r), s.min_ns / fileSize, s.mean_ns / fileSize, s.sd_ns / fileSize, mib / (s.min_ns * 1e-9),
+           mib / (s.mean_ns * 1e-9), px / (s.min_ns * 1e-9) / 1e6, 2.0 * px / s.min_ns);
+  }
+
+  if (out_file)
+  {
+    if (resident && hipMemcpy(out.data(), d_out, fileSize, hipMemcpyDeviceToHost) != hipSuccess)
+    {
+      puts("Failed to copy the output back.");
+      return 2;
+    }
+    FILE *f = fopen(out_file, "wb");
+    if (!f || fwrite(out.data(), 1, fileSize, f) != fileSize) // main.cpp:594-606
+    {
+      puts("Failed to write file.");
+      return 1;
+    }
+    fclose(f);
+  }
+  if (resident)
+  {
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+  }
+  mdct_shim_release();
+  return rc_all;
+}
