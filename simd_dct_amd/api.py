@@ -211,6 +211,18 @@ def prepare_fwd_quant_u8(src, dst, lut, sizeX, sizeY, by0, by1, layout=LAYOUT_Q3
     return Prepared(lib.mdct_fwd_quant_u8, args, (keep, src, dst))
 
 
+def prepare_roundtrip_i16_planes(planes, stream=None):
+    """planes as for roundtrip_i16_planes; descriptors marshalled once"""
+    lib = _lib.load()
+    arr = (_lib.PlaneI16 * len(planes))()
+    keep = []
+    for i, (src, dst, sx, sy, lut) in enumerate(planes):
+        k, lp = _lut_ptr(lut)
+        keep.append((k, src, dst))
+        arr[i] = _lib.PlaneI16(_ptr(src), _ptr(dst), sx, sx, sx, sy, lp)
+    return Prepared(lib.mdct_roundtrip_i16_planes, (arr, ctypes.c_int(len(planes)), _stream(stream)), keep)
+
+
 def prepare_stream_copy(src, dst, nbytes, stream=None):
     lib = _lib.load()
     return Prepared(lib.mdct_stream_copy, (ctypes.c_void_p(_ptr(src)), ctypes.c_void_p(_ptr(dst)), ctypes.c_size_t(nbytes), _stream(stream)), (src, dst))

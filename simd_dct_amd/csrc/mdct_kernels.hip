@@ -567,8 +567,11 @@ __device__ __forceinline__ void i16_block(const DctConsts &C, const int16_t *src
     store_i16x8<SHIFT>(C, dst + (size_t)r * pitch_out, b[r]);
 }
 
+// Register budget pinned to 4 waves/SIMD (<= 128 VGPRs): left to its occupancy heuristic the
+// compiler sometimes squeezes these kernels into ~88 VGPRs, serialising the row loads behind
+// the butterflies; measured 58 vs 49 us on the same work (tools/time_planes.py).
 template <int MODE, bool HAS_LUT>
-__global__ __launch_bounds__(kWG) void k_i16(I16Args a)
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_i16(I16Args a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x;
   if (t >= a.nblocks)
@@ -581,7 +584,9 @@ __global__ __launch_bounds__(kWG) void k_i16(I16Args a)
 
 // Several planes (each with its own table) in one launch: linear block index over the
 // concatenation of the planes; prefix[] is the exclusive scan of per-plane block counts.
-__global__ __launch_bounds__(kWG) void k_i16_planes(PlaneBatchArgs a)
+// LUTMODE: 0 no plane has a table, 1 every plane has one, 2 mixed (branch per wave)
+template <int LUTMODE>
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_i16_planes(PlaneBatchArgs a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x;
   // plane index from the wave's first block: wave-uniform, so the table reads stay scalar
@@ -602,34 +607,76 @@ __global__ __launch_bounds__(kWG) void k_i16_planes(PlaneBatchArgs a)
   // p is wave-uniform (planes are padded to whole waves): scalar table reads, scalar branch
   const int16_t *src = a.from[p] + (size_t)row * 8 * pin + (size_t)bx * 8;
   int16_t *dst = a.to[p] + (size_t)row * 8 * pout + (size_t)bx * 8;
-  if (a.has_lut[p])
+  if (LUTMODE == 1 || (LUTMODE == 2 && a.has_lut[p]))
     i16_block<MODE_ROUNDTRIP, true>(a.consts, src, dst, pin, pout, a.tb[p]);
   else
     i16_block<MODE_ROUNDTRIP, false>(a.consts, src, dst, pin, pout, a.tb[p]);
 }
 
-template <int MODE>
+// float32 rows are 32 B per block: if every lane fetched its own 2 x 16 B, each wave load would
+// touch 64 x 16 B at a 32-byte stride (half of every cache line per instruction).  When the
+// wave's 64 blocks are one contiguous 2 KiB row segment (plane width % 512 == 0) the WIDE form
+// instead issues two fully contiguous 1 KiB loads per row -- lane l takes floats [4l, 4l+4) of
+// each KiB, i.e. half a row of block l/2 resp. 32 + l/2 -- and lane pairs swap halves with one
+// DPP quad_perm [1,0,3,2] per register.  Even lane 2k ends up owning block k, odd lane 2k+1
+// block 32+k of the wave; stores mirror this.
+__device__ __forceinline__ float swap_pair(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+
+template <int MODE, bool WIDE>
 __global__ __launch_bounds__(kWG) void k_f32(F32Args a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x;
   if (t >= a.nblocks)
     return;
-  const uint32_t row = t / a.bpr;
-  const uint32_t bx = t - row * a.bpr;
-  const size_t by = a.by0 + row;
-  const float *src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
-  float *dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
   const DctConsts &C = a.consts;
-
+  const uint32_t lane = threadIdx.x & 63;
+  const bool odd = lane & 1;
   float b[8][8];
-#pragma unroll
-  for (int r = 0; r < 8; r++)
+  const float *src;
+  float *dst;
+
+  if constexpr (WIDE)
   {
-    const f32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)r * a.pitch_in));
-    const f32x4 hi = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)r * a.pitch_in + 4));
-    b[r][0] = lo.x; b[r][1] = lo.y; b[r][2] = lo.z; b[r][3] = lo.w;
-    b[r][4] = hi.x; b[r][5] = hi.y; b[r][6] = hi.z; b[r][7] = hi.w;
+    const uint32_t t0 = t - lane; // the wave's first block; all 64 blocks share a block row
+    const uint32_t row = t0 / a.bpr;
+    const uint32_t bx0 = t0 - row * a.bpr;
+    const size_t by = a.by0 + row;
+    src = a.from + by * 8 * a.pitch_in + (size_t)bx0 * 8 + lane * 4;
+    dst = a.to + by * 8 * a.pitch_out + (size_t)bx0 * 8 + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      const f32x4 A = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)r * a.pitch_in));
+      const f32x4 B = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)r * a.pitch_in + 256));
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        const float got = swap_pair(odd ? A[j] : B[j]); // even lanes receive A (right half), odd lanes B (left half)
+        b[r][j] = odd ? got : A[j];
+        b[r][4 + j] = odd ? B[j] : got;
+      }
+    }
   }
+  else
+  {
+    const uint32_t row = t / a.bpr;
+    const uint32_t bx = t - row * a.bpr;
+    const size_t by = a.by0 + row;
+    src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
+    dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      const f32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)r * a.pitch_in));
+      const f32x4 hi = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)r * a.pitch_in + 4));
+      b[r][0] = lo.x; b[r][1] = lo.y; b[r][2] = lo.z; b[r][3] = lo.w;
+      b[r][4] = hi.x; b[r][5] = hi.y; b[r][6] = hi.z; b[r][7] = hi.w;
+    }
+  }
+
   if constexpr (MODE == MODE_FWD)
   {
     raw_fwd(C, b);
@@ -644,13 +691,30 @@ __global__ __launch_bounds__(kWG) void k_f32(F32Args a)
       b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.scale[i];
     raw_inv(C, b);
   }
+
 #pragma unroll
   for (int r = 0; r < 8; r++)
   {
-    const f32x4 lo = {b[r][0], b[r][1], b[r][2], b[r][3]};
-    const f32x4 hi = {b[r][4], b[r][5], b[r][6], b[r][7]};
-    __builtin_nontemporal_store(lo, reinterpret_cast<f32x4 *>(dst + (size_t)r * a.pitch_out));
-    __builtin_nontemporal_store(hi, reinterpret_cast<f32x4 *>(dst + (size_t)r * a.pitch_out + 4));
+    if constexpr (WIDE)
+    {
+      f32x4 A, B;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        const float got = swap_pair(odd ? b[r][j] : b[r][4 + j]); // even sends its right half, odd its left
+        A[j] = odd ? got : b[r][j];
+        B[j] = odd ? b[r][4 + j] : got;
+      }
+      __builtin_nontemporal_store(A, reinterpret_cast<f32x4 *>(dst + (size_t)r * a.pitch_out));
+      __builtin_nontemporal_store(B, reinterpret_cast<f32x4 *>(dst + (size_t)r * a.pitch_out + 256));
+    }
+    else
+    {
+      const f32x4 lo = {b[r][0], b[r][1], b[r][2], b[r][3]};
+      const f32x4 hi = {b[r][4], b[r][5], b[r][6], b[r][7]};
+      __builtin_nontemporal_store(lo, reinterpret_cast<f32x4 *>(dst + (size_t)r * a.pitch_out));
+      __builtin_nontemporal_store(hi, reinterpret_cast<f32x4 *>(dst + (size_t)r * a.pitch_out + 4));
+    }
   }
 }
 
@@ -738,7 +802,15 @@ hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s)
   const uint32_t total = a.prefix[a.n];
   if (total == 0)
     return hipSuccess;
-  hipLaunchKernelGGL(k_i16_planes, dim3(grid_for(total)), dim3(kWG), 0, s, a);
+  int with = 0;
+  for (int i = 0; i < a.n; i++)
+    with += a.has_lut[i] ? 1 : 0;
+  if (with == 0)
+    hipLaunchKernelGGL(k_i16_planes<0>, dim3(grid_for(total)), dim3(kWG), 0, s, a);
+  else if (with == a.n)
+    hipLaunchKernelGGL(k_i16_planes<1>, dim3(grid_for(total)), dim3(kWG), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_i16_planes<2>, dim3(grid_for(total)), dim3(kWG), 0, s, a);
   return hipGetLastError();
 }
 
@@ -746,10 +818,16 @@ hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s)
 {
   if (a.nblocks == 0)
     return hipSuccess;
-  if (mode == MODE_FWD)
-    hipLaunchKernelGGL((k_f32<MODE_FWD>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
+  const bool wide = a.bpr % 64 == 0; // every wave = 64 blocks of one block row, 2 KiB contiguous per pixel row
+  const dim3 g(grid_for(a.nblocks)), b(kWG);
+  if (mode == MODE_FWD && wide)
+    hipLaunchKernelGGL((k_f32<MODE_FWD, true>), g, b, 0, s, a);
+  else if (mode == MODE_FWD)
+    hipLaunchKernelGGL((k_f32<MODE_FWD, false>), g, b, 0, s, a);
+  else if (wide)
+    hipLaunchKernelGGL((k_f32<MODE_INV, true>), g, b, 0, s, a);
   else
-    hipLaunchKernelGGL((k_f32<MODE_INV>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
+    hipLaunchKernelGGL((k_f32<MODE_INV, false>), g, b, 0, s, a);
   return hipGetLastError();
 }
 

@@ -204,7 +204,8 @@ def test_i16_saturation_pitch_and_ranges():
 
 
 def test_f32_matches_oracle_and_double():
-    for (W, H) in ((8, 8), (256, 64), (1000, 24)):
+    # widths % 512 == 0 take the kernel's wide-load form (lane pairs swap half rows), the others the plain form
+    for (W, H) in ((8, 8), (256, 64), (1000, 24), (512, 16), (1024, 40), (1536, 8)):
         src = synth.plane_u8_np(W, H, "photo").astype(np.float32) - 100.5
         d = dev(src)
         out = torch.empty_like(d)

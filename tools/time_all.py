@@ -1,0 +1,61 @@
+"""Steady-state timing of every engine entry point on BASELINE.json-sized inputs.
+   python3 tools/time_all.py   -> one line per kernel: us, algorithmic GB/s, % of 8 TB/s"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import simd_dct_amd as M
+from simd_dct_amd import synth
+
+W = H = 8192
+M.init(0)
+NS = 4
+i16 = [synth.plane_i16_torch(W, H, "photo", seed=synth.SEED + i) for i in range(NS)]
+o16 = [torch.empty_like(s) for s in i16]
+u8 = [synth.plane_u8_torch(W, H, "photo", seed=synth.SEED + 50 + i).reshape(-1) for i in range(NS)]
+o8 = [torch.empty(W * H, dtype=torch.uint8, device="cuda") for _ in range(NS)]
+f32 = [s.to(torch.float32) for s in i16[:2]]
+of32 = [torch.empty_like(s) for s in f32]
+lut2000 = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
+lut8 = (M.QUANTIZE_BASE * np.float32(8)).astype(np.float32)
+jpeg = (M.QUANTIZE_BASE * np.float32(100)).astype(np.float32)
+# 4:2:0 frame (config 3)
+Y = synth.plane_i16_torch(7680, 4320, "photo"); Cb = synth.plane_i16_torch(3840, 2160, "photo", seed=1); Cr = synth.plane_i16_torch(3840, 2160, "photo", seed=2)
+oY, oCb, oCr = torch.empty_like(Y), torch.empty_like(Cb), torch.empty_like(Cr)
+frame = [(Y, oY, 7680, 4320, jpeg), (Cb, oCb, 3840, 2160, jpeg), (Cr, oCr, 3840, 2160, jpeg)]
+frame_px = 7680 * 4320 + 2 * 3840 * 2160
+
+P = M.prepare_plane_i16
+Q = M.prepare_fwd_quant_u8
+cases = [
+    ("stream copy (roofline)", 4, W * H, [M.prepare_stream_copy(i16[i], o16[i], W * H * 2) for i in range(NS)]),
+    ("i16 roundtrip", 4, W * H, [P("roundtrip", i16[i], o16[i], W, H) for i in range(NS)]),
+    ("i16 roundtrip + table", 4, W * H, [P("roundtrip", i16[i], o16[i], W, H, lut=jpeg) for i in range(NS)]),
+    ("i16 fwd", 4, W * H, [P("fwd", i16[i], o16[i], W, H) for i in range(NS)]),
+    ("i16 fwd + table", 4, W * H, [P("fwd", i16[i], o16[i], W, H, lut=jpeg) for i in range(NS)]),
+    ("i16 inv", 4, W * H, [P("inv", i16[i], o16[i], W, H) for i in range(NS)]),
+    ("i16 inv + table", 4, W * H, [P("inv", i16[i], o16[i], W, H, lut=jpeg) for i in range(NS)]),
+    ("4:2:0 frame roundtrip+tables", 4, frame_px, [M.prepare_roundtrip_i16_planes(frame)]),
+    ("f32 fwd", 8, W * H, [lambda i=i: M.fwd_f32(f32[i], of32[i], W, H) for i in range(2)]),
+    ("f32 inv", 8, W * H, [lambda i=i: M.inv_f32(f32[i], of32[i], W, H) for i in range(2)]),
+    ("u8 q32 / AVX2 tier", 2, W * H, [Q(u8[i], o8[i], lut2000, W, H, 0, H // 8) for i in range(NS)]),
+    ("u8 stereo / SSE tier", 2, W * H, [Q(u8[i], o8[i], lut8, W, H, 0, H // 16, layout=M.LAYOUT_STEREO, profile=M.PROFILE_REF_SSE) for i in range(NS)]),
+    ("u8 stereo / scalar tier", 2, W * H, [Q(u8[i], o8[i], lut8, W, H, 0, H // 16, layout=M.LAYOUT_STEREO, profile=M.PROFILE_REF_SCALAR) for i in range(NS)]),
+    ("u8 encq / SSE tier", 2, W * H, [Q(u8[i], o8[i], lut8, W, H, 0, H // 8, layout=M.LAYOUT_BLOCK_SSE, profile=M.PROFILE_REF_SSE) for i in range(NS)]),
+    ("u8 encq / scalar tier", 2, W * H, [Q(u8[i], o8[i], lut8, W, H, 0, H // 8, layout=M.LAYOUT_BLOCK, profile=M.PROFILE_REF_SCALAR) for i in range(NS)]),
+]
+t = M.Timer()
+print(f"{'kernel':32s} {'us':>8s} {'Mpx/s':>10s} {'alg GB/s':>9s} {'% of 8 TB/s':>11s}")
+for name, bpp, px, calls in cases:
+    for i in range(300):
+        calls[i % len(calls)]()
+    best = []
+    for r in range(5):
+        t.start()
+        for i in range(40):
+            calls[i % len(calls)]()
+        t.stop()
+        best.append(t.elapsed_ms() / 40)
+    best.sort()
+    ms = best[len(best) // 2]
+    gbps = bpp * px / (ms * 1e-3) / 1e9
+    print(f"{name:32s} {ms*1e3:8.2f} {px/(ms*1e-3)/1e6:10.0f} {gbps:9.1f} {gbps/80:10.1f}%")
