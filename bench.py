@@ -189,7 +189,7 @@ def main():
     extras, allgather = {}, None
     if not args.no_extras:
         def rate(fn, bytes_per_launch, n=200):
-            for i in range(300):
+            for i in range(300 if n >= 100 else 10):
                 fn(i)
             torch.cuda.synchronize()
             timer.start()
@@ -213,6 +213,18 @@ def main():
         extras["fwd_quant_u8_q32"] = rate(prepared(lambda i: M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, H // 8)), 2 * W * H)
         extras["fwd_quant_u8_q32"]["Mpx_s"] = round(W * H / (extras["fwd_quant_u8_q32"]["ms"] * 1e-3) / 1e6, 0)
         extras["roundtrip_frac_of_measured_copy"] = round(achieved / extras["stream_copy_roofline"]["GBps"], 3)
+        # the same kernel without the per-launch drain: 8 planes stacked in memory are one tall
+        # plane (blocks are independent), one launch
+        try:
+            nb = 8
+            tall_in = torch.cat(srcs + srcs, dim=0)
+            tall_out = torch.empty_like(tall_in)
+            call = M.prepare_plane_i16("roundtrip", tall_in, tall_out, W, nb * H)
+            extras["roundtrip_8_planes_one_launch"] = rate(lambda i: call(), nb * 2 * nbytes, n=20)
+            extras["roundtrip_8_planes_one_launch"]["ms_per_plane"] = round(extras["roundtrip_8_planes_one_launch"]["ms"] / nb, 4)
+            del tall_in, tall_out
+        except Exception as e:
+            extras["roundtrip_8_planes_one_launch"] = {"error": str(e)[:120]}
 
     log("extras done")
     if dist is not None and not args.no_extras:

@@ -424,3 +424,15 @@ def test_host_pointer_pipeline_multi_chunk():
         assert np.array_equal(out, want)
     finally:
         M.set_max_simd(2)
+
+
+def test_stacked_batch_is_one_tall_plane():
+    """config 4 usage: a batch of independent planes stacked in memory is transformed by ONE call on
+    the tall plane (blocks are independent), identical to per-plane calls"""
+    W, H, N = 256, 64, 5
+    planes = [synth.plane_i16_np(W, H, "photo", seed=synth.SEED + i) for i in range(N)]
+    stacked = dev(np.concatenate(planes, axis=0))
+    out = torch.empty_like(stacked)
+    M.fwd_i16(stacked, out, W, N * H)
+    for i, p in enumerate(planes):
+        assert np.array_equal(out[i * H:(i + 1) * H].cpu().numpy(), O.i16("fwd", p, W, H)), i
