@@ -93,3 +93,20 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmdct_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_synthetic_generators_agree_host_and_torch():
+    """bench and tests feed the CPU checker and the GPU path from the same counter hash"""
+    import torch
+
+    from simd_dct_amd import synth
+
+    for kind in ("noise", "photo"):
+        a = synth.plane_u8_np(96, 40, kind, seed=123)
+        b = synth.plane_u8_torch(96, 40, kind, seed=123, device="cpu").numpy()
+        assert np.array_equal(a, b), kind
+    for bits in (8, 12):
+        a = synth.plane_i16_np(64, 24, "photo", seed=7, bits=bits)
+        b = synth.plane_i16_torch(64, 24, "photo", seed=7, bits=bits, device="cpu").numpy()
+        assert np.array_equal(a, b), bits
+        assert a.min() >= -(1 << (bits - 1)) and a.max() < (1 << (bits - 1))

@@ -436,3 +436,75 @@ def test_stacked_batch_is_one_tall_plane():
     M.fwd_i16(stacked, out, W, N * H)
     for i, p in enumerate(planes):
         assert np.array_equal(out[i * H:(i + 1) * H].cpu().numpy(), O.i16("fwd", p, W, H)), i
+
+
+def test_launches_are_graph_capturable():
+    """include/mdct.h promises that launches neither allocate nor synchronise: capture a forward, a
+    quantised round trip and a q32 call into one hipGraph, replay it on new data, compare with the oracle"""
+    W, H = 512, 128
+    lut = lut_x(40)
+    src = torch.zeros((H, W), dtype=torch.int16, device="cuda")
+    coef, rt = torch.empty_like(src), torch.empty_like(src)
+    img = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
+    q = torch.empty_like(img)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm up outside capture (lazy device probe)
+        M.fwd_i16(src, coef, W, H)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        M.fwd_i16(src, coef, W, H)
+        M.roundtrip_i16(src, rt, W, H, lut=lut)
+        M.fwd_quant_u8(img, q, lut_x(2000), W, H, 0, H // 8)
+    for seed in (1, 2):
+        hs = synth.plane_i16_np(W, H, "photo", seed=seed)
+        hi = synth.plane_u8_np(W, H, "noise", seed=seed)
+        src.copy_(dev(hs))
+        img.copy_(dev(hi.reshape(-1)))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(coef.cpu().numpy(), O.i16("fwd", hs, W, H))
+        assert np.array_equal(rt.cpu().numpy(), O.i16("roundtrip", hs, W, H, lut=lut))
+        rc, want = O.q32_native(hi, lut_x(2000), W, H, 0, H // 8)
+        assert np.array_equal(q.cpu().numpy(), want)
+
+
+def test_randomised_geometry_sweep():
+    """seeded random widths / heights / row ranges / tiers through the native C-ABI vs the oracle's
+    reference-semantics functions (which the native ranges are mapped onto), canary-checked"""
+    rng = np.random.default_rng(20261003)
+    combos = [("q32_avx", 64, 8), ("stereo_sse", 16, 16), ("stereo_scalar", 16, 16), ("encq_sse", 16, 8), ("encq_scalar", 8, 8)]
+    for it in range(40):
+        beh, xm, ym = combos[it % len(combos)]
+        W = int(rng.integers(1, 12)) * xm * (4 if xm < 64 else 1)
+        H = int(rng.integers(2, 20)) * 16
+        img = rng.integers(0, 256, W * H, dtype=np.uint8)
+        lut = (lut_x(float(rng.choice([1.0, 8.0, 100.0, 2000.0]))) * rng.uniform(0.3, 3.0, 64).astype(np.float32)).astype(np.float32)
+        y0 = int(rng.integers(0, H))
+        y1 = int(rng.integers(y0, 2 * H))
+        rc, got = run_ref_api(beh, img, lut, W, H, y0, y1)
+        want = np.full(W * H, CANARY, dtype=np.uint8)
+        rc2, want = O.run_behaviour(beh, img, lut, W, H, y0, y1, out=want)
+        assert rc == rc2 == 0, (beh, W, H, y0, y1, M.last_error())
+        assert np.array_equal(got, want), (beh, W, H, y0, y1, int((got != want).sum()))
+    for it in range(20):  # engine-own int16 paths: random geometry, pitch, range, table
+        W = int(rng.integers(1, 40)) * 8
+        H = int(rng.integers(1, 12)) * 8
+        pitch = W + 8 * int(rng.integers(0, 3))
+        src = rng.integers(-2048, 2048, (H, pitch), dtype=np.int16)
+        table = None if it % 3 == 0 else (lut_x(30) * rng.uniform(0.5, 2, 64).astype(np.float32)).astype(np.float32)
+        b0 = int(rng.integers(0, H // 8 + 1))
+        b1 = int(rng.integers(b0, H // 8 + 1))
+        mode = ("fwd", "inv", "roundtrip")[it % 3]
+        fn = {"fwd": M.fwd_i16, "inv": M.inv_i16, "roundtrip": M.roundtrip_i16}[mode]
+        out = torch.full((H, pitch), 4321, dtype=torch.int16, device="cuda")
+        fn(dev(src), out, W, H, lut=table, by0=b0, by1=b1, pitch_in=pitch, pitch_out=pitch)
+        want = np.full((H, pitch), 4321, dtype=np.int16)
+        o = O.oracle()
+        f = getattr(o, {"fwd": "orc_fwd_i16", "inv": "orc_inv_i16", "roundtrip": "orc_roundtrip_i16"}[mode])
+        lp = None
+        if table is not None:
+            keep, lp = O._lut(table)
+        assert f(src.ctypes.data, want.ctypes.data, pitch, pitch, lp, W, H, b0, b1) == 0
+        assert np.array_equal(out.cpu().numpy(), want), (mode, W, H, pitch, b0, b1)
