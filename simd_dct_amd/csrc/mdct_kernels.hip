@@ -348,8 +348,13 @@ constexpr int kQ32RowStride = 72;  // 64 lanes + 8 pad: keeps rows 8-byte aligne
 // Occupancy: the Q32 instantiation is asked to fit 6 waves/SIMD (80 VGPRs, 8 B of scratch):
 // measured -6 % kernel time vs the unconstrained 98 VGPRs / 5 waves; the other layouts spill
 // badly under the same bound and are left alone (profiles/r01_occupancy_variants.log).
+#ifdef MDCT_U8_WAVES
+#define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8_WAVES, MDCT_U8_WAVES)))
+#else
+#define MDCT_U8_ATTR __launch_bounds__(kWG, (LAYOUT == MDCT_LAYOUT_Q32 && !SAFE) ? 6 : 1)
+#endif
 template <int PROFILE, int LAYOUT, bool SAFE>
-__global__ __launch_bounds__(kWG, (LAYOUT == MDCT_LAYOUT_Q32 && !SAFE) ? 6 : 1) void k_fwd_quant_u8(U8Args a)
+__global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x; // linear block index within the launch
   const bool valid = t < a.nblocks;
@@ -567,11 +572,14 @@ __device__ __forceinline__ void i16_block(const DctConsts &C, const int16_t *src
     store_i16x8<SHIFT>(C, dst + (size_t)r * pitch_out, b[r]);
 }
 
-// Register budget pinned to 4 waves/SIMD (<= 128 VGPRs): left to its occupancy heuristic the
-// compiler sometimes squeezes these kernels into ~88 VGPRs, serialising the row loads behind
-// the butterflies; measured 58 vs 49 us on the same work (tools/time_planes.py).
+// The compiler's register/scheduling heuristic is steered per mode with amdgpu_waves_per_eu; the
+// values are the measured optimum of {2..6} on MI355X, ROCm 7.2 (profiles/r01_waves_per_eu.log):
+// forward 44.0 us with 2 (46.6 with 4), inverse 45.7 us with 4 (47.8 with 2), fused round trip
+// 47.4 us with 3 (48.3 with 4, 51.5 with 2).  Left to itself the compiler sometimes serialises the eight row loads
+// behind the butterflies (58 vs 49 us on identical work, tools/time_planes.py).
+constexpr int i16_waves(int mode) { return mode == MODE_ROUNDTRIP ? 3 : (mode == MODE_FWD ? 2 : 4); }
 template <int MODE, bool HAS_LUT>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_i16(I16Args a)
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(MODE), i16_waves(MODE)))) void k_i16(I16Args a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x;
   if (t >= a.nblocks)
@@ -625,8 +633,13 @@ __device__ __forceinline__ float swap_pair(float v)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
 }
 
+// scheduling steered like the int16 kernels (measured: 89.7 us with 2, 97.7 unsteered, 93-107 with 3..6)
+#ifndef MDCT_F32_WAVES
+#define MDCT_F32_WAVES 2
+#endif
+#define MDCT_F32_ATTR __attribute__((amdgpu_waves_per_eu(MDCT_F32_WAVES, MDCT_F32_WAVES)))
 template <int MODE, bool WIDE>
-__global__ __launch_bounds__(kWG) void k_f32(F32Args a)
+__global__ __launch_bounds__(kWG) MDCT_F32_ATTR void k_f32(F32Args a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x;
   if (t >= a.nblocks)
