@@ -233,11 +233,17 @@ __device__ __forceinline__ uint32_t quant_sse(float f, float q, float magic23)
 }
 
 // B4/B5 :245, :362  (uint8_t)roundf(_clamp(f*qs + 127/255, 0, 1) * 255)
-__device__ __forceinline__ uint32_t quant_scalar(float f, float qs)
+// roundf (half away from zero) of x in [0, 255] without libm: r = rne(x) by the magic add, and
+// the two differ only at an exact tie that rne resolved downwards (x - r == +0.5), where roundf
+// wants r + 1.  x - r is exact (|x - r| <= 0.5 and both are multiples of ulp(x)).
+__device__ __forceinline__ uint32_t quant_scalar(float f, float qs, float magic23)
 {
   float v = (f * qs) + (127.0f / 255.0f);
-  v = v > 0.f ? (v < 1.f ? v : 1.f) : 0.f;
-  return (uint32_t)roundf(v * 255.f);
+  v = v > 0.f ? (v < 1.f ? v : 1.f) : 0.f; // _clamp(v, 0, 1) of :50-54, NaN -> 0
+  const float x = v * 255.f;
+  const float t = x + magic23;
+  const float r = t - magic23;
+  return __float_as_uint(t) + ((x - r) == 0.5f ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -283,7 +289,7 @@ __device__ __forceinline__ float px_to_float(float f)
 // quantised bytes as int values q[v][u] (natural index) for the AVX/stereo layouts or
 // q[u][v]-transposed-stored semantics handled by the caller.
 template <int PROFILE, int LAYOUT, bool SAFE>
-__device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *src, size_t pitch, const QuantTable &qt, uint32_t (&out)[64])
+__device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *src, size_t pitch, const QuantTable &qt, const float *px_div255, uint32_t (&out)[64])
 {
   uint2 rows[8];
 #pragma unroll
@@ -294,14 +300,28 @@ __device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *
   for (int r = 0; r < 8; r++)
   {
     const uint2 v = rows[r];
-    b[r][0] = px_to_float<PROFILE>(ubyte_to_float<0>(v.x));
-    b[r][1] = px_to_float<PROFILE>(ubyte_to_float<1>(v.x));
-    b[r][2] = px_to_float<PROFILE>(ubyte_to_float<2>(v.x));
-    b[r][3] = px_to_float<PROFILE>(ubyte_to_float<3>(v.x));
-    b[r][4] = px_to_float<PROFILE>(ubyte_to_float<0>(v.y));
-    b[r][5] = px_to_float<PROFILE>(ubyte_to_float<1>(v.y));
-    b[r][6] = px_to_float<PROFILE>(ubyte_to_float<2>(v.y));
-    b[r][7] = px_to_float<PROFILE>(ubyte_to_float<3>(v.y));
+    if constexpr (PROFILE == MDCT_PROFILE_REF_SCALAR)
+    { // px / 255.f (:222, :343) has only 256 possible results: looked up, not divided (see kernel)
+      b[r][0] = px_div255[v.x & 0xFF];
+      b[r][1] = px_div255[(v.x >> 8) & 0xFF];
+      b[r][2] = px_div255[(v.x >> 16) & 0xFF];
+      b[r][3] = px_div255[v.x >> 24];
+      b[r][4] = px_div255[v.y & 0xFF];
+      b[r][5] = px_div255[(v.y >> 8) & 0xFF];
+      b[r][6] = px_div255[(v.y >> 16) & 0xFF];
+      b[r][7] = px_div255[v.y >> 24];
+    }
+    else
+    {
+      b[r][0] = px_to_float<PROFILE>(ubyte_to_float<0>(v.x));
+      b[r][1] = px_to_float<PROFILE>(ubyte_to_float<1>(v.x));
+      b[r][2] = px_to_float<PROFILE>(ubyte_to_float<2>(v.x));
+      b[r][3] = px_to_float<PROFILE>(ubyte_to_float<3>(v.x));
+      b[r][4] = px_to_float<PROFILE>(ubyte_to_float<0>(v.y));
+      b[r][5] = px_to_float<PROFILE>(ubyte_to_float<1>(v.y));
+      b[r][6] = px_to_float<PROFILE>(ubyte_to_float<2>(v.y));
+      b[r][7] = px_to_float<PROFILE>(ubyte_to_float<3>(v.y));
+    }
   }
 
   constexpr int K = PROFILE == MDCT_PROFILE_REF_AVX ? K_AVX : (PROFILE == MDCT_PROFILE_REF_SSE ? K_SSE : K_TRUE);
@@ -330,7 +350,7 @@ __device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *
     else if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
       out[s] = quant_sse<SAFE>(f, qt.q[s], C.magic23);
     else
-      out[s] = quant_scalar(f, qt.q[s]);
+      out[s] = quant_scalar(f, qt.q[s], C.magic23);
   }
 }
 
@@ -344,6 +364,7 @@ __device__ __forceinline__ uint32_t pack4_lo8(uint32_t a, uint32_t b, uint32_t c
 
 constexpr int kWG = 256;           // 4 waves
 constexpr int kQ32RowStride = 72;  // 64 lanes + 8 pad: keeps rows 8-byte aligned for ds_read_b64
+constexpr int kStereoRowStride = kWG + 16; // 256 blocks + pad, rows stay 16-byte aligned for ds_read_b128
 
 // Occupancy: the Q32 instantiation is asked to fit 6 waves/SIMD (80 VGPRs, 8 B of scratch):
 // measured -6 % kernel time vs the unconstrained 98 VGPRs / 5 waves; the other layouts spill
@@ -374,13 +395,25 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
       by = a.by0 + row;
   }
 
+  // scalar tiers: the 256 possible values of px / 255.f, each computed ONCE per workgroup with
+  // the same IEEE division the reference performs per pixel (one thread per value, kWG == 256)
+  const float *px_div255 = nullptr;
+  if constexpr (PROFILE == MDCT_PROFILE_REF_SCALAR)
+  {
+    static_assert(kWG == 256, "one table entry per thread");
+    __shared__ float div_tab[256];
+    div_tab[threadIdx.x] = (float)threadIdx.x / 255.f;
+    __syncthreads();
+    px_div255 = div_tab;
+  }
+
   uint32_t q[64];
   if (valid)
   {
     const uint8_t *src = a.from + (size_t)by * 8 * a.pitch + (size_t)bx * 8;
     if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
       src += (size_t)eye * a.eye_offset;
-    encode_block<PROFILE, LAYOUT, SAFE>(a.consts, src, a.pitch, a.qt, q);
+    encode_block<PROFILE, LAYOUT, SAFE>(a.consts, src, a.pitch, a.qt, px_div255, q);
   }
 
   if constexpr (LAYOUT == MDCT_LAYOUT_Q32)
@@ -422,7 +455,31 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
   }
   else if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
   {
-    if (valid)
+    // 64 coefficient planes; block t of the launch lands at byte (by0*2*bpr + t) of every plane
+    // (:1061-1099), so a full workgroup owns 256 consecutive bytes per plane.  Stage them in LDS
+    // as [coef][block] and store 16 B per lane (4 wide stores instead of 64 byte stores per lane).
+    __shared__ __attribute__((aligned(16))) uint8_t slds[64 * kStereoRowStride];
+    const uint32_t wg_t0 = blockIdx.x * kWG;
+    const bool full_wg = wg_t0 + kWG <= a.nblocks; // workgroup-uniform
+    if (full_wg)
+    {
+#pragma unroll
+      for (int c = 0; c < 64; c++)
+        slds[c * kStereoRowStride + threadIdx.x] = (uint8_t)q[c];
+      __syncthreads();
+      uint8_t *out0 = a.to + (size_t)a.by0 * 2 * a.bpr + wg_t0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+      {
+        const uint32_t chunk = threadIdx.x + kWG * k; // 64 planes x 16 chunks of 16 B
+        const uint32_t c = chunk >> 4, part = chunk & 15;
+        const uint4 v = *reinterpret_cast<const uint4 *>(slds + c * kStereoRowStride + part * 16);
+        typedef unsigned int u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+        const u32x4_unaligned w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4_unaligned *>(out0 + a.plane_stride * c + part * 16));
+      }
+    }
+    else if (valid)
     {
       const size_t pos = ((size_t)by * 2 + eye) * a.bpr + bx;
 #pragma unroll

@@ -508,3 +508,39 @@ def test_randomised_geometry_sweep():
             keep, lp = O._lut(table)
         assert f(src.ctypes.data, want.ctypes.data, pitch, pitch, lp, W, H, b0, b1) == 0
         assert np.array_equal(out.cpu().numpy(), want), (mode, W, H, pitch, b0, b1)
+
+
+def test_shim_mixed_pointers_and_async_stream():
+    """host->device, device->host and device->device (asynchronous, on a caller-chosen stream)
+    calls of the reference API all give the oracle's bytes"""
+    from simd_dct_amd import _lib
+
+    W, H = 256, 128
+    img = synth.plane_u8_np(W, H, "photo").reshape(-1)
+    lut = lut_x(2000)
+    want = np.full(W * H, CANARY, dtype=np.uint8)
+    O.run_behaviour("q32_avx", img, lut, W, H, 0, H, out=want)
+    d_img = dev(img)
+    # host in, device out
+    d_out = torch.full((W * H,), CANARY, dtype=torch.uint8, device="cuda")
+    assert M.simdDCT_EncodeQuantize32ReorderBuffer(img, d_out, lut, W, H, 0, H) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), want)
+    # device in, host out
+    h_out = np.full(W * H, CANARY, dtype=np.uint8)
+    assert M.simdDCT_EncodeQuantize32ReorderBuffer(d_img, h_out, lut, W, H, 0, H) == 0
+    assert np.array_equal(h_out, want)
+    # device to device, asynchronous on a side stream
+    lib = _lib.load()
+    side = torch.cuda.Stream()
+    d_out2 = torch.full((W * H,), CANARY, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    lib.mdct_shim_set_stream(side.cuda_stream)
+    lib.mdct_shim_set_async(1)
+    try:
+        assert M.simdDCT_EncodeQuantize32ReorderBuffer(d_img, d_out2, lut, W, H, 0, H) == 0
+        side.synchronize()
+        assert np.array_equal(d_out2.cpu().numpy(), want)
+    finally:
+        lib.mdct_shim_set_async(0)
+        lib.mdct_shim_set_stream(None)

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256, 6) void v_compute(U8Args a)
 #pragma unroll 1
   for (int i = 0; i < REPS; i++)
   {
-    encode_block<MDCT_PROFILE_REF_AVX, MDCT_LAYOUT_Q32, false>(a.consts, src + (acc.x & 1) * 8, a.pitch, a.qt, q);
+    encode_block<MDCT_PROFILE_REF_AVX, MDCT_LAYOUT_Q32, false>(a.consts, src + (acc.x & 1) * 8, a.pitch, a.qt, nullptr, q);
     if (WITH_LDS)
     {
 #pragma unroll
