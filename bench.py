@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W = H = 8192
 NSETS = 4
-PRECONDITION = 600  # untimed launches (~30 ms) before warmup, see main()
+PRECONDITION = 1000  # untimed launches (~50 ms) before warmup, see main()
 ALG_BYTES_PER_PX = 4  # int16 in + int16 out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -156,17 +156,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed pre-conditioning: for the first ~15 ms of sustained launches the chip's power
-    # management overshoots (kernel time 48 -> 61 -> 48 us, profiles/r01_sustained.log); the
-    # metric is the steady state, so settle before the W warmup steps and the K timed ones.
-    for i in range(PRECONDITION):
-        step(i)
-    for i in range(args.warmup):
+    # Correctness of the workload first (untimed): fused fwd->inv of every plane set is a bit-exact
+    # round trip.  Done BEFORE the pre-conditioning so that nothing idles the GPU afterwards.
+    for i in range(NSETS):
         step(i)
     torch.cuda.synchronize()
     verified = all(torch.equal(s, d) for s, d in zip(srcs, dsts))
 
+    # Untimed pre-conditioning.  From idle the chip's power management overshoots for the first
+    # ~400 launches (63 -> 47.3 us per launch, profiles/r01_transient_from_idle.log) and any idle
+    # gap longer than ~1 ms restarts that (profiles/r01_idle_gap.log).  The metric is the steady
+    # state, so: align the ranks, run 1000 untimed launches back to back, then the W warmup steps,
+    # and enter the timed region through the (sub-millisecond) barrier with no other work between.
     timer = M.Timer()
+    if dist is not None:
+        dist.barrier()
+    for i in range(PRECONDITION):
+        step(i)
+    for i in range(args.warmup):
+        step(i)
+
     barrier()
     t0 = time.perf_counter()
     timer.start()
@@ -228,29 +237,54 @@ def main():
 
     log("extras done")
     if dist is not None and not args.no_extras:
-        # north_star's whole-node run: block-row shards of one plane batch all-gathered over xGMI.
+        # north_star's whole-node run: every plane's block rows are sharded over the ranks, each rank
+        # transforms its shard (forward int16) and the coefficients are all-gathered over xGMI, in
+        # place (shards are contiguous slabs in rank order).  Three figures over the same NP planes:
+        # compute only, gather only, and pipelined (plane k's gather overlaps plane k+1's kernel:
+        # the collective is asynchronous on RCCL's stream).  Never part of `value`.
         try:
             from simd_dct_amd.sharding import shard_rows
 
+            NP = NSETS
             rows = H // 8
             b0, b1 = shard_rows(rows, world, rank)
-            full = dsts[0]
-            M.fwd_i16(srcs[0], full, W, H, by0=b0, by1=b1)
-            gath = full.view(torch.uint8).reshape(-1)
-            mine = gath[b0 * 8 * W * 2:b1 * 8 * W * 2]
-            torch.cuda.synchronize()
-            dist.barrier()
-            n = 10
-            t0 = time.perf_counter()
-            for _ in range(n):
-                M.fwd_i16(srcs[0], full, W, H, by0=b0, by1=b1)
-                dist.all_gather_into_tensor(gath, mine)
-            torch.cuda.synchronize()
-            dist.barrier()
-            dt = (time.perf_counter() - t0) / n
-            allgather = {"what": "one 8192x8192 int16 plane, block rows sharded over ranks, fwd + in-place all_gather_into_tensor",
-                         "ms": round(dt * 1e3, 3), "Mpx_s": round(W * H / dt / 1e6, 0),
-                         "busbw_GBps": round((world - 1) / world * W * H * 2 / dt / 1e9, 1)}
+            lo, hi = b0 * 8 * W * 2, b1 * 8 * W * 2
+            gath = [d.view(torch.uint8).reshape(-1) for d in dsts[:NP]]
+            fwd = [M.prepare_plane_i16("fwd", srcs[k], dsts[k], W, H, by0=b0, by1=b1) for k in range(NP)]
+
+            def timed(body, reps=5):
+                body()
+                torch.cuda.synchronize()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    body()
+                torch.cuda.synchronize()
+                dist.barrier()
+                return (time.perf_counter() - t0) / reps / NP
+
+            def compute_only():
+                for k in range(NP):
+                    fwd[k]()
+
+            def gather_only():
+                for k in range(NP):
+                    dist.all_gather_into_tensor(gath[k], gath[k][lo:hi])
+
+            def pipelined():
+                works = []
+                for k in range(NP):
+                    fwd[k]()
+                    works.append(dist.all_gather_into_tensor(gath[k], gath[k][lo:hi], async_op=True))
+                for w in works:
+                    w.wait()
+
+            tc, tg, tp = timed(compute_only), timed(gather_only), timed(pipelined)
+            plane_bytes = W * H * 2
+            allgather = {"what": f"{NP} planes of 8192x8192 int16, block rows sharded over {world} ranks, forward + in-place all_gather_into_tensor (RCCL)",
+                         "ms_per_plane": {"compute_only": round(tc * 1e3, 4), "gather_only": round(tg * 1e3, 4), "pipelined": round(tp * 1e3, 4)},
+                         "Mpx_s_pipelined": round(W * H / tp / 1e6, 0),
+                         "busbw_GBps_gather_only": round((world - 1) / world * plane_bytes / tg / 1e9, 1)}
         except Exception as e:
             allgather = {"error": str(e)[:200]}
 
