@@ -28,7 +28,7 @@ namespace mdct
 // a 4-byte encoding, the same op with a 32-bit literal is 8 bytes, and these kernels are
 // ~2000 straight-line VALU instructions per wave.
 
-enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2, K_OWN = 3 };
+enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2 }; // the reference's three 1-D kernels (the engine-own one is aan_fwd8 below)
 
 // ---------------------------------------------------------------------------------------
 // 1-D 8-point forward kernel on eight registers.
@@ -69,15 +69,11 @@ __device__ __forceinline__ void dct8(const DctConsts &C, float &p0, float &p1, f
       o1 = t1 + ((kCd * x25m) + (kCf * x43m)); // quirk: +Cf
       o3 = t3 + ((kCd * x43m) - (kCa * x25m)); // ((-Ca)*x25m) + (Cd*x43m)
     }
-    else if constexpr (K == K_AVX)
-    {
-      o1 = t1 + ((kCd * x25m) - (kCf * x43m));
-      o3 = t3 - ((kCa * x25m) + (kCd * x43m)); // quirk: -Cd
-    }
     else
     {
+      static_assert(K == K_AVX, "unknown 1-D kernel");
       o1 = t1 + ((kCd * x25m) - (kCf * x43m));
-      o3 = t3 - ((kCa * x25m) - (kCd * x43m));
+      o3 = t3 - ((kCa * x25m) + (kCd * x43m)); // quirk: -Cd
     }
     o5 = t5 + ((kCf * x25m) - (kCc * x43m));
     o7 = t7 + ((kCc * x25m) + (kCa * x43m));
@@ -89,7 +85,7 @@ __device__ __forceinline__ void dct8(const DctConsts &C, float &p0, float &p1, f
 
 // ---------------------------------------------------------------------------------------
 // Engine-own 1-D kernels (int16 / float32 paths; no reference counterpart): the scaled
-// Arai-Agui-Nakajima butterfly, 5 mul + 29 add per 8 points instead of 24 + 32.  Measured
+// Arai-Agui-Nakajima butterfly, 5 mul + 29 add per 8 points instead of 28 + 28.  Measured
 // on MI355X (tools/valubench, tools/exp_roundtrip): these kernels are bound by VALU ISSUE,
 // v_add/v_mul_f32 issue at ~2-3 cycles per wave64, v_fma_f32 and v_pk_*_f32 at ~4-5, so
 // neither fusing nor packing buys anything -- only fewer operations do.  The scale factors
@@ -97,11 +93,6 @@ __device__ __forceinline__ void dct8(const DctConsts &C, float &p0, float &p1, f
 // and for the fused round trip they cancel to exactly 1/64, which the final rounding step
 // absorbs (see store_i16x8).  Same operation order as the CPU checker (orc_aan_*).
 // ---------------------------------------------------------------------------------------
-struct AanK
-{
-  float c707, c382, c541, c1306, c1414, c1847, c1082, c2613;
-};
-
 __device__ __forceinline__ void aan_fwd8(const DctConsts &C, float &p0, float &p1, float &p2, float &p3, float &p4, float &p5, float &p6, float &p7)
 {
   const float t0 = p0 + p7, t7 = p0 - p7, t1 = p1 + p6, t6 = p1 - p6;
