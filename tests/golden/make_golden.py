@@ -60,6 +60,22 @@ def main():
                 rc, out = O.run_behaviour(beh, img, lut, bw, bh, 0, bh, use_reference=True)
                 big[f"{beh}__{kind}__{bw}x{bh}__x{scs[0]:g}"] = hashlib.sha256(out.tobytes()).hexdigest()
     meta["sha256_zero_prefilled"] = big
+    # BASELINE.json configs[0] at full size: the reference's own CPU path on the 8192x8192 synthetic
+    # plane (hash only).  "half" = the call main.cpp makes (top half processed, rest stays zero),
+    # "full" = the sizeY = 2H form that covers the whole plane.
+    W0 = H0 = 8192
+    img = synth.plane_u8_np(W0, H0, "photo")
+    cfg0 = {}
+    lut = (QUANTIZE_BASE * np.float32(2000.0)).astype(np.float32)
+    rc, out = O.run_behaviour("q32_avx", img, lut, W0, H0, 0, H0, use_reference=True)
+    cfg0["q32_avx__photo__8192x8192__x2000__half"] = hashlib.sha256(out.tobytes()).hexdigest()
+    out = np.zeros(W0 * H0, dtype=np.uint8)
+    O.run_behaviour("q32_avx", img, lut, W0, 2 * H0, 0, 2 * H0, out=out, use_reference=True)
+    cfg0["q32_avx__photo__8192x8192__x2000__full"] = hashlib.sha256(out.tobytes()).hexdigest()
+    lut8 = (QUANTIZE_BASE * np.float32(8.0)).astype(np.float32)
+    rc, out = O.run_behaviour("stereo_sse", img, lut8, W0, H0, 0, H0, use_reference=True)
+    cfg0["stereo_sse__photo__8192x8192__x8"] = hashlib.sha256(out.tobytes()).hexdigest()
+    meta["config0_sha256"] = cfg0
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **vec)
     with open(os.path.join(HERE, "ref_vectors.json"), "w") as f:
         json.dump(meta, f, indent=1)

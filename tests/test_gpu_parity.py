@@ -544,3 +544,22 @@ def test_shim_mixed_pointers_and_async_stream():
     finally:
         lib.mdct_shim_set_async(0)
         lib.mdct_shim_set_stream(None)
+
+
+def test_config0_full_size_hash_of_the_real_reference(golden):
+    """the GPU's bytes for the whole 8192x8192 plane hash to what the REAL reference produced
+    (tests/golden/ref_vectors.json, generated where /root/reference exists)"""
+    import hashlib
+
+    meta, _ = golden
+    W = H = 8192
+    img = synth.plane_u8_torch(W, H, "photo").reshape(-1)
+    out = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
+    assert M.simdDCT_EncodeQuantize32ReorderBuffer(img, out, lut_x(2000), W, H, 0, H) == 0  # main.cpp's own call
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == meta["config0_sha256"]["q32_avx__photo__8192x8192__x2000__half"]
+    out.zero_()
+    assert M.simdDCT_EncodeQuantize32ReorderBuffer(img, out, lut_x(2000), W, 2 * H, 0, 2 * H) == 0
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == meta["config0_sha256"]["q32_avx__photo__8192x8192__x2000__full"]
+    out.zero_()
+    assert M.simdDCT_EncodeQuantizeReorderStereoBuffer(img, out, lut_x(8), W, H, 0, H) == 0
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == meta["config0_sha256"]["stereo_sse__photo__8192x8192__x8"]

@@ -191,3 +191,19 @@ def test_row_range_is_additive():
     for (a, b) in ((0, 3), (3, 4), (4, 8)):
         O.q32_native(img, lut, W, H, a, b, out=parts)
     assert np.array_equal(parts, full)
+
+
+def test_config0_full_size_reference_cpu_path(golden):
+    """BASELINE.json configs[0]: single 8192x8192 uint8 plane through the reference's CPU path
+    (no GPU).  The oracle reproduces the hash the real reference gave for the whole plane."""
+    meta, _ = golden
+    W = H = 8192
+    img = synth.plane_u8_np(W, H, "photo")
+    lut = (QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
+    out = np.zeros(W * H, dtype=np.uint8)
+    O.run_behaviour("q32_avx", img, lut, W, 2 * H, 0, 2 * H, out=out)
+    assert hashlib.sha256(out.tobytes()).hexdigest() == meta["config0_sha256"]["q32_avx__photo__8192x8192__x2000__full"]
+    if O.reference() is not None:  # and the real thing, where it exists
+        ref = np.zeros(W * H, dtype=np.uint8)
+        O.run_behaviour("q32_avx", img, lut, W, 2 * H, 0, 2 * H, out=ref, use_reference=True)
+        assert np.array_equal(ref, out)
