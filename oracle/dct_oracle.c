@@ -296,8 +296,9 @@ int orc_stereo_sse(const uint8_t *from, uint8_t *to, const float *lut, size_t W,
   const int e = check_args(from, to, W, H, 8);
   if (e)
     return e;
-  if (W % 16 != 0)
-    return 2; /* the reference walks 16 px at a time and over-reads otherwise (:945) */
+  if (W % 16 != 0 || H % 16 != 0)
+    return 2; /* the reference walks 16 px at a time (:945) and reads the second image from row
+               * H/2 (:1097): it over-reads the plane otherwise; refused here and in the product */
   float q[64];
   make_q255(lut, q);
   const size_t plane = (W * H) / 64;
@@ -401,6 +402,8 @@ int orc_stereo_scalar(const uint8_t *from, uint8_t *to, const float *lut, size_t
   const int e = check_args(from, to, W, H, 8);
   if (e)
     return e;
+  if (H % 16 != 0)
+    return 2; /* second image starts at row H/2 (:292): the reference over-reads otherwise */
   float qs[64];
   make_qs(lut, qs);
   const size_t plane = (W * H) / 64;

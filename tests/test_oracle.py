@@ -207,3 +207,24 @@ def test_config0_full_size_reference_cpu_path(golden):
         ref = np.zeros(W * H, dtype=np.uint8)
         O.run_behaviour("q32_avx", img, lut, W, 2 * H, 0, 2 * H, out=ref, use_reference=True)
         assert np.array_equal(ref, out)
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """the checker itself is memory-safe: every entry point on exact-size heap buffers under
+    ASan + UBSan (CPU only; GPU sanitizers are not available on the pool)"""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "oracle_asan"
+    src = os.path.join(ROOT, "oracle")
+    r = subprocess.run(["gcc", "-std=c11", "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I" + src,
+                        os.path.join(src, "dct_oracle.c"), os.path.join(src, "sanitize_driver.c"), "-lm", "-o", str(exe)], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in (r.stderr + r.stdout).lower():
+        pytest.skip("sanitizer runtime not installed: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)  # ASan must come first in the library list
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "sanitize ok" in r.stdout, r.stdout + r.stderr
