@@ -110,6 +110,15 @@ int mdct_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch
                  size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
 int mdct_roundtrip_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
                        size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
+/* 8-bit pixels <-> int16 coefficients, the JPEG-style pair (3 algorithmic bytes per pixel):
+ *   fwd: coef = sat_i16(rne(dct(px - (level_shift ? 128 : 0)) / lut[i]))
+ *   inv: px   = clamp(rne(idct(coef * lut[i])) + (level_shift ? 128 : 0), 0, 255)
+ * pitch of the u8 plane in bytes, of the int16 plane in elements; coefficient rows 16-byte
+ * aligned, no alignment requirement on the pixel plane.  lut may be NULL. */
+int mdct_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift,
+                    size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
+int mdct_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift,
+                    size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
 int mdct_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
                  size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
 int mdct_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,

@@ -584,6 +584,53 @@ int orc_roundtrip_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, co
   return 0;
 }
 
+/* 8-bit pixels <-> int16 coefficients (the JPEG-style pair).  level_shift != 0 centres the
+ * pixels on zero (x - 128) on the way in and adds 128 back on the way out; pixels saturate to
+ * [0, 255].  Same AAN arithmetic and tables as the int16 entry points. */
+int orc_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pi, size_t po, const float *lut, int level_shift, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = own_args(from, to, pi, po, W, H, by0, by1);
+  if (e)
+    return e;
+  float qf[64], dq[64];
+  own_tables(lut, qf, dq);
+  FOR_BLOCKS
+  {
+    float blk[64];
+    for (int r = 0; r < 8; r++)
+      for (int c = 0; c < 8; c++)
+        blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c] - (level_shift ? 128.0f : 0.0f);
+    raw_fwd(blk);
+    for (int i = 0; i < 64; i++)
+      AT(i >> 3, i & 7) = sat_i16_rne(blk[i] * qf[i]);
+  }
+  return 0;
+}
+
+int orc_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pi, size_t po, const float *lut, int level_shift, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = own_args(from, to, pi, po, W, H, by0, by1);
+  if (e)
+    return e;
+  float qf[64], dq[64];
+  own_tables(lut, qf, dq);
+  FOR_BLOCKS
+  {
+    float blk[64];
+    LOAD_I16(blk);
+    for (int i = 0; i < 64; i++)
+      blk[i] = blk[i] * dq[i];
+    raw_inv(blk);
+    for (int i = 0; i < 64; i++)
+    {
+      float r = rintf(blk[i]);
+      r = r + (level_shift ? 128.0f : 0.0f); /* exact: integers well below 2^24 */
+      AT(i >> 3, i & 7) = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+    }
+  }
+  return 0;
+}
+
 int orc_fwd_f32(const float *from, float *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);

@@ -16,7 +16,8 @@
  *               orc_encq_scalar        B5  simd_dct.cpp:300-395
  *   UNPINNED ("parity unpinned": the reference has no int16 / float32-out / inverse
  *             path at all; these restate the engine's OWN arithmetic definition):
- *               orc_fwd_i16, orc_inv_i16, orc_roundtrip_i16, orc_fwd_f32, orc_fwd_f64ref
+ *               orc_fwd_i16, orc_inv_i16, orc_roundtrip_i16, orc_fwd_u8_i16, orc_inv_i16_u8,
+ *               orc_fwd_f32, orc_inv_f32, orc_fwd_f64ref
  *
  * All arithmetic is IEEE-754 binary32, one rounding per written operation, no FMA
  * (compile with -ffp-contract=off, never -ffast-math).
@@ -67,6 +68,10 @@ int orc_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_
                 size_t sizeX, size_t sizeY, size_t by0, size_t by1);
 int orc_roundtrip_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
                       size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+int orc_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift,
+                   size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+int orc_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift,
+                   size_t sizeX, size_t sizeY, size_t by0, size_t by1);
 int orc_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
                 size_t sizeX, size_t sizeY, size_t by0, size_t by1);
 int orc_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,

@@ -48,6 +48,8 @@ int main(void)
       if (orc_fwd_i16(i16, o16, W, W, tables[t], W, H, 0, H / 8)) return 30;
       if (orc_inv_i16(i16, o16, W, W, tables[t], W, H, 0, H / 8)) return 31;
       if (orc_roundtrip_i16(i16, o16, W, W, tables[t], W, H, 0, H / 8)) return 32;
+      if (orc_fwd_u8_i16(in, o16, W, W, tables[t], t, W, H, 0, H / 8)) return 33;
+      if (orc_inv_i16_u8(i16, out, W, W, tables[t], t, W, H, 0, H / 8)) return 34;
     }
     if (orc_fwd_f32(f32, of32, W, W, W, H, 0, H / 8)) return 40;
     if (orc_inv_f32(f32, of32, W, W, W, H, 0, H / 8)) return 41;

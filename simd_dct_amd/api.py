@@ -139,6 +139,26 @@ def roundtrip_i16(src, dst, sizeX, sizeY, lut=None, by0=0, by1=None, pitch_in=No
     return _plane(_lib.load().mdct_roundtrip_i16, src, dst, lut, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check)
 
 
+def fwd_u8_i16(src, dst, sizeX, sizeY, lut=None, level_shift=True, by0=0, by1=None, pitch_in=None, pitch_out=None, stream=None, check=True):
+    """8-bit pixels -> int16 coefficients (mdct_fwd_u8_i16)"""
+    keep, lp = _lut_ptr(lut)
+    rc = _lib.load().mdct_fwd_u8_i16(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, sizeX if pitch_out is None else pitch_out, lp, int(bool(level_shift)),
+                                     sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+def inv_i16_u8(src, dst, sizeX, sizeY, lut=None, level_shift=True, by0=0, by1=None, pitch_in=None, pitch_out=None, stream=None, check=True):
+    """int16 coefficients -> 8-bit pixels (mdct_inv_i16_u8)"""
+    keep, lp = _lut_ptr(lut)
+    rc = _lib.load().mdct_inv_i16_u8(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, sizeX if pitch_out is None else pitch_out, lp, int(bool(level_shift)),
+                                     sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
 def _plane_f32(fn, src, dst, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check):
     by1 = sizeY // 8 if by1 is None else by1
     rc = fn(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, sizeX if pitch_out is None else pitch_out, sizeX, sizeY, by0, by1, _stream(stream))

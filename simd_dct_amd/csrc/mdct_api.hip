@@ -178,6 +178,41 @@ int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t 
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "i16 kernel launch");
 }
 
+int run_u8_i16(int mode, const void *from, void *to, uint8_t *px, int16_t *coef, size_t pitch_px, size_t pitch_coef, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+               void *stream)
+{
+  if (from == nullptr || to == nullptr)
+    return fail(MDCT_INVALID_PARAMETER, "null plane pointer");
+  if (sizeX % 8 != 0 || sizeY % 8 != 0)
+    return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu is not a multiple of 8x8", sizeX, sizeY);
+  if (pitch_px < sizeX || pitch_coef < sizeX || by0 > by1 || by1 > sizeY / 8)
+    return fail(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows", by0, by1, sizeY / 8);
+  if (((uintptr_t)coef | (pitch_coef * sizeof(int16_t))) & 15)
+    return fail(MDCT_INVALID_PARAMETER, "coefficient rows must be 16-byte aligned");
+  const mdct_device_info *di;
+  int r = current(&di);
+  if (r)
+    return r;
+  mdct::U8I16Args a;
+  a.px = px;
+  a.coef = coef;
+  a.pitch_px = pitch_px;
+  a.pitch_coef = pitch_coef;
+  a.bpr = (uint32_t)(sizeX / 8);
+  a.by0 = (uint32_t)by0;
+  if ((r = count_blocks(sizeX / 8, by1 - by0, &a.nblocks)))
+    return r;
+  if ((r = make_own_tables(lut, a.tb)))
+    return r;
+  const float shift = level_shift ? 128.0f : 0.0f;
+  a.dc_shift = 64.0f * shift;
+  a.px_lo = 0.0f - shift;           // rne(x) + shift in [0, 255]  <=>  x clamped to [-shift, 255 - shift]
+  a.px_hi = 255.0f - shift;
+  a.px_magic = 12582912.0f + shift; // even, so ties still round to even; low byte = rne(x) + shift
+  const hipError_t e = mdct::launch_u8_i16(a, mode, (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "u8<->i16 kernel launch");
+}
+
 int run_f32(int mode, const float *from, float *to, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
 {
   int r = own_plane_args(from, to, sizeof(float), pitch_in, pitch_out, sizeX, sizeY, by0, by1);
@@ -294,6 +329,16 @@ int mdct_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch
 int mdct_roundtrip_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
 {
   return run_i16(mdct::MODE_ROUNDTRIP, from, to, pitch_in, pitch_out, lut, sizeX, sizeY, by0, by1, stream);
+}
+
+int mdct_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  return run_u8_i16(mdct::MODE_FWD, from, to, const_cast<uint8_t *>(from), to, pitch_in, pitch_out, lut, level_shift, sizeX, sizeY, by0, by1, stream);
+}
+
+int mdct_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  return run_u8_i16(mdct::MODE_INV, from, to, to, const_cast<int16_t *>(from), pitch_out, pitch_in, lut, level_shift, sizeX, sizeY, by0, by1, stream);
 }
 
 int mdct_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)

@@ -84,6 +84,18 @@ struct I16Args
   uint32_t bpr, by0, nblocks;
 };
 
+struct U8I16Args
+{
+  uint8_t *px;    // pixels: input of the forward, output of the inverse
+  int16_t *coef;  // coefficients: output of the forward, input of the inverse
+  OwnTables tb;
+  DctConsts consts;
+  size_t pitch_px, pitch_coef; // bytes / elements
+  uint32_t bpr, by0, nblocks;
+  float dc_shift;              // forward: 64*128 when level-shifting, else 0
+  float px_lo, px_hi, px_magic; // inverse: clamp bounds and rounding constant (shift folded in)
+};
+
 struct F32Args
 {
   const float *from;
@@ -111,6 +123,7 @@ struct PlaneBatchArgs
 hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool safe, hipStream_t s);
 hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s);
 hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s);
+hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s);
 hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s);
 hipError_t launch_stream_copy(const void *from, void *to, size_t bytes, int cus, hipStream_t s);
 

@@ -638,6 +638,73 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
   i16_block<MODE, HAS_LUT>(a.consts, a.from + by * 8 * a.pitch_in + (size_t)bx * 8, a.to + by * 8 * a.pitch_out + (size_t)bx * 8, a.pitch_in, a.pitch_out, a.tb);
 }
 
+// 8-bit pixels <-> int16 coefficients (JPEG-style pair): u8 rows are 8 B per lane (512 B per wave
+// load/store), int16 rows 16 B per lane.  The level shift costs nothing: on the way in it is
+// exactly "raw DC minus 64*128" (all other AAN outputs are differences of exact integer sums, so
+// the offset cancels bit for bit), on the way out it rides in the rounding constant
+// (1.5*2^23 + 128 is even, so ties round as before and the low byte is rne(x) + 128).
+template <int MODE, bool HAS_LUT>
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_u8_i16(U8I16Args a)
+{
+  const uint32_t t = blockIdx.x * kWG + threadIdx.x;
+  if (t >= a.nblocks)
+    return;
+  const uint32_t row = t / a.bpr;
+  const uint32_t bx = t - row * a.bpr;
+  const size_t by = a.by0 + row;
+  const DctConsts &C = a.consts;
+  float b[8][8];
+  if constexpr (MODE == MODE_FWD)
+  {
+    const uint8_t *src = a.px + by * 8 * a.pitch_px + (size_t)bx * 8;
+    int16_t *dst = a.coef + by * 8 * a.pitch_coef + (size_t)bx * 8;
+    uint2 rows[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      rows[r] = load8(src + (size_t)r * a.pitch_px);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      b[r][0] = ubyte_to_float<0>(rows[r].x); b[r][1] = ubyte_to_float<1>(rows[r].x);
+      b[r][2] = ubyte_to_float<2>(rows[r].x); b[r][3] = ubyte_to_float<3>(rows[r].x);
+      b[r][4] = ubyte_to_float<0>(rows[r].y); b[r][5] = ubyte_to_float<1>(rows[r].y);
+      b[r][6] = ubyte_to_float<2>(rows[r].y); b[r][7] = ubyte_to_float<3>(rows[r].y);
+    }
+    raw_fwd(C, b);
+    b[0][0] = b[0][0] - a.dc_shift; // 8192 or 0
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+      b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.tb.qf[i];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      store_i16x8<0>(C, dst + (size_t)r * a.pitch_coef, b[r]);
+  }
+  else
+  {
+    const int16_t *src = a.coef + by * 8 * a.pitch_coef + (size_t)bx * 8;
+    uint8_t *dst = a.px + by * 8 * a.pitch_px + (size_t)bx * 8;
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      unpack_i16x8(ld_stream16(src + (size_t)r * a.pitch_coef), b[r]);
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+      b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.tb.dq[i];
+    raw_inv(C, b);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      uint32_t t8[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) // clamp so that rne(x) + shift lands in [0, 255], then the magic add
+        t8[c] = __float_as_uint(__builtin_amdgcn_fmed3f(b[r][c], a.px_lo, a.px_hi) + a.px_magic);
+      typedef unsigned int u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
+      const u32x2_unaligned w = {pack4_lo8(t8[0], t8[1], t8[2], t8[3]), pack4_lo8(t8[4], t8[5], t8[6], t8[7])};
+      __builtin_nontemporal_store(w, reinterpret_cast<u32x2_unaligned *>(dst + (size_t)r * a.pitch_px));
+    }
+  }
+  (void)HAS_LUT;
+}
+
 // Several planes (each with its own table) in one launch: linear block index over the
 // concatenation of the planes; prefix[] is the exclusive scan of per-plane block counts.
 // LUTMODE: 0 no plane has a table, 1 every plane has one, 2 mixed (branch per wave)
@@ -872,6 +939,17 @@ hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s)
     hipLaunchKernelGGL(k_i16_planes<1>, dim3(grid_for(total)), dim3(kWG), 0, s, a);
   else
     hipLaunchKernelGGL(k_i16_planes<2>, dim3(grid_for(total)), dim3(kWG), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s)
+{
+  if (a.nblocks == 0)
+    return hipSuccess;
+  if (mode == MODE_FWD)
+    hipLaunchKernelGGL((k_u8_i16<MODE_FWD, true>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_u8_i16<MODE_INV, true>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
   return hipGetLastError();
 }
 

@@ -36,6 +36,8 @@ def oracle():
         lib.orc_q32_native.argtypes = [vp, vp, sz, f32p, sz, sz, sz, sz]
         for n in ("orc_fwd_i16", "orc_inv_i16", "orc_roundtrip_i16"):
             getattr(lib, n).argtypes = [vp, vp, sz, sz, f32p, sz, sz, sz, sz]
+        for n in ("orc_fwd_u8_i16", "orc_inv_i16_u8"):
+            getattr(lib, n).argtypes = [vp, vp, sz, sz, f32p, ctypes.c_int, sz, sz, sz, sz]
         for n in ("orc_fwd_f32", "orc_inv_f32", "orc_fwd_f64ref"):
             getattr(lib, n).argtypes = [vp, vp, sz, sz, sz, sz, sz, sz]
         lib.orc_dct8.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_int]
@@ -98,6 +100,23 @@ def i16(mode, src, W, H, lut=None, by0=0, by1=None, out=None):
         keep, lp = _lut(lut)
     fn = getattr(oracle(), {"fwd": "orc_fwd_i16", "inv": "orc_inv_i16", "roundtrip": "orc_roundtrip_i16"}[mode])
     rc = fn(src.ctypes.data, out.ctypes.data, W, W, lp, W, H, by0, H // 8 if by1 is None else by1)
+    assert rc == 0, rc
+    return out
+
+
+def u8_i16(mode, src, W, H, lut=None, level_shift=True):
+    """mode 'fwd': uint8 [H,W] -> int16; 'inv': int16 [H,W] -> uint8"""
+    lp = None
+    if lut is not None:
+        keep, lp = _lut(lut)
+    if mode == "fwd":
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        out = np.zeros((H, W), dtype=np.int16)
+        rc = oracle().orc_fwd_u8_i16(src.ctypes.data, out.ctypes.data, W, W, lp, int(level_shift), W, H, 0, H // 8)
+    else:
+        src = np.ascontiguousarray(src, dtype=np.int16)
+        out = np.zeros((H, W), dtype=np.uint8)
+        rc = oracle().orc_inv_i16_u8(src.ctypes.data, out.ctypes.data, W, W, lp, int(level_shift), W, H, 0, H // 8)
     assert rc == 0, rc
     return out
 

@@ -563,3 +563,47 @@ def test_config0_full_size_hash_of_the_real_reference(golden):
     out.zero_()
     assert M.simdDCT_EncodeQuantizeReorderStereoBuffer(img, out, lut_x(8), W, H, 0, H) == 0
     assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == meta["config0_sha256"]["stereo_sse__photo__8192x8192__x8"]
+
+
+def test_u8_i16_codec_pair_matches_oracle():
+    """8-bit pixels -> int16 coefficients -> 8-bit pixels (JPEG-style pair), with and without a
+    table and level shift, odd pitches and an unaligned pixel plane; bit-exact vs the oracle"""
+    rng = np.random.default_rng(99)
+    for (W, H) in ((8, 8), (72, 24), (512, 64), (1024, 128)):
+        img = synth.plane_u8_np(W, H, "photo", seed=W)
+        for table in (None, JPEG_LUMA):
+            for shift in (True, False):
+                d_img = dev(img)
+                coef = torch.full((H, W), 31000, dtype=torch.int16, device="cuda")
+                M.fwd_u8_i16(d_img, coef, W, H, lut=table, level_shift=shift)
+                want = O.u8_i16("fwd", img, W, H, lut=table, level_shift=shift)
+                assert np.array_equal(coef.cpu().numpy(), want), (W, H, table is not None, shift)
+                back = torch.full((H, W), 7, dtype=torch.uint8, device="cuda")
+                M.inv_i16_u8(coef, back, W, H, lut=table, level_shift=shift)
+                assert np.array_equal(back.cpu().numpy(), O.u8_i16("inv", want, W, H, lut=table, level_shift=shift))
+        # random (not DCT-shaped) coefficients exercise the decoder's saturation
+        wild = rng.integers(-3000, 3000, (H, W), dtype=np.int16)
+        out = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+        M.inv_i16_u8(dev(wild), out, W, H, lut=JPEG_LUMA)
+        assert np.array_equal(out.cpu().numpy(), O.u8_i16("inv", wild, W, H, lut=JPEG_LUMA))
+    # unaligned pixel plane (the coefficient plane must be 16-byte aligned, the pixels need not be)
+    W, H = 256, 32
+    img = synth.plane_u8_np(W, H, "noise")
+    buf = torch.zeros(W * H + 8, dtype=torch.uint8, device="cuda")
+    buf[3:3 + W * H] = dev(img.reshape(-1))
+    coef = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    M.fwd_u8_i16(buf[3:], coef, W, H)
+    assert np.array_equal(coef.cpu().numpy(), O.u8_i16("fwd", img, W, H))
+    # quality: 8192x8192 through JPEG luma quantisation and back stays a picture
+    W = H = 8192
+    big = synth.plane_u8_torch(W, H, "photo")
+    c = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    r = torch.empty_like(big)
+    M.fwd_u8_i16(big, c, W, H, lut=JPEG_LUMA)
+    M.inv_i16_u8(c, r, W, H, lut=JPEG_LUMA)
+    mse = ((r.float() - big.float()) ** 2).mean().item()
+    assert 10 * np.log10(255.0 ** 2 / mse) > 24.0
+    lossless = torch.empty_like(big)
+    M.fwd_u8_i16(big, c, W, H)
+    M.inv_i16_u8(c, lossless, W, H)
+    assert (lossless.int() - big.int()).abs().max().item() <= 2  # integer coefficients cost at most 2 grey levels

@@ -228,3 +228,29 @@ def test_oracle_under_address_and_ub_sanitizers(tmp_path):
     env.pop("LD_PRELOAD", None)  # ASan must come first in the library list
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "sanitize ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_u8_i16_pair_against_double():
+    """8-bit pixels <-> int16 coefficients: forward equals rounding the double-precision DCT of the
+    level-shifted pixels (up to exact .5 ties), inverse of the forward returns the pixels"""
+    W, H = 128, 64
+    img = synth.plane_u8_np(W, H, "photo")
+    for shift in (True, False):
+        coef = O.u8_i16("fwd", img, W, H, level_shift=shift)
+        ref = np.rint(O.f32("f64ref", img.astype(np.float32) - (128.0 if shift else 0.0), W, H))
+        assert np.abs(coef - ref).max() <= 1 and (coef != ref).mean() < 1e-2
+        back = O.u8_i16("inv", coef, W, H, level_shift=shift)
+        assert np.abs(back.astype(np.int32) - img).max() <= 2
+    # the level shift only moves DC, by exactly 8 * 128 = 1024
+    a = O.u8_i16("fwd", img, W, H, level_shift=True).astype(np.int32)
+    b = O.u8_i16("fwd", img, W, H, level_shift=False).astype(np.int32)
+    d = b - a
+    assert (d[::8, ::8] == 1024).all()
+    d[::8, ::8] = 0
+    assert not d.any()
+    # saturation of the decoder: absurd coefficients clamp to [0, 255]
+    wild = np.zeros((8, 8), dtype=np.int16)
+    wild[0, 0] = 32767
+    assert (O.u8_i16("inv", wild, 8, 8) == 255).all()
+    wild[0, 0] = -32768
+    assert (O.u8_i16("inv", wild, 8, 8) == 0).all()
