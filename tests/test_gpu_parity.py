@@ -3,6 +3,8 @@ the same seeded inputs, against the fixtures the real reference produced, and --
 BASELINE.json's full sizes -- through size-independent properties.  Bit-exact everywhere
 (u8 / int16 / float32 are all compared with array_equal); the only tolerance is config 5's
 float32-vs-double bound, stated where it is used."""
+import os
+
 import numpy as np
 import pytest
 
@@ -607,3 +609,50 @@ def test_u8_i16_codec_pair_matches_oracle():
     M.fwd_u8_i16(big, c, W, H)
     M.inv_i16_u8(c, lossless, W, H)
     assert (lossless.int() - big.int()).abs().max().item() <= 2  # integer coefficients cost at most 2 grey levels
+
+
+@pytest.mark.skipif(not os.environ.get("MDCT_SOAK"), reason="opt-in soak: MDCT_SOAK=<cases> python -m pytest tests -m gpu -k soak")
+def test_soak_random_differential():
+    """opt-in long differential run: MDCT_SOAK random cases across every entry point vs the oracle"""
+    n = int(os.environ["MDCT_SOAK"])
+    rng = np.random.default_rng(int(os.environ.get("MDCT_SOAK_SEED", "1")))
+    combos = [("q32_avx", 64), ("stereo_sse", 16), ("stereo_scalar", 16), ("encq_sse", 16), ("encq_scalar", 8)]
+    specials = [0.0, -0.7, 1e-6, 1e-30, np.inf, np.nan, 3e38]
+    for it in range(n):
+        beh, xm = combos[it % len(combos)]
+        W = int(rng.integers(1, 24)) * xm
+        H = int(rng.integers(1, 24)) * 16
+        kind = rng.integers(0, 3)
+        img = rng.integers(0, 256, W * H, dtype=np.uint8) if kind == 0 else (np.full(W * H, rng.integers(0, 256), dtype=np.uint8) if kind == 1 else synth.plane_u8_np(W, H, "photo", seed=it).reshape(-1))
+        lut = (lut_x(float(rng.choice([0.01, 1.0, 8.0, 100.0, 2000.0, 1e5]))) * rng.uniform(0.2, 5.0, 64).astype(np.float32)).astype(np.float32)
+        if it % 7 == 0:
+            lut[rng.integers(0, 64, 5)] = rng.choice(specials)
+        y0 = int(rng.integers(0, H + 16))
+        y1 = int(rng.integers(0, 2 * H + 16))
+        host = bool(it % 3 == 0)
+        rc, got = run_ref_api(beh, img, lut, W, H, y0, y1, host=host)
+        want = np.full(W * H, CANARY, dtype=np.uint8)
+        rc2, want = O.run_behaviour(beh, img, lut, W, H, y0, y1, out=want)
+        assert rc == rc2 == 0, (it, beh, W, H, y0, y1, M.last_error())
+        assert np.array_equal(got, want), (it, beh, W, H, y0, y1, host, int((got != want).sum()))
+        # engine-own
+        W2, H2 = int(rng.integers(1, 60)) * 8, int(rng.integers(1, 30)) * 8
+        src = rng.integers(-32768, 32768, (H2, W2), dtype=np.int16) if it % 4 == 0 else rng.integers(-2048, 2048, (H2, W2), dtype=np.int16)
+        table = None if it % 2 else (lut_x(float(rng.choice([0.5, 10, 200]))) * rng.uniform(0.3, 3, 64).astype(np.float32)).astype(np.float32)
+        for mode, fn in (("fwd", M.fwd_i16), ("inv", M.inv_i16), ("roundtrip", M.roundtrip_i16)):
+            out = torch.empty((H2, W2), dtype=torch.int16, device="cuda")
+            fn(dev(src), out, W2, H2, lut=table)
+            assert np.array_equal(out.cpu().numpy(), O.i16(mode, src, W2, H2, lut=table)), (it, mode, W2, H2)
+        px = rng.integers(0, 256, (H2, W2), dtype=np.uint8)
+        c = torch.empty((H2, W2), dtype=torch.int16, device="cuda")
+        M.fwd_u8_i16(dev(px), c, W2, H2, lut=table, level_shift=bool(it & 1))
+        assert np.array_equal(c.cpu().numpy(), O.u8_i16("fwd", px, W2, H2, lut=table, level_shift=bool(it & 1)))
+        p = torch.empty((H2, W2), dtype=torch.uint8, device="cuda")
+        M.inv_i16_u8(dev(src), p, W2, H2, lut=table, level_shift=bool(it & 1))
+        assert np.array_equal(p.cpu().numpy(), O.u8_i16("inv", src, W2, H2, lut=table, level_shift=bool(it & 1)))
+        f = rng.normal(0, 300, (H2, W2)).astype(np.float32)
+        fo = torch.empty((H2, W2), dtype=torch.float32, device="cuda")
+        M.fwd_f32(dev(f), fo, W2, H2)
+        assert np.array_equal(fo.cpu().numpy(), O.f32("fwd", f, W2, H2))
+        M.inv_f32(dev(f), fo, W2, H2)
+        assert np.array_equal(fo.cpu().numpy(), O.f32("inv", f, W2, H2))

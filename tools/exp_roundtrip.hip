@@ -229,6 +229,15 @@ int main()
   vs.push_back({"multi4 NT prefetch", [&](int s) { hipLaunchKernelGGL((v_multi<true, 4>), dim3(a.nblocks / 256 / 4), dim3(256), 0, 0, args(s)); }, {}});
   vs.push_back({"multi4 plain prefetch", [&](int s) { hipLaunchKernelGGL((v_multi<false, 4>), dim3(a.nblocks / 256 / 4), dim3(256), 0, 0, args(s)); }, {}});
   vs.push_back({"multi8 NT prefetch", [&](int s) { hipLaunchKernelGGL((v_multi<true, 8>), dim3(a.nblocks / 256 / 8), dim3(256), 0, 0, args(s)); }, {}});
+  // occupancy limited by reserving (unused) dynamic LDS: 160 KiB per CU / reservation = workgroups per CU
+  for (int kb : {0, 32, 40, 53, 80})
+  {
+    static char names[5][40];
+    static int idx = 0;
+    snprintf(names[idx], sizeof names[idx], "product RT, %d KiB LDS pad", kb);
+    const char *nm = names[idx++];
+    vs.push_back({nm, [&, kb](int s) { hipLaunchKernelGGL((k_i16<MODE_ROUNDTRIP, false>), dim3(a.nblocks / 256), dim3(256), kb * 1024, 0, args(s)); }, {}});
+  }
   const uint32_t ntiles = a.nblocks / 64;
   vs.push_back({"dma persist 4w x1024WG", [&](int s) { hipLaunchKernelGGL((v_dma<4>), dim3(1024), dim3(256), 0, 0, args(s), ntiles); }, {}});
   vs.push_back({"dma persist 4w x768WG", [&](int s) { hipLaunchKernelGGL((v_dma<4>), dim3(768), dim3(256), 0, 0, args(s), ntiles); }, {}});
