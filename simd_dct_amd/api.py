@@ -222,6 +222,16 @@ def prepare_plane_i16(mode, src, dst, sizeX, sizeY, lut=None, by0=0, by1=None, p
     return Prepared(fn, args, (keep, src, dst))
 
 
+def prepare_u8_i16(mode, src, dst, sizeX, sizeY, lut=None, level_shift=True, stream=None):
+    """mode 'fwd' (uint8 -> int16) or 'inv' (int16 -> uint8): Prepared launch"""
+    lib = _lib.load()
+    fn = lib.mdct_fwd_u8_i16 if mode == "fwd" else lib.mdct_inv_i16_u8
+    keep, lp = _lut_ptr(lut)
+    sz = ctypes.c_size_t
+    args = (ctypes.c_void_p(_ptr(src)), ctypes.c_void_p(_ptr(dst)), sz(sizeX), sz(sizeX), lp, ctypes.c_int(int(bool(level_shift))), sz(sizeX), sz(sizeY), sz(0), sz(sizeY // 8), _stream(stream))
+    return Prepared(fn, args, (keep, src, dst))
+
+
 def prepare_fwd_quant_u8(src, dst, lut, sizeX, sizeY, by0, by1, layout=LAYOUT_Q32, profile=PROFILE_REF_AVX, pitch_in=None, stream=None):
     lib = _lib.load()
     keep, lp = _lut_ptr(lut)

@@ -37,8 +37,8 @@ cases = [
     ("4:2:0 frame roundtrip+tables", 4, frame_px, [M.prepare_roundtrip_i16_planes(frame)]),
     ("f32 fwd", 8, W * H, [lambda i=i: M.fwd_f32(f32[i], of32[i], W, H) for i in range(2)]),
     ("f32 inv", 8, W * H, [lambda i=i: M.inv_f32(f32[i], of32[i], W, H) for i in range(2)]),
-    ("u8 px -> i16 coef (+table)", 3, W * H, [lambda i=i: M.fwd_u8_i16(u8[i].reshape(H, W), o16[i], W, H, lut=jpeg) for i in range(NS)]),
-    ("i16 coef -> u8 px (+table)", 3, W * H, [lambda i=i: M.inv_i16_u8(i16[i], o8[i].reshape(H, W), W, H, lut=jpeg) for i in range(NS)]),
+    ("u8 px -> i16 coef (+table)", 3, W * H, [M.prepare_u8_i16("fwd", u8[i], o16[i], W, H, lut=jpeg) for i in range(NS)]),
+    ("i16 coef -> u8 px (+table)", 3, W * H, [M.prepare_u8_i16("inv", i16[i], o8[i], W, H, lut=jpeg) for i in range(NS)]),
     ("u8 q32 / AVX2 tier", 2, W * H, [Q(u8[i], o8[i], lut2000, W, H, 0, H // 8) for i in range(NS)]),
     ("u8 stereo / SSE tier", 2, W * H, [Q(u8[i], o8[i], lut8, W, H, 0, H // 16, layout=M.LAYOUT_STEREO, profile=M.PROFILE_REF_SSE) for i in range(NS)]),
     ("u8 stereo / scalar tier", 2, W * H, [Q(u8[i], o8[i], lut8, W, H, 0, H // 16, layout=M.LAYOUT_STEREO, profile=M.PROFILE_REF_SCALAR) for i in range(NS)]),
