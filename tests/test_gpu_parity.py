@@ -222,6 +222,12 @@ def test_f32_matches_oracle_and_double():
         back = torch.empty_like(d)
         M.inv_f32(out, back, W, H)
         assert np.array_equal(back.cpu().numpy(), O.f32("inv", got, W, H))
+        if H >= 24:  # a block-row sub-range leaves the other rows alone (both load forms)
+            part = torch.full_like(d, 3.25)
+            M.fwd_f32(d, part, W, H, by0=1, by1=2)
+            wantp = np.full((H, W), 3.25, dtype=np.float32)
+            wantp[8:16] = O.f32("fwd", src, W, H)[8:16]
+            assert np.array_equal(part.cpu().numpy(), wantp)
 
 
 def test_plane_batch_420_one_call():
