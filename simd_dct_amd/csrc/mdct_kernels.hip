@@ -279,14 +279,19 @@ __device__ __forceinline__ float px_to_float(float f)
 // Loads the lane's block, runs both passes in the profile's order and returns the 64
 // quantised bytes as int values q[v][u] (natural index) for the AVX/stereo layouts or
 // q[u][v]-transposed-stored semantics handled by the caller.
-template <int PROFILE, int LAYOUT, bool SAFE>
-__device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *src, size_t pitch, const QuantTable &qt, const float *px_div255, uint32_t (&out)[64])
+// the lane's block as eight 8-byte rows, all eight loads in flight together
+__device__ __forceinline__ void load_block_rows(const uint8_t *src, size_t pitch, uint2 (&rows)[8])
 {
-  uint2 rows[8];
 #pragma unroll
-  for (int r = 0; r < 8; r++) // all eight loads in flight before the first convert
+  for (int r = 0; r < 8; r++)
     rows[r] = load8(src + (size_t)r * pitch);
-  float b[8][8];
+}
+
+// convert (consumes `rows`), both passes in the profile's order, quantise: out[s] = word whose low
+// byte is the coefficient at stored index s
+template <int PROFILE, int LAYOUT, bool SAFE>
+__device__ __forceinline__ void encode_rows(const DctConsts &C, const uint2 (&rows)[8], const QuantTable &qt, const float *px_div255, float (&b)[8][8])
+{
 #pragma unroll
   for (int r = 0; r < 8; r++)
   {
@@ -315,6 +320,12 @@ __device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *
     }
   }
 
+  (void)C; (void)qt;
+}
+
+template <int PROFILE, int LAYOUT, bool SAFE>
+__device__ __forceinline__ void transform_quantise(const DctConsts &C, float (&b)[8][8], const QuantTable &qt, uint32_t (&out)[64])
+{
   constexpr int K = PROFILE == MDCT_PROFILE_REF_AVX ? K_AVX : (PROFILE == MDCT_PROFILE_REF_SSE ? K_SSE : K_TRUE);
   // STEREO tiers transpose first (T, rows, T, rows == columns then rows, :961-1004, :225-241);
   // Q32 and the encq tiers run rows then columns (:2158/:2189, :347-358, :1608-1636).
@@ -343,6 +354,16 @@ __device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *
     else
       out[s] = quant_scalar(f, qt.q[s], C.magic23);
   }
+}
+
+template <int PROFILE, int LAYOUT, bool SAFE>
+__device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *src, size_t pitch, const QuantTable &qt, const float *px_div255, uint32_t (&out)[64])
+{
+  uint2 rows[8];
+  load_block_rows(src, pitch, rows);
+  float b[8][8];
+  encode_rows<PROFILE, LAYOUT, SAFE>(C, rows, qt, px_div255, b);
+  transform_quantise<PROFILE, LAYOUT, SAFE>(C, b, qt, out);
 }
 
 // four low bytes -> one dword, upper bits of the inputs ignored (3 x v_perm_b32)

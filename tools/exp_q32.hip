@@ -54,6 +54,59 @@ __global__ __launch_bounds__(256, 6) void v_compute(U8Args a)
   *reinterpret_cast<uint4 *>(a.to + (size_t)t * 64) = acc;
 }
 
+// persistent waves, register prefetch: the raw bytes of tile i are dead after the converts, so the
+// loads of tile i+1 reuse those 16 VGPRs and are in flight during the butterflies of tile i.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void v_pipe(U8Args a, uint32_t ntiles)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4][64 * kQ32RowStride];
+  const uint32_t lane = threadIdx.x & 63;
+  uint8_t *wl = lds[threadIdx.x >> 6];
+  const uint32_t total_waves = gridDim.x * 4;
+  uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  auto src_of = [&](uint32_t tl) {
+    const uint32_t t = tl * 64 + lane;
+    const uint32_t row = t / a.bpr, bx = t - row * a.bpr;
+    return a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)bx * 8;
+  };
+  uint2 rows[8];
+  load_block_rows(src_of(tile), a.pitch, rows);
+  for (;;)
+  {
+    float b[8][8];
+    encode_rows<MDCT_PROFILE_REF_AVX, MDCT_LAYOUT_Q32, false>(a.consts, rows, a.qt, nullptr, b);
+    const uint32_t next = tile + total_waves;
+    const bool more = next < ntiles;
+    if (more)
+      load_block_rows(src_of(next), a.pitch, rows);
+    uint32_t q[64];
+    transform_quantise<MDCT_PROFILE_REF_AVX, MDCT_LAYOUT_Q32, false>(a.consts, b, a.qt, q);
+#pragma unroll
+    for (int c = 0; c < 64; c++)
+      wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint8_t *outw = a.to + ((size_t)a.by0 * a.bpr + (size_t)tile * 64) * 64;
+    const uint32_t c2 = (lane & 31) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const uint32_t g = 2 * k + (lane >> 5);
+      const uint2 lo = *reinterpret_cast<const uint2 *>(wl + c2 * kQ32RowStride + g * 8);
+      const uint2 hi = *reinterpret_cast<const uint2 *>(wl + (c2 + 1) * kQ32RowStride + g * 8);
+      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+      const u32x4_t v = {lo.x, lo.y, hi.x, hi.y};
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(outw + g * 512 + c2 * 8));
+    }
+    if (!more) break;
+    // the next iteration's LDS writes must not overtake this iteration's LDS reads (same wave:
+    // LDS operations of one wave execute in order)
+    tile = next;
+  }
+}
+
 int main()
 {
   const size_t W = 8192, H = 8192, bytes = W * H;
@@ -82,6 +135,26 @@ int main()
   vs.push_back({"compute x3 +lds", [&](int s) { hipLaunchKernelGGL((v_compute<3, true>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
   vs.push_back({"compute x1 nolds", [&](int s) { hipLaunchKernelGGL((v_compute<1, false>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
   vs.push_back({"compute x3 nolds", [&](int s) { hipLaunchKernelGGL((v_compute<3, false>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
+  const uint32_t ntiles = a.nblocks / 64;
+  vs.push_back({"pipe 6w grid 1536", [&](int s) { hipLaunchKernelGGL((v_pipe<6>), dim3(1536), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  vs.push_back({"pipe 6w grid 1024", [&](int s) { hipLaunchKernelGGL((v_pipe<6>), dim3(1024), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  vs.push_back({"pipe 6w grid 2048", [&](int s) { hipLaunchKernelGGL((v_pipe<6>), dim3(2048), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  vs.push_back({"pipe 5w grid 1280", [&](int s) { hipLaunchKernelGGL((v_pipe<5>), dim3(1280), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  vs.push_back({"pipe 4w grid 1024", [&](int s) { hipLaunchKernelGGL((v_pipe<4>), dim3(1024), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  vs.push_back({"pipe 6w grid 4096 (1 tile)", [&](int s) { hipLaunchKernelGGL((v_pipe<6>), dim3(4096), dim3(256), 0, 0, args(s), ntiles); }, {}});
+  // correctness of the pipelined variants against the product kernel
+  {
+    std::vector<uint8_t> ref(bytes), got(bytes);
+    vs[0].f(0); hipMemcpy(ref.data(), B[0], bytes, hipMemcpyDeviceToHost);
+    for (size_t k = 5; k < vs.size(); k++)
+    {
+      hipMemset(B[0], 0x55, bytes);
+      vs[k].f(0); hipMemcpy(got.data(), B[0], bytes, hipMemcpyDeviceToHost);
+      size_t bad = 0;
+      for (size_t i = 0; i < bytes; i++) bad += got[i] != ref[i];
+      if (bad) printf("!! %s: %zu mismatching bytes\n", vs[k].name, bad);
+    }
+  }
   for (auto &v : vs) for (int i = 0; i < 300; i++) v.f(i % NS);
   hipDeviceSynchronize();
   for (int round = 0; round < 7; round++)
