@@ -662,3 +662,27 @@ def test_soak_random_differential():
         assert np.array_equal(fo.cpu().numpy(), O.f32("fwd", f, W2, H2))
         M.inv_f32(dev(f), fo, W2, H2)
         assert np.array_equal(fo.cpu().numpy(), O.f32("inv", f, W2, H2))
+
+
+RELINKED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "simd_dct_relinked")
+
+
+@pytest.mark.skipif(not os.path.exists(RELINKED), reason="oracle/_ref/simd_dct_relinked not built (make -C oracle relink, needs /root/reference)")
+def test_reference_harness_relinked_against_the_engine(tmp_path):
+    """the drop-in claim at link level: the reference's OWN main.cpp (unchanged, compiled from where
+    it lies by oracle/Makefile) linked against libmdct_hip.so instead of the reference's
+    simd_dct.cpp, run with its own command line; its --to dump must be the oracle's bytes"""
+    import subprocess
+
+    W, H = 512, 256
+    img = synth.plane_u8_np(W, H, "photo")
+    raw = tmp_path / "in.raw"
+    img.tofile(raw)
+    for mode, beh, scale, written in (("enc-quant32", "q32_avx", 2000, W * H // 2), ("enc-quant-stereo", "stereo_sse", 8, W * H)):
+        dump = tmp_path / f"{mode}.bin"
+        r = subprocess.run([RELINKED, str(raw), str(W), str(H), "--mode", mode, "--quality", str(scale), "--runs", "2", "--to", str(dump)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = np.fromfile(dump, dtype=np.uint8)
+        rc, want = O.run_behaviour(beh, img, lut_x(scale), W, H, 0, H)
+        # the harness malloc()s its output buffer: only the bytes the function writes are defined
+        assert np.array_equal(got[:written], want[:written]), mode
