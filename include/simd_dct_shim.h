@@ -55,6 +55,11 @@ void mdct_shim_set_stream(void *stream);
 void mdct_shim_set_async(int enabled);
 /* frees the calling thread's staging buffers */
 void mdct_shim_release(void);
+/* Optional: page-lock a caller-owned host buffer that is reused across calls (hipHostRegister).
+ * Host-pointer calls then DMA to/from it in place instead of bouncing through the shim's pinned
+ * buffers with memcpy.  Unpin before freeing it.  Returns 0 / 1 / 2 like every entry point. */
+int mdct_shim_pin(void *p, size_t bytes);
+int mdct_shim_unpin(void *p);
 /* C-linkage handle onto the three C++-linkage functions above for FFI callers that cannot
  * spell mangled names (ctypes, cgo, JNI).  which: 0 = ...32ReorderBuffer (simd_dct.h:31),
  * 1 = ...ReorderStereoBuffer (simd_dct.h:30), 2 = ...EncodeQuantizeBuffer (simd_dct.h:29).

@@ -93,16 +93,23 @@ bool reserve(uint8_t *&p, size_t &cap, size_t need)
   return true;
 }
 
-bool is_device_ptr(const void *p)
+enum PtrKind { PTR_PAGEABLE, PTR_PINNED, PTR_DEVICE };
+
+PtrKind classify(const void *p)
 {
   hipPointerAttribute_t attr;
   if (hipPointerGetAttributes(&attr, p) != hipSuccess)
   {
     (void)hipGetLastError(); // plain malloc memory on older runtimes
-    return false;
+    return PTR_PAGEABLE;
   }
-  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+  if (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged)
+    return PTR_DEVICE;
+  // hipHostMalloc'ed or hipHostRegister'ed (mdct_shim_pin): DMA-able in place, no bounce buffer
+  return attr.type == hipMemoryTypeHost ? PTR_PINNED : PTR_PAGEABLE;
 }
+
+bool is_device_ptr(const void *p) { return classify(p) == PTR_DEVICE; }
 
 size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 
@@ -153,6 +160,7 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
   // only by plain memcpy to/from pinned bounce buffers.
   if (!dev_in && !dev_out && !scattered)
   {
+    const bool pinned_in = classify(pFrom) == PTR_PINNED, pinned_out = classify(pTo) == PTR_PINNED;
     const size_t strip = 8 * sizeX; // bytes per block row, input and output alike
     size_t rows_per_chunk = ((size_t)4 << 20) / strip;
     rows_per_chunk = rows_per_chunk < 1 ? 1 : rows_per_chunk;
@@ -165,7 +173,8 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
         const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
         if (hipStreamSynchronize(st.stream[sl]) != hipSuccess)
           return false;
-        memcpy(pTo + r0 * strip, st.pin_out[sl], (r1 - r0) * strip);
+        if (!pinned_out)
+          memcpy(pTo + r0 * strip, st.pin_out[sl], (r1 - r0) * strip);
         return true;
       };
       for (size_t c = 0; c < nchunks && r == MDCT_SUCCESS; c++)
@@ -175,11 +184,16 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
           return sdr_NotSupported;
         const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
         const size_t off = r0 * strip, len = (r1 - r0) * strip;
-        memcpy(st.pin_in[sl], pFrom + off, len);
-        if (hipMemcpyAsync(st.in + off, st.pin_in[sl], len, hipMemcpyHostToDevice, st.stream[sl]) != hipSuccess)
+        const uint8_t *h_in = pFrom + off; // pinned caller memory is DMA'd in place
+        if (!pinned_in)
+        {
+          memcpy(st.pin_in[sl], pFrom + off, len);
+          h_in = st.pin_in[sl];
+        }
+        if (hipMemcpyAsync(st.in + off, h_in, len, hipMemcpyHostToDevice, st.stream[sl]) != hipSuccess)
           return sdr_NotSupported;
         r = mdct_fwd_quant_u8(st.in, st.out, sizeX, lut, sizeX, sizeY, r0, r1, layout, profile, st.stream[sl]);
-        if (r == MDCT_SUCCESS && hipMemcpyAsync(st.pin_out[sl], st.out + off, len, hipMemcpyDeviceToHost, st.stream[sl]) != hipSuccess)
+        if (r == MDCT_SUCCESS && hipMemcpyAsync(pinned_out ? pTo + off : st.pin_out[sl], st.out + off, len, hipMemcpyDeviceToHost, st.stream[sl]) != hipSuccess)
           return sdr_NotSupported;
       }
       for (size_t c = nchunks >= 2 ? nchunks - 2 : 0; c < nchunks; c++)
@@ -282,6 +296,30 @@ void mdct_shim_set_max_simd(int level) { g_max_simd.store(level < 0 ? 0 : (level
 void mdct_shim_set_stream(void *stream) { g_stream.store(stream); }
 void mdct_shim_set_async(int enabled) { g_async.store(enabled != 0); }
 void mdct_shim_release(void) { release(tl_stage); }
+
+int mdct_shim_pin(void *p, size_t bytes)
+{
+  if (p == nullptr || bytes == 0)
+    return MDCT_INVALID_PARAMETER;
+  if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return MDCT_NOT_SUPPORTED;
+  }
+  return MDCT_SUCCESS;
+}
+
+int mdct_shim_unpin(void *p)
+{
+  if (p == nullptr)
+    return MDCT_INVALID_PARAMETER;
+  if (hipHostUnregister(p) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    return MDCT_NOT_SUPPORTED;
+  }
+  return MDCT_SUCCESS;
+}
 
 // C handles onto the C++-linkage functions above, for FFI callers (ctypes / cgo / JNI)
 // that cannot spell Itanium-mangled names.  which: 0 q32, 1 stereo, 2 encq.

@@ -686,3 +686,27 @@ def test_reference_harness_relinked_against_the_engine(tmp_path):
         rc, want = O.run_behaviour(beh, img, lut_x(scale), W, H, 0, H)
         # the harness malloc()s its output buffer: only the bytes the function writes are defined
         assert np.array_equal(got[:written], want[:written]), mode
+
+
+def test_shim_pinned_host_buffers_dma_in_place():
+    """mdct_shim_pin: page-locked caller buffers are DMA'd in place by the host-pointer pipeline
+    (no bounce memcpy); results unchanged, pin/unpin status codes"""
+    from simd_dct_amd import _lib
+
+    lib = _lib.load()
+    W, H = 4096, 1024
+    img = np.ascontiguousarray(synth.plane_u8_np(W, H, "photo").reshape(-1))
+    out = np.full(W * H, CANARY, dtype=np.uint8)
+    lut = lut_x(2000)
+    assert lib.mdct_shim_pin(img.ctypes.data, img.nbytes) == 0
+    assert lib.mdct_shim_pin(out.ctypes.data, out.nbytes) == 0
+    try:
+        assert M.simdDCT_EncodeQuantize32ReorderBuffer(img, out, lut, W, H, 0, H) == 0
+        want = np.full(W * H, CANARY, dtype=np.uint8)
+        O.run_behaviour("q32_avx", img, lut, W, H, 0, H, out=want)
+        assert np.array_equal(out, want)
+    finally:
+        assert lib.mdct_shim_unpin(img.ctypes.data) == 0
+        assert lib.mdct_shim_unpin(out.ctypes.data) == 0
+    assert lib.mdct_shim_unpin(out.ctypes.data) == 2  # not registered any more
+    assert lib.mdct_shim_pin(None, 16) == 1

@@ -100,6 +100,7 @@ int main(int argc, char **argv)
     puts("\t--max-simd <avx2 / sse41 / ssse3 / sse2 / none>\tReference tier to reproduce.");
     puts("\t--mode <enc-quant / enc-quant32 / enc-quant-stereo>\tOnly execute a specified mode (repeatable).");
     puts("\t--resident\t\t\tKeep input and output in HBM (device pointers through the same API).");
+    puts("\t--pin\t\t\t\tPage-lock the host buffers once (mdct_shim_pin): host-pointer calls then DMA in place.");
     puts("\t--device <n>\t\t\tHIP device ordinal.");
     return 1;
   }
@@ -113,7 +114,7 @@ int main(int argc, char **argv)
   const char *out_file = nullptr;
   size_t runs = 128; // main.cpp:21
   float quality = 1.0f;
-  bool resident = false;
+  bool resident = false, pin = false;
   int device = 0, max_simd = 2;
   bool m_encq = false, m_q32 = false, m_stereo = false;
   for (int i = 4; i < argc; i++)
@@ -124,6 +125,7 @@ int main(int argc, char **argv)
     else if (a == "--quality") quality = (float)strtoull(next(), nullptr, 10); // main.cpp:214
     else if (a == "--runs") runs = strtoull(next(), nullptr, 10);
     else if (a == "--resident") resident = true;
+    else if (a == "--pin") pin = true;
     else if (a == "--device") device = atoi(next());
     else if (a == "--mode")
     {
@@ -181,6 +183,11 @@ int main(int argc, char **argv)
   printf("File: '%s' (%" PRIu64 " Bytes)\nDevice: '%s' (%d CUs, wave%d, %.0f GB HBM) via %s pointers, reference tier <= %s\n", filename.c_str(), (uint64_t)fileSize, di.name, di.compute_units,
          di.wavefront_size, di.hbm_bytes / 1e9, resident ? "device" : "host", max_simd == 2 ? "AVX2" : (max_simd == 1 ? "SSE" : "scalar"));
 
+  if (pin && !resident && (mdct_shim_pin(in.data(), fileSize) != 0 || mdct_shim_pin(out.data(), fileSize) != 0))
+  {
+    puts("mdct_shim_pin failed.");
+    return 2;
+  }
   uint8_t *d_in = nullptr, *d_out = nullptr;
   const uint8_t *p_in = in.data();
   uint8_t *p_out = out.data();
@@ -250,6 +257,11 @@ int main(int argc, char **argv)
   {
     (void)hipFree(d_in);
     (void)hipFree(d_out);
+  }
+  if (pin && !resident)
+  {
+    mdct_shim_unpin(in.data());
+    mdct_shim_unpin(out.data());
   }
   mdct_shim_release();
   return rc_all;
