@@ -223,7 +223,9 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
   {
     if (!reserve(st.out, st.out_cap, total))
       return sdr_NotSupported;
-    if (scattered && hipMemcpyAsync(st.out, pTo, total, hipMemcpyHostToDevice, hs) != hipSuccess)
+    // STEREO over its whole range writes every byte of every coefficient plane: nothing to preserve
+    const bool writes_everything = layout == MDCT_LAYOUT_STEREO && b0 == 0 && b1 == sizeY / 16;
+    if (scattered && !writes_everything && hipMemcpyAsync(st.out, pTo, total, hipMemcpyHostToDevice, hs) != hipSuccess)
       return sdr_NotSupported;
     d_out = st.out;
   }
