@@ -54,6 +54,47 @@ __global__ __launch_bounds__(256, 6) void v_compute(U8Args a)
   *reinterpret_cast<uint4 *>(a.to + (size_t)t * 64) = acc;
 }
 
+// Staggered start: the first resident generation of waves all issue their loads at t = 0 and then
+// all compute together, and the convoy persists (every later wave starts when its predecessor
+// ends).  Delay first-generation wave k of each SIMD by k x (one wave's compute time) so that the
+// SIMD always has one wave computing while the others load.
+template <int STEP>
+__global__ __launch_bounds__(256, 6) void v_stagger(U8Args a, uint32_t first_gen_blocks)
+{
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  if (__builtin_amdgcn_readfirstlane(t) < first_gen_blocks)
+  {
+    const uint32_t wid = __builtin_amdgcn_s_getreg(0x1804) & 15; // HW_REG_HW_ID[3:0]: wave slot within the SIMD
+    for (uint32_t k = 0; k < wid; k++)
+      __builtin_amdgcn_s_sleep(STEP);
+  }
+  const uint32_t row = t / a.bpr, bx = t - row * a.bpr;
+  const uint8_t *src = a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)bx * 8;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4][64 * kQ32RowStride];
+  uint8_t *wl = lds[threadIdx.x >> 6];
+  uint32_t q[64];
+  encode_block<MDCT_PROFILE_REF_AVX, MDCT_LAYOUT_Q32, false>(a.consts, src, a.pitch, a.qt, nullptr, q);
+#pragma unroll
+  for (int c = 0; c < 64; c++)
+    wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint8_t *outw = a.to + ((size_t)a.by0 * a.bpr + (t - lane)) * 64;
+  const uint32_t c2 = (lane & 31) * 2;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const uint32_t g = 2 * k + (lane >> 5);
+    const uint2 lo = *reinterpret_cast<const uint2 *>(wl + c2 * kQ32RowStride + g * 8);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(wl + (c2 + 1) * kQ32RowStride + g * 8);
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t v = {lo.x, lo.y, hi.x, hi.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(outw + g * 512 + c2 * 8));
+  }
+}
+
 // persistent waves, register prefetch: the raw bytes of tile i are dead after the converts, so the
 // loads of tile i+1 reuse those 16 VGPRs and are in flight during the butterflies of tile i.
 template <int MINW>
@@ -136,6 +177,12 @@ int main()
   vs.push_back({"compute x1 nolds", [&](int s) { hipLaunchKernelGGL((v_compute<1, false>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
   vs.push_back({"compute x3 nolds", [&](int s) { hipLaunchKernelGGL((v_compute<3, false>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s)); }, {}});
   const uint32_t ntiles = a.nblocks / 64;
+  const uint32_t fg = 6 * 1024 * 64; // first resident generation: 6 waves x 1024 SIMDs x 64 blocks
+  vs.push_back({"stagger step 0 (control)", [&](int s) { hipLaunchKernelGGL((v_stagger<0>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s), 0u); }, {}});
+  vs.push_back({"stagger 12 x64 cyc/slot", [&](int s) { hipLaunchKernelGGL((v_stagger<12>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s), fg); }, {}});
+  vs.push_back({"stagger 25 x64 cyc/slot", [&](int s) { hipLaunchKernelGGL((v_stagger<25>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s), fg); }, {}});
+  vs.push_back({"stagger 47 x64 cyc/slot", [&](int s) { hipLaunchKernelGGL((v_stagger<47>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s), fg); }, {}});
+  vs.push_back({"stagger 80 x64 cyc/slot", [&](int s) { hipLaunchKernelGGL((v_stagger<80>), dim3(a.nblocks / 256), dim3(256), 0, 0, args(s), fg); }, {}});
   vs.push_back({"pipe 6w grid 1536", [&](int s) { hipLaunchKernelGGL((v_pipe<6>), dim3(1536), dim3(256), 0, 0, args(s), ntiles); }, {}});
   vs.push_back({"pipe 6w grid 1024", [&](int s) { hipLaunchKernelGGL((v_pipe<6>), dim3(1024), dim3(256), 0, 0, args(s), ntiles); }, {}});
   vs.push_back({"pipe 6w grid 2048", [&](int s) { hipLaunchKernelGGL((v_pipe<6>), dim3(2048), dim3(256), 0, 0, args(s), ntiles); }, {}});
