@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL (default).  gloo only rehearses the multi-rank control flow on a box with fewer GPUs than ranks.")
     args = ap.parse_args()
 
     import numpy as np
@@ -123,12 +125,16 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
     dist = None
+    local = local % max(1, torch.cuda.device_count())  # rehearsal: more ranks than GPUs share a device
     torch.cuda.set_device(local)
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run, also for one rank (exercises RCCL)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     M.init(local)
     info = M.device_info()
     t_start = time.perf_counter()
@@ -186,7 +192,7 @@ def main():
     wall = time.perf_counter() - t0
     kernel_ms = timer.elapsed_ms() / args.steps  # HIP events on the launch stream, avg per launch
     if dist is not None:
-        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, kernel_ms = t.tolist()
 
@@ -255,7 +261,7 @@ def main():
             extras["roundtrip_8_planes_one_launch"] = {"error": str(e)[:120]}
 
     log("extras done")
-    if dist is not None and not args.no_extras:
+    if dist is not None and not args.no_extras and args.backend == "nccl":
         # north_star's whole-node run: every plane's block rows are sharded over the ranks, each rank
         # transforms its shard (forward int16) and the coefficients are all-gathered over xGMI, in
         # place (shards are contiguous slabs in rank order).  Three figures over the same NP planes:
