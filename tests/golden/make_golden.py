@@ -22,12 +22,18 @@ from simd_dct_amd.api import QUANTIZE_BASE  # noqa: E402
 
 W, H = 128, 64
 CANARY = 0xA5
+# tiers of one family write identical bytes under the pinned flags; the fixtures hold the first one's
+FAMILY = {"q32_avx": ("q32_avx2", "q32_avx512vl"), "stereo_sse": ("stereo_sse41", "stereo_ssse3", "stereo_sse2"), "encq_sse": ("encq_sse41", "encq_ssse3"),
+          "stereo_scalar": ("stereo_scalar",), "encq_scalar": ("encq_scalar",)}
+PUBLIC = {"q32_avx": 0, "stereo_sse": 1, "encq_sse": 2}  # what the dispatchers pick on an AVX2 host
 
 
 def main():
     assert O.reference() is not None, "build oracle/_ref first: make -C oracle ref"
     vec = {}
     meta = {"W": W, "H": H, "canary": CANARY, "cases": []}
+    flags = O.host_cpu_flags()
+    verified = set()
     inputs = {"noise": synth.plane_u8_np(W, H, "noise"), "photo": synth.plane_u8_np(W, H, "photo")}
     for k, v in inputs.items():
         vec[f"in_{k}"] = v
@@ -42,6 +48,16 @@ def main():
                     O.run_behaviour(beh, img, lut, W, H, y0, y1, out=out, use_reference=True)
                     key = f"{beh}__{kind}__x{sc:g}__{y0}_{y1}"
                     vec[key] = out
+                    # the other tiers of the same family, and the public dispatcher after _DetectCPUFeatures(),
+                    # must have written the same bytes (simd_dct.cpp:1869, :1106, :1330, :1707, :71-133)
+                    for tier in FAMILY[beh]:
+                        if O.REF_TIERS[tier][1] is None or O.REF_TIERS[tier][1] in flags:
+                            assert np.array_equal(O.run_tier(tier, img, lut, W, H, y0, y1, out=np.full(W * H, CANARY, dtype=np.uint8)), out), (tier, key)
+                            verified.add(tier)
+                    if beh in PUBLIC:
+                        rc, pub = O.run_public(PUBLIC[beh], img, lut, W, H, y0, y1, out=np.full(W * H, CANARY, dtype=np.uint8))
+                        assert rc == 0 and np.array_equal(pub, out), ("public", key)
+                        verified.add(f"public:{beh}")
                     meta["cases"].append({"key": key, "behaviour": beh, "input": kind, "scale": sc, "startY": y0, "endY": y1})
     # q32 over the full plane through the sizeY = 2H call trick; the
     # buffers are W*H, the reference is told 2H rows.
@@ -76,6 +92,7 @@ def main():
     rc, out = O.run_behaviour("stereo_sse", img, lut8, W0, H0, 0, H0, use_reference=True)
     cfg0["stereo_sse__photo__8192x8192__x8"] = hashlib.sha256(out.tobytes()).hexdigest()
     meta["config0_sha256"] = cfg0
+    meta["tiers_verified_identical_to_the_fixtures"] = sorted(verified)
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **vec)
     with open(os.path.join(HERE, "ref_vectors.json"), "w") as f:
         json.dump(meta, f, indent=1)

@@ -53,8 +53,50 @@ def reference():
         lib = ctypes.CDLL(REF_SO)
         lib.ref_call_tier.argtypes = [ctypes.c_int, vp, vp, f32p, sz, sz, sz, sz]
         lib.ref_call_public.argtypes = [ctypes.c_int, vp, vp, f32p, sz, sz, sz, sz]
+        lib.ref_detect_cpu.argtypes = []
+        lib.ref_detect_cpu.restype = None
         _ref = lib
     return _ref
+
+
+# every tier function the reference exports (oracle/ref_driver.cpp ids) -> the x86 feature it needs
+REF_TIERS = {
+    "q32_avx2": (0, "avx2"), "q32_avx512vl": (1, "avx512vl"),
+    "stereo_sse41": (2, "sse4_1"), "stereo_ssse3": (3, "ssse3"), "stereo_sse2": (4, "sse2"), "stereo_scalar": (5, None),
+    "encq_sse41": (6, "sse4_1"), "encq_ssse3": (7, "ssse3"), "encq_scalar": (8, None),
+}
+
+
+def host_cpu_flags():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return set(line.split(":", 1)[1].split())
+    except OSError:
+        pass
+    return set()
+
+
+def run_tier(tier, img, lut, W, H, y0, y1, out=None):
+    """the real reference's tier function `tier` (a REF_TIERS key), called directly"""
+    img = np.ascontiguousarray(img, dtype=np.uint8).reshape(-1)
+    out = np.zeros(W * H, dtype=np.uint8) if out is None else out
+    keep, lp = _lut(lut)
+    rc = reference().ref_call_tier(REF_TIERS[tier][0], img.ctypes.data, out.ctypes.data, lp, W, H, y0, y1)
+    assert rc == 0, rc
+    return out
+
+
+def run_public(which, img, lut, W, H, y0, y1, out=None, detect=True):
+    """the real reference's PUBLIC dispatcher (0 q32, 1 stereo, 2 encq; simd_dct.cpp:71-133), after the
+    caller-side _DetectCPUFeatures() main.cpp:449 performs.  Returns (simdDctResult, out)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8).reshape(-1)
+    out = np.zeros(W * H, dtype=np.uint8) if out is None else out
+    keep, lp = _lut(lut)
+    if detect:
+        reference().ref_detect_cpu()
+    rc = reference().ref_call_public(which, img.ctypes.data, out.ctypes.data, lp, W, H, y0, y1)
+    return rc, out
 
 
 def _lut(lut):

@@ -97,6 +97,45 @@ def test_oracle_equals_real_reference_extreme_tables():
             assert np.array_equal(a, b), (beh, special)
 
 
+@pytest.mark.skipif(O.reference() is None, reason="oracle/_ref not built (needs /root/reference)")
+def test_every_reference_tier_and_public_dispatcher_is_pinned():
+    """The tiers nobody calls by default -- q32 AVX-512VL (simd_dct.cpp:1869-2059), stereo SSSE3 / SSE2
+    (:1330-1536, :1106-1327), encq SSSE3 (:1707-1864) -- equal the pinned tier of their family byte for
+    byte, and the three PUBLIC dispatchers (:71-133) after _DetectCPUFeatures() pick exactly those."""
+    flags = O.host_cpu_flags()
+    rng = np.random.default_rng(20261003)
+    same = {"q32_avx512vl": ("q32_avx2", "q32_avx"), "stereo_ssse3": ("stereo_sse41", "stereo_sse"), "stereo_sse2": ("stereo_sse41", "stereo_sse"),
+            "encq_ssse3": ("encq_sse41", "encq_sse")}
+    ran = 0
+    for (W, H) in ((64, 16), (192, 48), (256, 64)):
+        for scale in (1.0, 8.0, 2000.0):
+            img = rng.integers(0, 256, W * H, dtype=np.uint8)
+            lut = (QUANTIZE_BASE * np.float32(scale) * rng.uniform(0.5, 2.0, 64).astype(np.float32)).astype(np.float32)
+            for (y0, y1) in ((0, H), (16, 32), (8, H // 2)):
+                for tier, (pinned, beh) in same.items():
+                    if O.REF_TIERS[tier][1] not in flags:
+                        continue
+                    a = O.run_tier(tier, img, lut, W, H, y0, y1, out=np.full(W * H, 0x5A, dtype=np.uint8))
+                    b = O.run_tier(pinned, img, lut, W, H, y0, y1, out=np.full(W * H, 0x5A, dtype=np.uint8))
+                    c = np.full(W * H, 0x5A, dtype=np.uint8)
+                    O.run_behaviour(beh, img, lut, W, H, y0, y1, out=c)  # the restatement
+                    assert np.array_equal(a, b) and np.array_equal(a, c), (tier, W, H, scale, y0, y1)
+                    ran += 1
+                # public entry points after feature detection: q32 -> AVX-512VL/AVX2, stereo -> SSE4.1, encq -> SSE4.1
+                if "avx2" in flags and "sse4_1" in flags:
+                    for which, beh in ((0, "q32_avx"), (1, "stereo_sse"), (2, "encq_sse")):
+                        rc, a = O.run_public(which, img, lut, W, H, y0, y1, out=np.full(W * H, 0x5A, dtype=np.uint8))
+                        c = np.full(W * H, 0x5A, dtype=np.uint8)
+                        O.run_behaviour(beh, img, lut, W, H, y0, y1, out=c)
+                        assert rc == 0 and np.array_equal(a, c), ("public", which, W, H, scale, y0, y1)
+    assert ran > 0
+    # dispatcher status codes (simd_dct.cpp:75-76, :117-118): null -> 1, bad shape -> 2
+    img = np.zeros(64 * 16, dtype=np.uint8)
+    assert O.run_public(0, img, QUANTIZE_BASE, 56, 16, 0, 16)[0] == 2
+    assert O.run_public(1, img, QUANTIZE_BASE, 60, 16, 0, 16)[0] == 2
+    assert O.reference().ref_call_public(0, None, img.ctypes.data, O._lut(QUANTIZE_BASE)[1], 64, 16, 0, 16) == 1
+
+
 def test_argument_errors_match_reference_codes():
     img = np.zeros(64 * 16, dtype=np.uint8)
     lut = QUANTIZE_BASE
