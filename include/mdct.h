@@ -92,6 +92,14 @@ int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const f
                       size_t sizeX, size_t sizeY, size_t by0, size_t by1,
                       int layout, int profile, void *stream);
 
+/* The same with an OUTPUT pitch (north_star: "plane in/out, width/height/stride"; the reference has
+ * none, its strips are tight, simd_dct.cpp:2227-2230): block row `by` of the Q32 or BLOCK layout starts
+ * at to + by * pitch_out instead of to + by * 8 * sizeX.  pitch_out >= 8 * sizeX, multiple of 16 bytes;
+ * layouts Q32 and BLOCK only (the other two have no row strips). */
+int mdct_fwd_quant_u8_pitched(const uint8_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
+                              size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                              int layout, int profile, void *stream);
+
 /* ---- engine-own variants (no reference counterpart; BASELINE.json configs 2-5) --------
  * Planes are row-major, pitches in ELEMENTS, coefficient (v,u) of block (by,bx) lives
  * at (by*8+v, bx*8+u); coefficients are those of the orthonormal 2-D DCT-II.

@@ -23,6 +23,23 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* simd_dct.h:7-20: parameter decorations and the status tests callers of the reference use */
+#ifndef IN
+#define IN
+#endif
+#ifndef OUT
+#define OUT
+#endif
+#ifndef IN_OUT
+#define IN_OUT IN OUT
+#endif
+#ifndef _SUCCEEDED
+#define _SUCCEEDED(errorCode) (sdr_Success == (errorCode))
+#endif
+#ifndef _FAILED
+#define _FAILED(errorCode) (!(_SUCCEEDED(errorCode)))
+#endif
+
 #ifdef __cplusplus
 
 /* simd_dct.h:22-27 */
@@ -33,27 +50,53 @@ enum simdDctResult
   sdr_NotSupported,
 };
 
+/* Deviations from the reference, all on inputs where the reference reads or writes out of bounds
+ * (DESIGN.md 1): the stereo function needs sizeY % 16 == 0 and the SSE tiers sizeX % 16 == 0 -- the
+ * reference walks 16 px / two eyes at a time and returns sdr_Success after over-reading
+ * (simd_dct.cpp:945, :1591); here such planes return sdr_NotSupported.  With the tier cap at SSE4.1
+ * the reference's q32 would run its lane-mis-packed SSE4.1 variant (:2267-2539); here: sdr_NotSupported. */
+
 /* simd_dct.h:29 -> tiers simd_dct.cpp:1540 (SSE4.1, default) / :300 (scalar) */
-simdDctResult simdDCT_EncodeQuantizeBuffer(const uint8_t *pFrom, uint8_t *pTo, const float *pQuantizeLUT, const size_t sizeX, const size_t sizeY, const size_t startY, const size_t endY);
+simdDctResult simdDCT_EncodeQuantizeBuffer(IN const uint8_t *pFrom, OUT uint8_t *pTo, IN const float *pQuantizeLUT, const size_t sizeX, const size_t sizeY, const size_t startY, const size_t endY);
 /* simd_dct.h:30 -> tiers simd_dct.cpp:896 (SSE4.1, default) / :177 (scalar) */
-simdDctResult simdDCT_EncodeQuantizeReorderStereoBuffer(const uint8_t *pFrom, uint8_t *pTo, const float *pQuantizeLUT, const size_t sizeX, const size_t sizeY, const size_t startY, const size_t endY);
+simdDctResult simdDCT_EncodeQuantizeReorderStereoBuffer(IN const uint8_t *pFrom, OUT uint8_t *pTo, IN const float *pQuantizeLUT, const size_t sizeX, const size_t sizeY, const size_t startY, const size_t endY);
 /* simd_dct.h:31 -> tier simd_dct.cpp:2064 (AVX2 == AVX-512VL) */
-simdDctResult simdDCT_EncodeQuantize32ReorderBuffer(const uint8_t *pFrom, uint8_t *pTo, const float *pQuantizeLUT, const size_t sizeX, const size_t sizeY, const size_t startY, const size_t endY);
+simdDctResult simdDCT_EncodeQuantize32ReorderBuffer(IN const uint8_t *pFrom, OUT uint8_t *pTo, IN const float *pQuantizeLUT, const size_t sizeX, const size_t sizeY, const size_t startY, const size_t endY);
 
 extern "C" {
 #endif
 
-/* Counterpart of the reference's mutable CPU-flag globals / `--max-simd` (main.cpp:283-438):
- * which reference tier the shim reproduces.  0 = none: scalar tiers, and q32 returns
- * sdr_NotSupported exactly as simd_dct.cpp:127 does; 1 = SSE: stereo/encq SSE tiers, q32
- * not supported (the reference's SSE4.1 q32 variant mis-packs lanes and is not reproduced);
- * 2 = AVX2 (default): what an AVX2 host runs after _DetectCPUFeatures(). */
+/* Counterpart of the reference's mutable CPU-flag globals / `--max-simd` (main.cpp:87-97, :283-438):
+ * the highest reference tier the shim reproduces, process-wide like those globals.
+ *   level            q32 (simd_dct.cpp:120-127)   stereo (:78-85)        encq (:100-105)
+ *   MDCT_SIMD_NONE   sdr_NotSupported             scalar :177            scalar :300
+ *   MDCT_SIMD_SSE2   sdr_NotSupported             SSE2 :1106             scalar :300 (no SSE2 tier exists)
+ *   MDCT_SIMD_SSSE3  sdr_NotSupported             SSSE3 :1330            SSSE3 :1707
+ *   MDCT_SIMD_SSE41  sdr_NotSupported (see above) SSE4.1 :896            SSE4.1 :1540
+ *   MDCT_SIMD_AVX2   AVX2 :2064 == AVX-512VL      SSE4.1                 SSE4.1
+ * (the SSE tiers of one function write identical bytes.)  Default when never called, or called with
+ * a negative level: if the program also links the reference's simd_platform.c, the shim follows its
+ * flag globals (sse2Supported ... avx512VLSupported, simd_platform.h:21-46) exactly as the reference's
+ * dispatchers do -- so the reference's own main.cpp, relinked, keeps its `--max-simd` behaviour and
+ * gets the scalar tiers until it has called _DetectCPUFeatures(); otherwise MDCT_SIMD_AVX2. */
+enum
+{
+  MDCT_SIMD_NONE = 0,
+  MDCT_SIMD_SSE2 = 1,
+  MDCT_SIMD_SSSE3 = 2,
+  MDCT_SIMD_SSE41 = 3,
+  MDCT_SIMD_AVX2 = 4
+};
 void mdct_shim_set_max_simd(int level);
-/* stream (hipStream_t as void*) used for device-pointer calls, and whether they return
- * before completion.  Per process. */
+/* the level in effect right now (after flag-following) */
+int mdct_shim_get_max_simd(void);
+/* stream (hipStream_t as void*) used for device-pointer calls, and whether they return before
+ * completion.  Per HOST THREAD (every thread that calls the three functions has its own setting,
+ * default: null stream, synchronous).  Host-pointer calls are synchronous and use the thread's
+ * internal copy streams. */
 void mdct_shim_set_stream(void *stream);
 void mdct_shim_set_async(int enabled);
-/* frees the calling thread's staging buffers */
+/* frees the calling thread's staging buffers now (they are also freed when the thread exits) */
 void mdct_shim_release(void);
 /* Optional: page-lock a caller-owned host buffer that is reused across calls (hipHostRegister).
  * Host-pointer calls then DMA to/from it in place instead of bouncing through the shim's pinned
@@ -66,6 +109,9 @@ int mdct_shim_unpin(void *p);
  * Returns the simdDctResult value. */
 int mdct_shim_call(int which, const uint8_t *pFrom, uint8_t *pTo, const float *pQuantizeLUT,
                    size_t sizeX, size_t sizeY, size_t startY, size_t endY);
+/* the same with the stream / async choice passed per call instead of per thread */
+int mdct_shim_call_on(int which, const uint8_t *pFrom, uint8_t *pTo, const float *pQuantizeLUT,
+                      size_t sizeX, size_t sizeY, size_t startY, size_t endY, void *stream, int async);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mdct_get_device_info": (c_int, [ctypes.POINTER(DeviceInfo)]),
     "mdct_last_error": (ctypes.c_char_p, []),
     "mdct_fwd_quant_u8": (c_int, [c_void_p, c_void_p, c_size_t, f32p, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_int, c_void_p]),
+    "mdct_fwd_quant_u8_pitched": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, f32p, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_int, c_void_p]),
     "mdct_fwd_i16": (c_int, _PLANE),
     "mdct_inv_i16": (c_int, _PLANE),
     "mdct_roundtrip_i16": (c_int, _PLANE),
@@ -69,12 +70,14 @@ SIGNATURES = {
     "mdct_timer_elapsed_ms": (ctypes.c_double, [c_void_p]),
     "mdct_stream_synchronize": (c_int, [c_void_p]),
     "mdct_shim_set_max_simd": (None, [c_int]),
+    "mdct_shim_get_max_simd": (c_int, []),
     "mdct_shim_set_stream": (None, [c_void_p]),
     "mdct_shim_set_async": (None, [c_int]),
     "mdct_shim_release": (None, []),
     "mdct_shim_pin": (c_int, [c_void_p, c_size_t]),
     "mdct_shim_unpin": (c_int, [c_void_p]),
     "mdct_shim_call": (c_int, _REF),
+    "mdct_shim_call_on": (c_int, _REF + [c_void_p, c_int]),
 }
 
 # the reference's three C++-linkage entry points (simd_dct.h:29-31), Itanium-mangled

@@ -85,8 +85,11 @@ def device_info():
 
 # ----------------------------------------------------------------------------- reference API
 def _ref_call(which, pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY):
+    """Device tensors: the kernel runs on torch's CURRENT stream (ordered against the work that
+    produced the tensors) and the call returns when it has finished, like the reference's
+    blocking functions.  Host arrays: the shim's synchronous staging pipeline."""
     keep, lp = _lut_ptr(pQuantizeLUT)
-    return _lib.load().mdct_shim_call(which, _ptr(pFrom), _ptr(pTo), lp, sizeX, sizeY, startY, endY)
+    return _lib.load().mdct_shim_call_on(which, _ptr(pFrom), _ptr(pTo), lp, sizeX, sizeY, startY, endY, _stream(), 0)
 
 
 def simdDCT_EncodeQuantize32ReorderBuffer(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY):
@@ -104,15 +107,27 @@ def simdDCT_EncodeQuantizeBuffer(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY,
     return _ref_call(2, pFrom, pTo, pQuantizeLUT, sizeX, sizeY, startY, endY)
 
 
+SIMD_NONE, SIMD_SSE2, SIMD_SSSE3, SIMD_SSE41, SIMD_AVX2 = 0, 1, 2, 3, 4  # include/simd_dct_shim.h
+
+
 def set_max_simd(level):
-    """Counterpart of `--max-simd` (main.cpp:283-438): 0 none/scalar, 1 SSE, 2 AVX2 (default)."""
+    """Counterpart of `--max-simd` (main.cpp:283-438): SIMD_NONE .. SIMD_AVX2 (default), see
+    include/simd_dct_shim.h for the tier each level selects per function; negative = unset."""
     _lib.load().mdct_shim_set_max_simd(int(level))
 
 
+def get_max_simd():
+    return _lib.load().mdct_shim_get_max_simd()
+
+
 # -------------------------------------------------------------------------------- native API
-def fwd_quant_u8(src, dst, lut, sizeX, sizeY, by0, by1, layout=LAYOUT_Q32, profile=PROFILE_REF_AVX, pitch_in=None, stream=None, check=True):
+def fwd_quant_u8(src, dst, lut, sizeX, sizeY, by0, by1, layout=LAYOUT_Q32, profile=PROFILE_REF_AVX, pitch_in=None, pitch_out=None, stream=None, check=True):
+    """pitch_out (bytes between the output strips of consecutive block rows) selects mdct_fwd_quant_u8_pitched"""
     keep, lp = _lut_ptr(lut)
-    rc = _lib.load().mdct_fwd_quant_u8(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, lp, sizeX, sizeY, by0, by1, layout, profile, _stream(stream))
+    if pitch_out is None:
+        rc = _lib.load().mdct_fwd_quant_u8(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, lp, sizeX, sizeY, by0, by1, layout, profile, _stream(stream))
+    else:
+        rc = _lib.load().mdct_fwd_quant_u8_pitched(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, pitch_out, lp, sizeX, sizeY, by0, by1, layout, profile, _stream(stream))
     if check:
         _check(rc)
     return rc

@@ -270,7 +270,8 @@ int mdct_get_device_info(mdct_device_info *info)
 
 const char *mdct_last_error(void) { return g_err; }
 
-int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int layout, int profile, void *stream)
+// pitch_out: 0 = the reference's addressing (strips of 8*sizeX bytes, tight)
+static int fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int layout, int profile, void *stream)
 {
   // argument checks in the order of the reference dispatchers: null -> 1, shape -> 2
   // (simd_dct.cpp:75-76, :97-98, :117-118); the table is not null-checked there, here it is.
@@ -286,6 +287,10 @@ int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const f
     return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu: width must be a multiple of %zu and height of %zu for this layout", sizeX, sizeY, xmul, ymul);
   if (pitch_in < sizeX || by0 > by1 || by1 > sizeY / ymul)
     return fail(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows", by0, by1, sizeY / ymul);
+  if (pitch_out != 0 && layout != MDCT_LAYOUT_Q32 && layout != MDCT_LAYOUT_BLOCK)
+    return fail(MDCT_NOT_SUPPORTED, "an output strip pitch exists for the Q32 and BLOCK layouts only");
+  if (pitch_out != 0 && (pitch_out < 8 * sizeX || pitch_out % 16 != 0))
+    return fail(MDCT_INVALID_PARAMETER, "output strip pitch %zu must be >= 8*sizeX = %zu and a multiple of 16", pitch_out, 8 * sizeX);
 
   const mdct_device_info *di;
   int r = current(&di);
@@ -302,6 +307,8 @@ int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const f
     a.qt.q[i] = profile == MDCT_PROFILE_REF_SCALAR ? 1.f / (lut[i] * vr) : 255.0f / (lut[i] * vr);
   a.pitch = pitch_in;
   a.sizeX = sizeX;
+  a.out_strip = pitch_out ? pitch_out : 8 * sizeX;
+  a.out_tight = a.out_strip == 8 * sizeX;
   a.eye_offset = pitch_in * (sizeY / 2);
   a.plane_stride = (sizeX * sizeY) / 64;
   a.bpr = (uint32_t)(sizeX / 8);
@@ -314,6 +321,18 @@ int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const f
   const bool safe = profile != MDCT_PROFILE_REF_SCALAR && table_needs_safe(a.qt.q);
   const hipError_t e = mdct::launch_fwd_quant_u8(a, layout, profile, safe, (hipStream_t)stream);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "u8 kernel launch");
+}
+
+int mdct_fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int layout, int profile, void *stream)
+{
+  return fwd_quant_u8(from, to, pitch_in, 0, lut, sizeX, sizeY, by0, by1, layout, profile, stream);
+}
+
+int mdct_fwd_quant_u8_pitched(const uint8_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int layout, int profile, void *stream)
+{
+  if (pitch_out == 0)
+    return fail(MDCT_INVALID_PARAMETER, "output strip pitch is 0");
+  return fwd_quant_u8(from, to, pitch_in, pitch_out, lut, sizeX, sizeY, by0, by1, layout, profile, stream);
 }
 
 int mdct_fwd_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)

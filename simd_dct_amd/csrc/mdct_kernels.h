@@ -65,6 +65,7 @@ struct U8Args
   DctConsts consts;
   size_t pitch;        // input row pitch, bytes
   size_t sizeX;        // plane width, bytes (output addressing)
+  size_t out_strip;    // Q32 / BLOCK: bytes between the output strips of consecutive block rows (8*sizeX when tight)
   size_t eye_offset;   // STEREO: byte offset of the second image
   size_t plane_stride; // STEREO: bytes per coefficient plane (sizeX*sizeY/64)
   uint32_t bpr;        // blocks per block row (sizeX/8)
@@ -72,6 +73,7 @@ struct U8Args
   uint32_t by_last;    // BLOCK_SSE: last block row of the launch
   uint32_t nblocks;    // blocks in the launch
   uint32_t spill_ok;   // BLOCK_SSE: trailing spill stays inside the buffer
+  uint32_t out_tight;  // out_strip == 8*sizeX: a launch's Q32 / BLOCK output is one contiguous slab
 };
 
 struct I16Args

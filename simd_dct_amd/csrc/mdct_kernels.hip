@@ -461,7 +461,14 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
         const uint2 hi = *reinterpret_cast<const uint2 *>(wl + (c2 + 1) * kQ32RowStride + g * 8);
         typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
         const u32x4_t v = {lo.x, lo.y, hi.x, hi.y};
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(outw + g * 512 + c2 * 8));
+        uint8_t *dst = outw + g * 512 + c2 * 8;
+        if (!a.out_tight)
+        { // pitched strips (mdct_fwd_quant_u8_pitched): group G of the launch -> (block row, group x)
+          const uint32_t G = (wave_t0 >> 3) + g, gpr = a.bpr >> 3;
+          const uint32_t grow = G / gpr;
+          dst = a.to + (size_t)(a.by0 + grow) * a.out_strip + (size_t)(G - grow * gpr) * 512 + c2 * 8;
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(dst));
       }
     }
   }
@@ -503,7 +510,7 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
   {
     if (valid)
     {
-      uint8_t *dst = a.to + (size_t)by * 8 * a.sizeX + (size_t)bx * 64;
+      uint8_t *dst = a.to + (size_t)by * a.out_strip + (size_t)bx * 64;
 #pragma unroll
       for (int k = 0; k < 4; k++)
       {

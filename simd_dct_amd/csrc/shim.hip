@@ -2,7 +2,8 @@
 //
 // Translates the reference's call semantics (top-half loop, inclusive endY, tier choice)
 // into the engine's half-open block-row ranges, and serves host pointers by staging
-// the touched rows through HBM.  Re-entrant: staging buffers are per thread.
+// the touched rows through HBM.  Re-entrant: staging buffers, stream and async flag are per
+// host thread; only the tier cap is process-wide (like the reference's CPU-flag globals).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -11,12 +12,51 @@
 #include "mdct.h"
 #include "simd_dct_shim.h"
 
+// The reference's dispatchers read mutable CPU-flag globals (simd_platform.h:21-46, C linkage)
+// that the CALLER fills in via _DetectCPUFeatures() and `--max-simd` clears (main.cpp:283-438).
+// A program that still links the reference's simd_platform.c (e.g. its unchanged main.cpp,
+// INTEGRATION.md 1) defines them; the shim then follows them exactly like simd_dct.cpp:78-85,
+// :100-105, :120-127 do, unless mdct_shim_set_max_simd() has been called.  Weak: absent in
+// every other program, where the default is the AVX2 tier.
+extern "C" {
+extern bool sse2Supported __attribute__((weak));
+extern bool ssse3Supported __attribute__((weak));
+extern bool sse41Supported __attribute__((weak));
+extern bool avx2Supported __attribute__((weak));
+extern bool avx512VLSupported __attribute__((weak));
+}
+
 namespace
 {
 
-std::atomic<int> g_max_simd{2};
-std::atomic<void *> g_stream{nullptr};
-std::atomic<int> g_async{0};
+std::atomic<int> g_max_simd{-1}; // -1: not set (follow the reference's flags when linked, else AVX2)
+
+struct ThreadConfig
+{
+  void *stream = nullptr;
+  int async = 0;
+};
+thread_local ThreadConfig tl_cfg;
+
+int effective_level()
+{
+  const int set = g_max_simd.load();
+  if (set >= 0)
+    return set;
+  if (&sse2Supported && &ssse3Supported && &sse41Supported && &avx2Supported && &avx512VLSupported)
+  {
+    if (avx512VLSupported || avx2Supported)
+      return MDCT_SIMD_AVX2;
+    if (sse41Supported && sse2Supported)
+      return MDCT_SIMD_SSE41;
+    if (ssse3Supported && sse2Supported)
+      return MDCT_SIMD_SSSE3;
+    if (sse2Supported)
+      return MDCT_SIMD_SSE2;
+    return MDCT_SIMD_NONE;
+  }
+  return MDCT_SIMD_AVX2;
+}
 
 struct Staging
 {
@@ -27,26 +67,34 @@ struct Staging
   size_t pin_cap = 0;
   hipStream_t stream[2] = {nullptr, nullptr};
   int device = -1;
+
+  void release()
+  {
+    // errors are ignored on purpose: at process exit the runtime may already be shutting down
+    if (in)
+      (void)hipFree(in);
+    if (out)
+      (void)hipFree(out);
+    for (int i = 0; i < 2; i++)
+    {
+      if (pin_in[i])
+        (void)hipHostFree(pin_in[i]);
+      if (pin_out[i])
+        (void)hipHostFree(pin_out[i]);
+      if (stream[i])
+        (void)hipStreamDestroy(stream[i]);
+      pin_in[i] = pin_out[i] = nullptr;
+      stream[i] = nullptr;
+    }
+    (void)hipGetLastError();
+    in = out = nullptr;
+    in_cap = out_cap = pin_cap = 0;
+    device = -1;
+  }
+  // a worker thread that exits without mdct_shim_release() gives its HBM / pinned memory back
+  ~Staging() { release(); }
 };
 thread_local Staging tl_stage;
-
-void release(Staging &s)
-{
-  if (s.in)
-    (void)hipFree(s.in);
-  if (s.out)
-    (void)hipFree(s.out);
-  for (int i = 0; i < 2; i++)
-  {
-    if (s.pin_in[i])
-      (void)hipHostFree(s.pin_in[i]);
-    if (s.pin_out[i])
-      (void)hipHostFree(s.pin_out[i]);
-    if (s.stream[i])
-      (void)hipStreamDestroy(s.stream[i]);
-  }
-  s = Staging();
-}
 
 bool reserve_pipeline(Staging &s, size_t chunk_bytes)
 {
@@ -125,43 +173,59 @@ void ref_range(size_t sizeY, size_t startY, size_t endY, size_t step, size_t *b0
     *b0 = *b1;
 }
 
+// both pipeline streams idle before an error return: no copy may still target the caller's memory
+simdDctResult pipeline_failed(Staging &st)
+{
+  for (int i = 0; i < 2; i++)
+    if (st.stream[i])
+      (void)hipStreamSynchronize(st.stream[i]);
+  (void)hipGetLastError();
+  return sdr_NotSupported;
+}
+
 simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t sizeX, size_t sizeY, size_t b0, size_t b1, int layout, int profile)
 {
-  if (b0 >= b1)
+  // nothing to do: the reference's loops simply do not execute (also for sizeX == 0, which passes its shape test)
+  if (b0 >= b1 || sizeX == 0)
     return sdr_Success;
   const bool dev_in = is_device_ptr(pFrom), dev_out = is_device_ptr(pTo);
-  void *stream = g_stream.load();
+  void *stream = tl_cfg.stream;
 
   if (dev_in && dev_out)
   {
     int r = mdct_fwd_quant_u8(pFrom, pTo, sizeX, lut, sizeX, sizeY, b0, b1, layout, profile, stream);
-    if (r == MDCT_SUCCESS && !g_async.load())
+    if (r == MDCT_SUCCESS && !tl_cfg.async)
       r = mdct_stream_synchronize(stream);
     return (simdDctResult)r;
   }
 
-  // Host path.  Input: the touched pixel rows only.  Output: Q32/BLOCK write whole row
-  // strips; STEREO and BLOCK_SSE write scattered bytes, so their destination is first
-  // mirrored into HBM to keep untouched bytes untouched.
+  // Host path.  Input: the touched pixel rows only.  Output: only the bytes this row range
+  // writes travel back, so concurrent calls on disjoint ranges (the reference's intended
+  // multi-core use) never touch each other's rows:
+  //   Q32 / BLOCK   whole row strips [b0*8*sizeX, b1*8*sizeX)
+  //   BLOCK_SSE     the same strips, of which the tier writes only half the bytes
+  //                 (simd_dct.cpp:1662-1676) -> the strip is mirrored into HBM first
+  //   STEREO        the segment [b0*2*bpr, b1*2*bpr) of each of the 64 coefficient planes
   Staging &st = tl_stage;
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (st.device != dev)
   {
-    release(st);
+    st.release();
     st.device = dev;
   }
   const size_t total = sizeX * sizeY;
-  const bool scattered = layout == MDCT_LAYOUT_STEREO || layout == MDCT_LAYOUT_BLOCK_SSE;
+  const size_t strip = 8 * sizeX; // bytes per block row, input and output alike
 
   // Both pointers on the host and a strip layout: chunked pipeline.  Block-row strips of
-  // ~4 MiB ping-pong over two streams, so strip k's kernel and device->host copy overlap strip
-  // k+1's host->device copy (PCIe is full duplex); the caller's pageable memory is touched
-  // only by plain memcpy to/from pinned bounce buffers.
-  if (!dev_in && !dev_out && !scattered)
+  // ~4 MiB ping-pong over two internal streams, so strip k's kernel and device->host copy
+  // overlap strip k+1's host->device copy (PCIe is full duplex); the caller's pageable memory
+  // is touched only by plain memcpy to/from pinned bounce buffers.  A host-pointer call is
+  // synchronous by nature (the output must be in host memory on return) and its operands are
+  // not produced by any stream, so it does not involve the thread's configured stream.
+  if (!dev_in && !dev_out && (layout == MDCT_LAYOUT_Q32 || layout == MDCT_LAYOUT_BLOCK))
   {
     const bool pinned_in = classify(pFrom) == PTR_PINNED, pinned_out = classify(pTo) == PTR_PINNED;
-    const size_t strip = 8 * sizeX; // bytes per block row, input and output alike
     size_t rows_per_chunk = ((size_t)4 << 20) / strip;
     rows_per_chunk = rows_per_chunk < 1 ? 1 : rows_per_chunk;
     if (reserve(st.in, st.in_cap, total) && reserve(st.out, st.out_cap, total) && reserve_pipeline(st, rows_per_chunk * strip))
@@ -181,7 +245,7 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
       {
         const int sl = (int)(c & 1);
         if (c >= 2 && !drain(c - 2))
-          return sdr_NotSupported;
+          return pipeline_failed(st);
         const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
         const size_t off = r0 * strip, len = (r1 - r0) * strip;
         const uint8_t *h_in = pFrom + off; // pinned caller memory is DMA'd in place
@@ -191,15 +255,20 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
           h_in = st.pin_in[sl];
         }
         if (hipMemcpyAsync(st.in + off, h_in, len, hipMemcpyHostToDevice, st.stream[sl]) != hipSuccess)
-          return sdr_NotSupported;
+          return pipeline_failed(st);
         r = mdct_fwd_quant_u8(st.in, st.out, sizeX, lut, sizeX, sizeY, r0, r1, layout, profile, st.stream[sl]);
         if (r == MDCT_SUCCESS && hipMemcpyAsync(pinned_out ? pTo + off : st.pin_out[sl], st.out + off, len, hipMemcpyDeviceToHost, st.stream[sl]) != hipSuccess)
-          return sdr_NotSupported;
+          return pipeline_failed(st);
+      }
+      if (r != MDCT_SUCCESS)
+      {
+        (void)pipeline_failed(st);
+        return (simdDctResult)r;
       }
       for (size_t c = nchunks >= 2 ? nchunks - 2 : 0; c < nchunks; c++)
-        if (!drain(c) && r == MDCT_SUCCESS)
-          return sdr_NotSupported;
-      return (simdDctResult)r;
+        if (!drain(c))
+          return pipeline_failed(st);
+      return sdr_Success;
     }
     (void)hipGetLastError(); // could not set the pipeline up: fall through to the plain path
   }
@@ -207,15 +276,24 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
   const uint8_t *d_in = pFrom;
   uint8_t *d_out = pTo;
   hipStream_t hs = (hipStream_t)stream;
+  const size_t bpr = sizeX / 8;
+  const size_t plane_stride = total / 64;                    // STEREO: bytes per coefficient plane
+  const size_t seg_off = b0 * 2 * bpr, seg_len = (b1 - b0) * 2 * bpr; // STEREO: this range's bytes of every plane
+  const size_t off = b0 * strip;
+  size_t len = (b1 - b0) * strip;
+  if (layout == MDCT_LAYOUT_BLOCK_SSE && off + len + 64 <= total)
+    len += 64; // the surviving spill of the last pair (simd_dct.cpp:1676) lands in the next strip
 
   if (!dev_in)
   {
-    // STEREO reads both halves of the plane; stage all of it.  Others: rows [b0*8, b1*8).
-    const size_t off = layout == MDCT_LAYOUT_STEREO ? 0 : b0 * 8 * sizeX;
-    const size_t len = layout == MDCT_LAYOUT_STEREO ? total : (b1 - b0) * 8 * sizeX;
     if (!reserve(st.in, st.in_cap, total))
       return sdr_NotSupported;
-    if (hipMemcpyAsync(st.in + off, pFrom + off, len, hipMemcpyHostToDevice, hs) != hipSuccess)
+    hipError_t e;
+    if (layout == MDCT_LAYOUT_STEREO) // block rows [b0, b1) of BOTH stacked images
+      e = hipMemcpy2DAsync(st.in + off, total / 2, pFrom + off, total / 2, (b1 - b0) * strip, 2, hipMemcpyHostToDevice, hs);
+    else
+      e = hipMemcpyAsync(st.in + off, pFrom + off, (b1 - b0) * strip, hipMemcpyHostToDevice, hs);
+    if (e != hipSuccess)
       return sdr_NotSupported;
     d_in = st.in;
   }
@@ -223,25 +301,36 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
   {
     if (!reserve(st.out, st.out_cap, total))
       return sdr_NotSupported;
-    // STEREO over its whole range writes every byte of every coefficient plane: nothing to preserve
-    const bool writes_everything = layout == MDCT_LAYOUT_STEREO && b0 == 0 && b1 == sizeY / 16;
-    if (scattered && !writes_everything && hipMemcpyAsync(st.out, pTo, total, hipMemcpyHostToDevice, hs) != hipSuccess)
+    // BLOCK_SSE leaves half of every strip byte untouched: start from the caller's bytes
+    if (layout == MDCT_LAYOUT_BLOCK_SSE && hipMemcpyAsync(st.out + off, pTo + off, len, hipMemcpyHostToDevice, hs) != hipSuccess)
       return sdr_NotSupported;
     d_out = st.out;
   }
 
   int r = mdct_fwd_quant_u8(d_in, d_out, sizeX, lut, sizeX, sizeY, b0, b1, layout, profile, stream);
   if (r != MDCT_SUCCESS)
+  {
+    (void)hipStreamSynchronize(hs);
     return (simdDctResult)r;
+  }
 
   if (!dev_out)
   {
-    const size_t off = scattered ? 0 : b0 * 8 * sizeX;
-    const size_t len = scattered ? total : (b1 - b0) * 8 * sizeX;
-    if (hipMemcpyAsync(pTo + off, st.out + off, len, hipMemcpyDeviceToHost, hs) != hipSuccess)
+    hipError_t e;
+    if (layout == MDCT_LAYOUT_STEREO)
+      e = hipMemcpy2DAsync(pTo + seg_off, plane_stride, st.out + seg_off, plane_stride, seg_len, 64, hipMemcpyDeviceToHost, hs);
+    else
+      e = hipMemcpyAsync(pTo + off, st.out + off, len, hipMemcpyDeviceToHost, hs);
+    if (e != hipSuccess)
+    {
+      (void)hipStreamSynchronize(hs);
       return sdr_NotSupported;
+    }
   }
-  if (!dev_out || !g_async.load())
+  // anything that staged through this thread's buffers completes before returning; a device
+  // output fed from a host input may stay asynchronous only if the input copy has been consumed,
+  // which nothing but a synchronise can guarantee -> synchronous as well
+  if (!dev_out || !dev_in || !tl_cfg.async)
     r = mdct_stream_synchronize(stream);
   return (simdDctResult)r;
 }
@@ -255,8 +344,10 @@ simdDctResult simdDCT_EncodeQuantize32ReorderBuffer(const uint8_t *pFrom, uint8_
     return sdr_InvalidParameter;
   if ((sizeX & ~(size_t)63) != sizeX || (sizeY & ~(size_t)7) != sizeY)
     return sdr_NotSupported;
-  if (g_max_simd.load() < 2)
-    return sdr_NotSupported; // :127, no scalar tier exists
+  // :120-127: AVX-512VL -> AVX2 -> SSE4.1 -> not supported.  The SSE4.1 variant (:2267-2539) mis-packs
+  // its lanes (dead code on any AVX2 host) and is not reproduced: not supported here.
+  if (effective_level() < MDCT_SIMD_AVX2)
+    return sdr_NotSupported;
   size_t b0, b1;
   ref_range(sizeY, startY, endY, 16, &b0, &b1);
   return run(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, b0, b1, MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX);
@@ -271,7 +362,8 @@ simdDctResult simdDCT_EncodeQuantizeReorderStereoBuffer(const uint8_t *pFrom, ui
     return sdr_NotSupported;
   size_t b0, b1;
   ref_range(sizeY, startY, endY, 16, &b0, &b1);
-  const int profile = g_max_simd.load() >= 1 ? MDCT_PROFILE_REF_SSE : MDCT_PROFILE_REF_SCALAR;
+  // :78-85: SSE4.1 -> SSSE3 -> SSE2 (all three write the same bytes) -> scalar
+  const int profile = effective_level() >= MDCT_SIMD_SSE2 ? MDCT_PROFILE_REF_SSE : MDCT_PROFILE_REF_SCALAR;
   return run(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, b0, b1, MDCT_LAYOUT_STEREO, profile);
 }
 
@@ -283,7 +375,7 @@ simdDctResult simdDCT_EncodeQuantizeBuffer(const uint8_t *pFrom, uint8_t *pTo, c
   if ((sizeX & ~(size_t)7) != sizeX || (sizeY & ~(size_t)7) != sizeY)
     return sdr_NotSupported;
   size_t b0, b1;
-  if (g_max_simd.load() >= 1)
+  if (effective_level() >= MDCT_SIMD_SSSE3) // :100-105: SSE4.1 -> SSSE3 (same bytes) -> scalar; there is no SSE2 tier
   {
     ref_range(sizeY, startY, endY, 16, &b0, &b1);
     return run(pFrom, pTo, pQuantizeLUT, sizeX, sizeY, b0, b1, MDCT_LAYOUT_BLOCK_SSE, MDCT_PROFILE_REF_SSE);
@@ -294,10 +386,11 @@ simdDctResult simdDCT_EncodeQuantizeBuffer(const uint8_t *pFrom, uint8_t *pTo, c
 
 extern "C" {
 
-void mdct_shim_set_max_simd(int level) { g_max_simd.store(level < 0 ? 0 : (level > 2 ? 2 : level)); }
-void mdct_shim_set_stream(void *stream) { g_stream.store(stream); }
-void mdct_shim_set_async(int enabled) { g_async.store(enabled != 0); }
-void mdct_shim_release(void) { release(tl_stage); }
+void mdct_shim_set_max_simd(int level) { g_max_simd.store(level < 0 ? -1 : (level > MDCT_SIMD_AVX2 ? MDCT_SIMD_AVX2 : level)); }
+int mdct_shim_get_max_simd(void) { return effective_level(); }
+void mdct_shim_set_stream(void *stream) { tl_cfg.stream = stream; }
+void mdct_shim_set_async(int enabled) { tl_cfg.async = enabled != 0; }
+void mdct_shim_release(void) { tl_stage.release(); }
 
 int mdct_shim_pin(void *p, size_t bytes)
 {
@@ -334,6 +427,18 @@ int mdct_shim_call(int which, const uint8_t *pFrom, uint8_t *pTo, const float *l
   case 2: return (int)simdDCT_EncodeQuantizeBuffer(pFrom, pTo, lut, sizeX, sizeY, startY, endY);
   }
   return MDCT_INVALID_PARAMETER;
+}
+
+// the same with the stream / async choice per call (no thread state): what a binding that
+// owns streams (e.g. a torch extension passing its current stream) should use
+int mdct_shim_call_on(int which, const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t sizeX, size_t sizeY, size_t startY, size_t endY, void *stream, int async)
+{
+  const ThreadConfig saved = tl_cfg;
+  tl_cfg.stream = stream;
+  tl_cfg.async = async != 0;
+  const int r = mdct_shim_call(which, pFrom, pTo, lut, sizeX, sizeY, startY, endY);
+  tl_cfg = saved;
+  return r;
 }
 
 } // extern "C"

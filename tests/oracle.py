@@ -170,3 +170,68 @@ def f32(mode, src, W, H, by0=0, by1=None):
     rc = fn(src.ctypes.data, out.ctypes.data, W, W, W, H, by0, H // 8 if by1 is None else by1)
     assert rc == 0, rc
     return out
+
+
+# ------------------------------------------------------------------ whole-plane checks, threaded
+def host_threads(cap=32):
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def _par_rows(call, rows, threads=None):
+    """run call(b0, b1) over disjoint block-row stripes on host threads (ctypes releases the GIL)"""
+    import threading
+
+    threads = host_threads() if threads is None else threads
+    threads = max(1, min(threads, rows))
+    cuts = [rows * i // threads for i in range(threads + 1)]
+    errs = []
+
+    def work(a, b):
+        try:
+            rc = call(a, b)
+            if rc != 0:
+                errs.append(rc)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(a, b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+
+
+def i16_par(mode, src, W, H, lut=None, out=None, threads=None):
+    """i16() over a whole (large) plane on all host threads"""
+    src = np.ascontiguousarray(src, dtype=np.int16)
+    out = np.empty((H, W), dtype=np.int16) if out is None else out
+    lp = None
+    if lut is not None:
+        keep, lp = _lut(lut)
+    fn = getattr(oracle(), {"fwd": "orc_fwd_i16", "inv": "orc_inv_i16", "roundtrip": "orc_roundtrip_i16"}[mode])
+    _par_rows(lambda a, b: fn(src.ctypes.data, out.ctypes.data, W, W, lp, W, H, a, b), H // 8, threads)
+    return out
+
+
+def q32_native_par(img, lut, W, H, out=None, threads=None):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty(W * H, dtype=np.uint8) if out is None else out
+    keep, lp = _lut(lut)
+    _par_rows(lambda a, b: oracle().orc_q32_native(img.ctypes.data, out.ctypes.data, W, lp, W, H, a, b), H // 8, threads)
+    return out
+
+
+def f32_par(mode, src, W, H, threads=None):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    out = np.empty((H, W), dtype=np.float64 if mode == "f64ref" else np.float32)
+    fn = getattr(oracle(), {"fwd": "orc_fwd_f32", "inv": "orc_inv_f32", "f64ref": "orc_fwd_f64ref"}[mode])
+    _par_rows(lambda a, b: fn(src.ctypes.data, out.ctypes.data, W, W, W, H, a, b), H // 8, threads)
+    return out

@@ -65,7 +65,7 @@ def test_status_codes_without_device(lib):
     try:
         assert api.simdDCT_EncodeQuantize32ReorderBuffer(a, a, lut, 64, 16, 0, 16) == api.sdr_NotSupported
     finally:
-        api.set_max_simd(2)
+        api.set_max_simd(api.SIMD_AVX2)
     # native entry points
     assert api.fwd_quant_u8(None, a, lut, 64, 16, 0, 2, check=False) == 1
     assert api.fwd_quant_u8(a, a, lut, 56, 16, 0, 2, check=False) == 2
@@ -110,3 +110,89 @@ def test_synthetic_generators_agree_host_and_torch():
         b = synth.plane_i16_torch(64, 24, "photo", seed=7, bits=bits, device="cpu").numpy()
         assert np.array_equal(a, b), bits
         assert a.min() >= -(1 << (bits - 1)) and a.max() < (1 << (bits - 1))
+
+
+def _cxx(tmp_path, name, source, link=True):
+    """compile (and link against libmdct_hip.so) a small C++ caller, the way a user of the reference would"""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = tmp_path / (name + ".cpp")
+    src.write_text(source)
+    exe = tmp_path / name
+    cmd = ["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src)]
+    cmd += (["-L" + os.path.dirname(_lib.LIB_PATH), "-lmdct_hip", "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)] if link else ["-fsyntax-only"])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return str(exe)
+
+
+def test_header_carries_the_reference_macros(tmp_path, lib):
+    """simd_dct.h:7-20: IN / OUT / IN_OUT and _SUCCEEDED / _FAILED survive a header swap"""
+    _cxx(tmp_path, "macros", '''
+#include "simd_dct_shim.h"
+static_assert(_SUCCEEDED(sdr_Success) && _FAILED(sdr_NotSupported) && _FAILED(sdr_InvalidParameter), "status tests");
+static simdDctResult call(IN const uint8_t *a, OUT uint8_t *b, IN_OUT float *t) { return simdDCT_EncodeQuantizeBuffer(a, b, t, 8, 8, 0, 8); }
+int main() { (void)&call; return 0; }
+''', link=False)
+
+
+def test_shim_follows_the_reference_cpu_flags_when_linked(tmp_path, lib):
+    """A program that still links the reference's simd_platform.c defines its flag globals
+    (simd_platform.h:21-46); the shim then picks tiers exactly as simd_dct.cpp:78-85, :100-105, :120-127
+    do -- all false until the caller runs _DetectCPUFeatures() -- unless mdct_shim_set_max_simd() overrides."""
+    import subprocess
+
+    exe = _cxx(tmp_path, "flags", '''
+#include <cstdio>
+#include "simd_dct_shim.h"
+extern "C" { bool sse2Supported = false, ssse3Supported = false, sse41Supported = false, avx2Supported = false, avx512VLSupported = false; }
+int main() {
+  static uint8_t a[64 * 16], b[64 * 16];
+  static float lut[64];
+  for (float &f : lut) f = 1.f;
+  printf("%d", mdct_shim_get_max_simd());                      // nothing detected: scalar tiers
+  printf(" %d", (int)simdDCT_EncodeQuantize32ReorderBuffer(a, b, lut, 64, 16, 0, 16)); // -> sdr_NotSupported (:127), no device touched
+  sse2Supported = true;            printf(" %d", mdct_shim_get_max_simd());
+  ssse3Supported = true;           printf(" %d", mdct_shim_get_max_simd());
+  sse41Supported = true;           printf(" %d", mdct_shim_get_max_simd());
+  avx2Supported = true;            printf(" %d", mdct_shim_get_max_simd());
+  avx2Supported = false; avx512VLSupported = true; printf(" %d", mdct_shim_get_max_simd());
+  mdct_shim_set_max_simd(MDCT_SIMD_SSSE3); printf(" %d", mdct_shim_get_max_simd());   // explicit cap wins
+  mdct_shim_set_max_simd(-1);      printf(" %d", mdct_shim_get_max_simd());            // unset: flags again
+  printf(" %d\\n", (int)simdDCT_EncodeQuantizeBuffer(a, b, lut, 0, 16, 0, 16));        // sizeX == 0: nothing to do, success
+  return 0;
+}
+''')
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["0", "2", "1", "2", "3", "4", "4", "2", "4", "0"], r.stdout
+    # without those globals in the program the default is the AVX2 tier
+    assert api.get_max_simd() == api.SIMD_AVX2
+
+
+def test_cli_max_simd_spellings():
+    """main.cpp:87-97 spells the tiers sse4.1 / sse4.2 / avx512f / avx512bw; unknown ones abort (:438)"""
+    import subprocess
+
+    cli = G.build_cli()
+    r = subprocess.run([cli, "synthetic:noise", "64", "16", "--max-simd", "sse41"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Invalid SIMD Variant 'sse41'" in r.stdout
+    for ok in ("sse4.1", "sse4.2", "avx512f", "avx512bw", "avx", "ssse3", "sse3", "sse2", "none", "avx2"):
+        r = subprocess.run([cli, "synthetic:noise", "64", "16", "--max-simd", ok, "--cpu-core", "0", "--runs", "1"], capture_output=True, text=True, timeout=60)
+        assert "Invalid" not in r.stdout, (ok, r.stdout)
+        assert r.returncode in (0, 2, 3), (ok, r.returncode, r.stdout)  # 2/3: no HIP device in this container
+
+
+def test_pitched_output_argument_checks(lib):
+    a = np.zeros(64 * 16, dtype=np.uint8)
+    lut = api.QUANTIZE_BASE
+    assert api.fwd_quant_u8(a, a, lut, 64, 16, 0, 2, pitch_out=256, check=False) == 1  # < 8*sizeX
+    assert api.fwd_quant_u8(a, a, lut, 64, 16, 0, 2, pitch_out=520, check=False) == 1  # not a multiple of 16
+    assert api.fwd_quant_u8(a, a, lut, 64, 16, 0, 1, layout=api.LAYOUT_STEREO, profile=api.PROFILE_REF_SSE, pitch_out=1024, check=False) == 2
+    assert "Q32 and BLOCK" in api.last_error()
+    # sizeX == 0 passes the reference's shape test and does nothing (simd_dct.cpp:118, :2103)
+    assert api.simdDCT_EncodeQuantize32ReorderBuffer(a, a, lut, 0, 16, 0, 16) == api.sdr_Success
+    assert api.simdDCT_EncodeQuantizeBuffer(a, a, lut, 0, 16, 0, 16) == api.sdr_Success

@@ -9,10 +9,12 @@
 //
 //   simd_dct_cli <raw_grayscale_image_file | synthetic:noise | synthetic:photo> <X> <Y>
 //        [--to <file>] [--quality <n>] [--runs <n>] [--mode enc-quant|enc-quant32|enc-quant-stereo]...
-//        [--max-simd avx2|sse41|ssse3|sse2|none] [--resident] [--device <n>]
+//        [--max-simd avx512bw|avx512f|avx2|avx|sse4.2|sse4.1|ssse3|sse3|sse2|none] [--cpu-core <n>] [--resident] [--pin] [--device <n>]
 //
 // Build: hipcc -O2 -std=c++17 -Iinclude tools/simd_dct_cli.cpp -Lsimd_dct_amd -lmdct_hip -Wl,-rpath,'$ORIGIN/../simd_dct_amd' -o tools/simd_dct_cli
 #include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <cinttypes>
 #include <cmath>
@@ -97,7 +99,8 @@ int main(int argc, char **argv)
     puts("\t--to <file_name>\t\tStore the last output in the specified file.");
     puts("\t--quality <n>\t\t\tMultiplies the base quantization table (integer, as the reference parses it).");
     puts("\t--runs <uint>\t\t\tRun the benchmark for a specified amount of times.");
-    puts("\t--max-simd <avx2 / sse41 / ssse3 / sse2 / none>\tReference tier to reproduce.");
+    puts("\t--max-simd <avx512bw / avx512f / avx2 / avx / sse4.2 / sse4.1 / ssse3 / sse3 / sse2 / none>\tHighest reference tier to reproduce.");
+    puts("\t--cpu-core <uint>\t\tPin the host thread to a CPU core.");
     puts("\t--mode <enc-quant / enc-quant32 / enc-quant-stereo>\tOnly execute a specified mode (repeatable).");
     puts("\t--resident\t\t\tKeep input and output in HBM (device pointers through the same API).");
     puts("\t--pin\t\t\t\tPage-lock the host buffers once (mdct_shim_pin): host-pointer calls then DMA in place.");
@@ -115,7 +118,7 @@ int main(int argc, char **argv)
   size_t runs = 128; // main.cpp:21
   float quality = 1.0f;
   bool resident = false, pin = false;
-  int device = 0, max_simd = 2;
+  int device = 0, max_simd = MDCT_SIMD_AVX2;
   bool m_encq = false, m_q32 = false, m_stereo = false;
   for (int i = 4; i < argc; i++)
   {
@@ -137,8 +140,21 @@ int main(int argc, char **argv)
     }
     else if (a == "--max-simd")
     {
+      // the reference's spellings (main.cpp:87-97); each caps the tier like its flag clearing does (:283-438)
       const std::string m = next();
-      max_simd = (m == "none") ? 0 : ((m == "sse2" || m == "ssse3" || m == "sse3" || m == "sse41" || m == "sse42" || m == "avx") ? 1 : 2);
+      if (m == "avx512bw" || m == "avx512f" || m == "avx2") max_simd = MDCT_SIMD_AVX2;
+      else if (m == "avx" || m == "sse4.2" || m == "sse4.1") max_simd = MDCT_SIMD_SSE41;
+      else if (m == "ssse3") max_simd = MDCT_SIMD_SSSE3;
+      else if (m == "sse3" || m == "sse2") max_simd = MDCT_SIMD_SSE2;
+      else if (m == "none") max_simd = MDCT_SIMD_NONE;
+      else { printf("Invalid SIMD Variant '%s' specified.", m.c_str()); return 1; }
+    }
+    else if (a == "--cpu-core")
+    { // main.cpp:239-259: pin the calling (host) thread, for steadier host-pointer timings
+      cpu_set_t set;
+      CPU_ZERO(&set);
+      CPU_SET((int)strtoull(next(), nullptr, 10), &set);
+      pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
     }
     else { printf("Invalid Parameter '%s'. Aborting.", a.c_str()); return 1; }
   }
@@ -181,7 +197,7 @@ int main(int argc, char **argv)
   mdct_get_device_info(&di);
   mdct_shim_set_max_simd(max_simd);
   printf("File: '%s' (%" PRIu64 " Bytes)\nDevice: '%s' (%d CUs, wave%d, %.0f GB HBM) via %s pointers, reference tier <= %s\n", filename.c_str(), (uint64_t)fileSize, di.name, di.compute_units,
-         di.wavefront_size, di.hbm_bytes / 1e9, resident ? "device" : "host", max_simd == 2 ? "AVX2" : (max_simd == 1 ? "SSE" : "scalar"));
+         di.wavefront_size, di.hbm_bytes / 1e9, resident ? "device" : "host", max_simd == MDCT_SIMD_AVX2 ? "AVX2" : (max_simd == MDCT_SIMD_SSE41 ? "SSE4.1" : (max_simd == MDCT_SIMD_SSSE3 ? "SSSE3" : (max_simd == MDCT_SIMD_SSE2 ? "SSE2" : "scalar"))));
 
   if (pin && !resident && (mdct_shim_pin(in.data(), fileSize) != 0 || mdct_shim_pin(out.data(), fileSize) != 0))
   {
