@@ -305,6 +305,22 @@ static int fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_
   constexpr float vr = .95f;
   for (int i = 0; i < 64; i++) // simd_dct.cpp:2239, :910 (x255 tiers) / :192 (scalar tiers)
     a.qt.q[i] = profile == MDCT_PROFILE_REF_SCALAR ? 1.f / (lut[i] * vr) : 255.0f / (lut[i] * vr);
+  const bool safe = profile != MDCT_PROFILE_REF_SCALAR && table_needs_safe(a.qt.q);
+  if (profile == MDCT_PROFILE_REF_AVX)
+  { // the packed-fp32 kernel wants the multipliers in its register-pair order, negated for the fast quantiser
+    static const int pa[4] = {0, 2, 1, 5}, pb[4] = {4, 6, 3, 7}; // == mdct::kPairA / kPairB
+    float t[64];
+    for (int v = 0; v < 8; v++)
+      for (int j = 0; j < 4; j++)
+      {
+        t[(v * 4 + j) * 2] = a.qt.q[v * 8 + pa[j]];
+        t[(v * 4 + j) * 2 + 1] = a.qt.q[v * 8 + pb[j]];
+      }
+    for (int i = 0; i < 64; i++)
+      a.qt.q[i] = safe ? t[i] : -t[i];
+    const mdct::DctConsts &c = a.consts;
+    a.pk = mdct::PkConstsArg{{c.a, c.f}, {c.c, c.d}, {c.b, c.e}, {c.n, c.magic23 + 128.0f}};
+  }
   a.pitch = pitch_in;
   a.sizeX = sizeX;
   a.out_strip = pitch_out ? pitch_out : 8 * sizeX;
@@ -318,7 +334,6 @@ static int fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_
   if ((r = count_blocks(sizeX / 8, rows, &a.nblocks)))
     return r;
   a.spill_ok = by1 * 8 * sizeX + 64 <= sizeX * sizeY;
-  const bool safe = profile != MDCT_PROFILE_REF_SCALAR && table_needs_safe(a.qt.q);
   const hipError_t e = mdct::launch_fwd_quant_u8(a, layout, profile, safe, (hipStream_t)stream);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "u8 kernel launch");
 }

@@ -57,11 +57,19 @@ struct OwnTables
   float dq[64];
 };
 
+// B1 on packed fp32: the butterfly constants as the register pairs the kernel consumes
+// (Ca,Cf) (Cc,Cd) (Cb,Ce) (Cn, rounding constant 1.5*2^23 + 128), see encode_block_avx_pk
+struct PkConstsArg
+{
+  float af[2], cd[2], be[2], nm[2];
+};
+
 struct U8Args
 {
   const uint8_t *from;
   uint8_t *to;
-  QuantTable qt;
+  QuantTable qt;       // REF_AVX: in the packed kernel's pair order (mdct_api.hip)
+  PkConstsArg pk;      // REF_AVX only
   DctConsts consts;
   size_t pitch;        // input row pitch, bytes
   size_t sizeX;        // plane width, bytes (output addressing)

@@ -177,6 +177,103 @@ __device__ __forceinline__ void pass_cols(const DctConsts &C, float (&b)[8][8])
 }
 
 // ---------------------------------------------------------------------------------------
+// K_AVX on packed fp32 (v_pk_add_f32 / v_pk_mul_f32): 28 instead of 56 instructions per 8-point
+// transform, identical bits.  Each half of a packed op is an individually rounded IEEE op, and
+// a + (-b) == a - b, so only the instruction count changes; on gfx950 a packed op issues in
+// ~5 cycles against ~2.7 for each of the two scalar ops it replaces, and at fewer than 8 waves
+// per SIMD the gap is wider (profiles/r01_valubench2.log, profiles/r02_q32_variants.md).
+//
+// Row pass ("horizontal"): the 8 values of one block row sit in 4 adjacent register pairs
+// (p0,p1)(p2,p3)(p4,p5)(p6,p7).  op_sel picks which half of each source feeds each half of the
+// result and neg_lo/neg_hi negate per half, so every butterfly stage is ONE packed op producing
+// two DIFFERENT quantities of simd_dct.cpp:2160-2183:
+//   (x07p,x16p) (x25p,x34p) (x07m,x61m) (x25m,x43m) (pp,qp) (pm,qm) (o0,o4) (o2,o6)
+//   (t1,t3) (t5,t7) (u1,u3) (u5,u7) (o1,o3) (o5,o7)
+// The outputs come out paired (0,4)(2,6)(1,3)(5,7) along u, identically for every row, so the
+// column pass ("vertical", simd_dct.cpp:2189-2215) is the plain butterfly on 4 column pairs.
+// No register moves anywhere.  Written as inline asm: the compiler folds only trivial
+// shuffles into op_sel and materialises the rest as v_mov / extra packed ops.
+// ---------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define MDCT_PKA(d, a, b, mods) asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b))
+#define MDCT_PKM(d, a, k, mods) asm("v_pk_mul_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "s"(k))
+// halves of the constant operand (src1) used for (lo, hi) of the result
+#define MDCT_K_LL "op_sel:[0,0] op_sel_hi:[1,0]"
+#define MDCT_K_HH "op_sel:[0,1] op_sel_hi:[1,1]"
+#define MDCT_K_LH "op_sel:[0,0] op_sel_hi:[1,1]"
+#define MDCT_K_HL "op_sel:[0,1] op_sel_hi:[1,0]"
+#define MDCT_X "op_sel:[0,1] op_sel_hi:[1,0]" // lo = a.lo (+) b.hi, hi = a.hi (+) b.lo
+#define MDCT_NEG_B "neg_lo:[0,1] neg_hi:[0,1]"  // a - b in both halves
+
+struct PkConsts
+{
+  f32x2 af, cd, be, nm; // (Ca,Cf) (Cc,Cd) (Cb,Ce) (Cn, rounding constant)
+};
+
+static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernels.h) is the kernel-argument image of PkConsts");
+
+// one block row held in 4 pairs -> (o0,o4) (o2,o6) (o1,o3) (o5,o7), each already times Cn
+__device__ __forceinline__ void dct8_avx_h(const PkConsts &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o13, f32x2 &o57)
+{
+  f32x2 s1, s2, d, e, pqp, pqm, r, t, m1, m2, m3, m4, n1, n2, n3, n4, t13, t57, u13, u57;
+  MDCT_PKA(s1, a01, a67, MDCT_X);                                  // (p0+p7, p1+p6)
+  MDCT_PKA(s2, a23, a45, MDCT_X);                                  // (p2+p5, p3+p4)
+  MDCT_PKA(d, a01, a67, MDCT_X " neg_lo:[0,1] neg_hi:[1,0]");      // (p0-p7, p6-p1)
+  MDCT_PKA(e, a23, a45, MDCT_X " neg_lo:[0,1] neg_hi:[1,0]");      // (p2-p5, p4-p3)
+  MDCT_PKA(pqp, s1, s2, MDCT_X);                                   // (x07p+x34p, x16p+x25p)
+  MDCT_PKA(pqm, s1, s2, MDCT_X " " MDCT_NEG_B);                    // (x07p-x34p, x16p-x25p)
+  MDCT_PKA(o04, pqp, pqp, "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]"); // (pp+qp, pp-qp)
+  MDCT_PKM(r, pqm, K.be, MDCT_K_LL);                               // (Cb pm, Cb qm)
+  MDCT_PKM(t, pqm, K.be, MDCT_K_HH);                               // (Ce pm, Ce qm)
+  MDCT_PKA(o26, r, t, MDCT_X " neg_hi:[1,0]");                     // (Cb pm + Ce qm, Ce pm - Cb qm)
+  MDCT_PKM(m1, d, K.af, MDCT_K_LH);                                // (Ca x07m, Cf x61m)
+  MDCT_PKM(m2, d, K.cd, MDCT_K_LL);                                // (Cc x07m, Cc x61m)
+  MDCT_PKM(m3, d, K.cd, MDCT_K_HH);                                // (Cd x07m, Cd x61m)
+  MDCT_PKM(m4, d, K.af, MDCT_K_HL);                                // (Cf x07m, Ca x61m)
+  MDCT_PKA(t13, m1, m2, MDCT_X " neg_lo:[0,1]");                   // (Ca x07m - Cc x61m, Cf x61m + Cc x07m)
+  MDCT_PKA(t57, m3, m4, MDCT_X);                                   // (Cd x07m + Ca x61m, Cd x61m + Cf x07m)
+  MDCT_PKM(n1, e, K.cd, MDCT_K_HH);                                // (Cd x25m, Cd x43m)
+  MDCT_PKM(n2, e, K.af, MDCT_K_LH);                                // (Ca x25m, Cf x43m)
+  MDCT_PKM(n3, e, K.af, MDCT_K_HL);                                // (Cf x25m, Ca x43m)
+  MDCT_PKM(n4, e, K.cd, MDCT_K_LL);                                // (Cc x25m, Cc x43m)
+  MDCT_PKA(u13, n1, n2, MDCT_X " neg_lo:[0,1]");                   // (Cd x25m - Cf x43m, Cd x43m + Ca x25m)
+  MDCT_PKA(u57, n3, n4, MDCT_X " neg_lo:[0,1]");                   // (Cf x25m - Cc x43m, Ca x43m + Cc x25m)
+  MDCT_PKA(o13, t13, u13, "neg_hi:[0,1]");                         // (t1 + u1, t3 - u3): the k=3 quirk of :2181
+  MDCT_PKA(o57, t57, u57, "");                                     // (t5 + u5, t7 + u7)
+  MDCT_PKM(o04, o04, K.nm, MDCT_K_LL);
+  MDCT_PKM(o26, o26, K.nm, MDCT_K_LL);
+  MDCT_PKM(o13, o13, K.nm, MDCT_K_LL);
+  MDCT_PKM(o57, o57, K.nm, MDCT_K_LL);
+}
+
+// the same transform down a column PAIR, p[r] = (B[r][u1], B[r][u2]), in place
+__device__ __forceinline__ void dct8_avx_v(const PkConsts &K, f32x2 (&p)[8])
+{
+  f32x2 x07p, x16p, x25p, x34p, x07m, x61m, x25m, x43m, pp, pm, qp, qm, o0, o4, a, b, o2, o6;
+  MDCT_PKA(x07p, p[0], p[7], ""); MDCT_PKA(x16p, p[1], p[6], ""); MDCT_PKA(x25p, p[2], p[5], ""); MDCT_PKA(x34p, p[3], p[4], "");
+  MDCT_PKA(x07m, p[0], p[7], MDCT_NEG_B); MDCT_PKA(x61m, p[6], p[1], MDCT_NEG_B);
+  MDCT_PKA(x25m, p[2], p[5], MDCT_NEG_B); MDCT_PKA(x43m, p[4], p[3], MDCT_NEG_B);
+  MDCT_PKA(pp, x07p, x34p, ""); MDCT_PKA(pm, x07p, x34p, MDCT_NEG_B);
+  MDCT_PKA(qp, x16p, x25p, ""); MDCT_PKA(qm, x16p, x25p, MDCT_NEG_B);
+  MDCT_PKA(o0, pp, qp, ""); MDCT_PKA(o4, pp, qp, MDCT_NEG_B);
+  MDCT_PKM(a, pm, K.be, MDCT_K_LL); MDCT_PKM(b, qm, K.be, MDCT_K_HH); MDCT_PKA(o2, a, b, "");          // Cb pm + Ce qm
+  MDCT_PKM(a, pm, K.be, MDCT_K_HH); MDCT_PKM(b, qm, K.be, MDCT_K_LL); MDCT_PKA(o6, a, b, MDCT_NEG_B);  // Ce pm - Cb qm
+  f32x2 t1, t3, t5, t7, u1, u3, u5, u7, c, dd;
+  MDCT_PKM(a, x07m, K.af, MDCT_K_LL); MDCT_PKM(b, x61m, K.cd, MDCT_K_LL); MDCT_PKA(t1, a, b, MDCT_NEG_B);   // Ca x07m - Cc x61m
+  MDCT_PKM(a, x07m, K.cd, MDCT_K_LL); MDCT_PKM(b, x61m, K.af, MDCT_K_HH); MDCT_PKA(t3, a, b, "");           // Cc x07m + Cf x61m
+  MDCT_PKM(a, x07m, K.cd, MDCT_K_HH); MDCT_PKM(b, x61m, K.af, MDCT_K_LL); MDCT_PKA(t5, a, b, "");           // Cd x07m + Ca x61m
+  MDCT_PKM(a, x07m, K.af, MDCT_K_HH); MDCT_PKM(b, x61m, K.cd, MDCT_K_HH); MDCT_PKA(t7, a, b, "");           // Cf x07m + Cd x61m
+  MDCT_PKM(c, x25m, K.cd, MDCT_K_HH); MDCT_PKM(dd, x43m, K.af, MDCT_K_HH); MDCT_PKA(u1, c, dd, MDCT_NEG_B); // Cd x25m - Cf x43m
+  MDCT_PKM(c, x25m, K.af, MDCT_K_LL); MDCT_PKM(dd, x43m, K.cd, MDCT_K_HH); MDCT_PKA(u3, c, dd, "");         // Ca x25m + Cd x43m
+  MDCT_PKM(c, x25m, K.af, MDCT_K_HH); MDCT_PKM(dd, x43m, K.cd, MDCT_K_LL); MDCT_PKA(u5, c, dd, MDCT_NEG_B); // Cf x25m - Cc x43m
+  MDCT_PKM(c, x25m, K.cd, MDCT_K_LL); MDCT_PKM(dd, x43m, K.af, MDCT_K_LL); MDCT_PKA(u7, c, dd, "");         // Cc x25m + Ca x43m
+  f32x2 o1, o3, o5, o7;
+  MDCT_PKA(o1, t1, u1, ""); MDCT_PKA(o3, t3, u3, MDCT_NEG_B); MDCT_PKA(o5, t5, u5, ""); MDCT_PKA(o7, t7, u7, "");
+  MDCT_PKM(p[0], o0, K.nm, MDCT_K_LL); MDCT_PKM(p[1], o1, K.nm, MDCT_K_LL); MDCT_PKM(p[2], o2, K.nm, MDCT_K_LL); MDCT_PKM(p[3], o3, K.nm, MDCT_K_LL);
+  MDCT_PKM(p[4], o4, K.nm, MDCT_K_LL); MDCT_PKM(p[5], o5, K.nm, MDCT_K_LL); MDCT_PKM(p[6], o6, K.nm, MDCT_K_LL); MDCT_PKM(p[7], o7, K.nm, MDCT_K_LL);
+}
+
+// ---------------------------------------------------------------------------------------
 // Quantisers.  They return a word whose LOW BYTE is the quantised coefficient (the upper
 // bits are not cleaned: every consumer stores or packs the low byte only).
 //
@@ -366,6 +463,58 @@ __device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *
   transform_quantise<PROFILE, LAYOUT, SAFE>(C, b, qt, out);
 }
 
+// B1 on packed fp32: raw bytes -> both passes -> quantise; out[v*8+u] = word whose low byte is the
+// stored byte (SAFE) or its complement (fast form, see below).  `qt` holds the multipliers in PAIR
+// ORDER, (v*4+j)*2 + {0,1} = coefficient (v, kPairA[j]) / (v, kPairB[j]), already negated for the
+// fast form (mdct_api.hip).
+//
+// Fast form of clamp(127 + rne(v), 0, 255), |v| < 2^31 (simd_dct.cpp:2224): rne is odd-symmetric, so
+// 127 + rne(v) = 255 - (rne(-v) + 128); -v = f * (-q) exactly; clamp -v to [-128, 127] and add
+// 1.5*2^23 + 128 (even, so ties round as before): the low byte of that float is rne(-v) + 128, and
+// the stored byte is its complement.  The complement is applied to whole dwords after the LDS
+// reorder (4 v_not per lane instead of 64 integer adds).
+constexpr int kPairA[4] = {0, 2, 1, 5}, kPairB[4] = {4, 6, 3, 7};
+template <bool SAFE>
+__device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uint2 (&rows)[8], const QuantTable &qt, uint32_t (&out)[64])
+{
+  f32x2 col[4][8]; // col[j][r] = (B[r][kPairA[j]], B[r][kPairB[j]]) after the row pass
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    const f32x2 a01 = {ubyte_to_float<0>(rows[r].x), ubyte_to_float<1>(rows[r].x)}; // :2143, raw 0..255
+    const f32x2 a23 = {ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
+    const f32x2 a45 = {ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)};
+    const f32x2 a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
+    dct8_avx_h(K, a01, a23, a45, a67, col[0][r], col[1][r], col[2][r], col[3][r]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    dct8_avx_v(K, col[j]);
+#pragma unroll
+    for (int v = 0; v < 8; v++)
+    {
+      const f32x2 qp = reinterpret_cast<const f32x2 *>(qt.q)[v * 4 + j];
+      f32x2 m;
+      MDCT_PKM(m, col[j][v], qp, MDCT_K_LH);
+      if constexpr (SAFE)
+      {
+        out[v * 8 + kPairA[j]] = (uint32_t)clamp255((int32_t)((uint32_t)cvtps_epi32_exact(m.x) + 127u));
+        out[v * 8 + kPairB[j]] = (uint32_t)clamp255((int32_t)((uint32_t)cvtps_epi32_exact(m.y) + 127u));
+      }
+      else
+      {
+        f32x2 t;
+        m.x = __builtin_amdgcn_fmed3f(m.x, -128.0f, 127.0f);
+        m.y = __builtin_amdgcn_fmed3f(m.y, -128.0f, 127.0f);
+        MDCT_PKA(t, m, K.nm, MDCT_K_HH); // + (magic, magic)
+        out[v * 8 + kPairA[j]] = __float_as_uint(t.x);
+        out[v * 8 + kPairB[j]] = __float_as_uint(t.y);
+      }
+    }
+  }
+}
+
 // four low bytes -> one dword, upper bits of the inputs ignored (3 x v_perm_b32)
 __device__ __forceinline__ uint32_t pack4_lo8(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
@@ -378,13 +527,97 @@ constexpr int kWG = 256;           // 4 waves
 constexpr int kQ32RowStride = 72;  // 64 lanes + 8 pad: keeps rows 8-byte aligned for ds_read_b64
 constexpr int kStereoRowStride = kWG + 16; // 256 blocks + pad, rows stay 16-byte aligned for ds_read_b128
 
-// Occupancy: the Q32 instantiation is asked to fit 6 waves/SIMD (80 VGPRs, 8 B of scratch):
-// measured -6 % kernel time vs the unconstrained 98 VGPRs / 5 waves; the other layouts spill
-// badly under the same bound and are left alone (profiles/r01_occupancy_variants.log).
+// ---------------------------------------------------------------------------------------
+// B1 (simd_dct.cpp:2064-2262): the reference's primary product, its own kernel.
+// Output of 8 consecutive blocks (one reference "group") is 512 contiguous bytes
+// [coef*8 + blk] (:2227-2230) and group G of the plane sits at G*512, so a wave's 64 blocks
+// cover 4096 contiguous output bytes.  They are staged through wave-private LDS as rows
+// [coef][lane] so that every lane then stores 16 contiguous bytes.  No workgroup barrier:
+// only the wave that wrote a row reads it.  Everything that is live across the transform is
+// wave-uniform (SGPRs), which is what lets the fast form fit 6 waves/SIMD (80 VGPRs).
+// ---------------------------------------------------------------------------------------
+#ifndef MDCT_Q32_MINW
+#define MDCT_Q32_MINW 6
+#endif
+// GENERAL = false: the launch is a whole number of waves and the output strips are tight (the host
+// checks), so nothing is guarded; GENERAL = true adds the partial last wave and pitched strips.
+template <bool SAFE, bool GENERAL>
+__global__ __launch_bounds__(kWG, (SAFE || GENERAL) ? 1 : MDCT_Q32_MINW) void k_q32_avx(U8Args a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWG / 64][64 * kQ32RowStride];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t wave_t0 = blockIdx.x * kWG + wave * 64; // first block of this wave within the launch
+  if (wave_t0 >= a.nblocks) // whole waves past the end of the launch (the grid is in workgroups of 4 waves)
+    return;
+  uint32_t wave_blocks = 64, t = wave_t0 + lane;
+  if constexpr (GENERAL)
+  {
+    wave_blocks = min(64u, a.nblocks - wave_t0);
+    t = wave_t0 + min(lane, wave_blocks - 1); // lanes past the end redo the last block; their bytes are never read back
+  }
+  uint32_t q[64];
+  {
+    const uint32_t row = t / a.bpr;
+    const uint32_t bx = t - row * a.bpr;
+    uint2 rows[8];
+    load_block_rows(a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)bx * 8, a.pitch, rows);
+    encode_block_avx_pk<SAFE>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
+  }
+  uint8_t *wl = lds[wave];
+#pragma unroll
+  for (int c = 0; c < 64; c++)
+    wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  uint8_t *outw = a.to + ((size_t)a.by0 * a.bpr + wave_t0) * 64; // == first group * 512
+  const uint32_t c2 = (lane & 31) * 2;
+  auto staged = [&](uint32_t g) { // coefficients c2, c2+1 of group g: 16 contiguous output bytes
+    const uint2 lo = *reinterpret_cast<const uint2 *>(wl + c2 * kQ32RowStride + g * 8);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(wl + (c2 + 1) * kQ32RowStride + g * 8);
+    u32x4_t v = {lo.x, lo.y, hi.x, hi.y};
+    if constexpr (!SAFE)
+      v = ~v; // the fast quantiser staged complemented bytes (encode_block_avx_pk)
+    return v;
+  };
+  if constexpr (!GENERAL)
+  { // four unguarded 1 KiB stores
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const uint32_t g = 2 * k + (lane >> 5);
+      __builtin_nontemporal_store(staged(g), reinterpret_cast<u32x4_t *>(outw + g * 512 + c2 * 8));
+    }
+    return;
+  }
+  // partial last wave and / or pitched strips (mdct_fwd_quant_u8_pitched)
+  const uint32_t wave_groups = wave_blocks >> 3; // nblocks % 8 == 0
+#pragma unroll 1
+  for (int k = 0; k < 4; k++)
+  {
+    const uint32_t g = 2 * k + (lane >> 5);
+    if (g < wave_groups)
+    {
+      uint8_t *dst = outw + g * 512 + c2 * 8;
+      if (!a.out_tight)
+      { // group G of the launch -> (block row, group x)
+        const uint32_t G = (wave_t0 >> 3) + g, gpr = a.bpr >> 3;
+        const uint32_t grow = G / gpr;
+        dst = a.to + (size_t)(a.by0 + grow) * a.out_strip + (size_t)(G - grow * gpr) * 512 + c2 * 8;
+      }
+      __builtin_nontemporal_store(staged(g), reinterpret_cast<u32x4_t *>(dst));
+    }
+  }
+}
+
+// The other tiers / layouts.
 #ifdef MDCT_U8_WAVES
 #define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8_WAVES, MDCT_U8_WAVES)))
 #else
-#define MDCT_U8_ATTR __launch_bounds__(kWG, (LAYOUT == MDCT_LAYOUT_Q32 && !SAFE) ? 6 : 1)
+#define MDCT_U8_ATTR __launch_bounds__(kWG)
 #endif
 template <int PROFILE, int LAYOUT, bool SAFE>
 __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
@@ -428,51 +661,7 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
     encode_block<PROFILE, LAYOUT, SAFE>(a.consts, src, a.pitch, a.qt, px_div255, q);
   }
 
-  if constexpr (LAYOUT == MDCT_LAYOUT_Q32)
-  {
-    // Output of 8 consecutive blocks (one reference "group") is 512 contiguous bytes
-    // [coef*8 + blk] (:2227-2230) and group G of the plane sits at G*512, so a wave's
-    // 64 blocks cover 4096 contiguous output bytes.  Stage them through wave-private
-    // LDS as rows [coef][lane] so that every lane then stores 16 contiguous bytes.
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kWG / 64][64 * kQ32RowStride];
-    uint8_t *wl = lds[threadIdx.x >> 6];
-    if (valid)
-    {
-#pragma unroll
-      for (int c = 0; c < 64; c++)
-        wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    const uint32_t wave_t0 = t - lane;                                   // first block of this wave
-    const uint32_t wave_blocks = wave_t0 < a.nblocks ? min(64u, a.nblocks - wave_t0) : 0u;
-    const uint32_t wave_groups = wave_blocks >> 3;                        // nblocks % 8 == 0
-    uint8_t *outw = a.to + ((size_t)a.by0 * a.bpr + wave_t0) * 64;         // == first group * 512
-    const uint32_t c2 = (lane & 31) * 2;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-    {
-      const uint32_t g = 2 * k + (lane >> 5);
-      if (g < wave_groups)
-      {
-        const uint2 lo = *reinterpret_cast<const uint2 *>(wl + c2 * kQ32RowStride + g * 8);
-        const uint2 hi = *reinterpret_cast<const uint2 *>(wl + (c2 + 1) * kQ32RowStride + g * 8);
-        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-        const u32x4_t v = {lo.x, lo.y, hi.x, hi.y};
-        uint8_t *dst = outw + g * 512 + c2 * 8;
-        if (!a.out_tight)
-        { // pitched strips (mdct_fwd_quant_u8_pitched): group G of the launch -> (block row, group x)
-          const uint32_t G = (wave_t0 >> 3) + g, gpr = a.bpr >> 3;
-          const uint32_t grow = G / gpr;
-          dst = a.to + (size_t)(a.by0 + grow) * a.out_strip + (size_t)(G - grow * gpr) * 512 + c2 * 8;
-        }
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(dst));
-      }
-    }
-  }
-  else if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
+  if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
   {
     // 64 coefficient planes; block t of the launch lands at byte (by0*2*bpr + t) of every plane
     // (:1061-1099), so a full workgroup owns 256 consecutive bytes per plane.  Stage them in LDS
@@ -921,7 +1110,19 @@ hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool sa
   if (a.nblocks == 0)
     return hipSuccess;
   if (layout == MDCT_LAYOUT_Q32 && profile == MDCT_PROFILE_REF_AVX)
-    return launch_u8_pl<MDCT_PROFILE_REF_AVX, MDCT_LAYOUT_Q32>(a, safe, s);
+  {
+    const bool general = a.nblocks % 64 != 0 || !a.out_tight;
+    const dim3 g(grid_for(a.nblocks)), b(kWG);
+    if (safe && general)
+      hipLaunchKernelGGL((k_q32_avx<true, true>), g, b, 0, s, a);
+    else if (safe)
+      hipLaunchKernelGGL((k_q32_avx<true, false>), g, b, 0, s, a);
+    else if (general)
+      hipLaunchKernelGGL((k_q32_avx<false, true>), g, b, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_q32_avx<false, false>), g, b, 0, s, a);
+    return hipGetLastError();
+  }
   if (layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SSE)
     return launch_u8_pl<MDCT_PROFILE_REF_SSE, MDCT_LAYOUT_STEREO>(a, safe, s);
   if (layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR)
