@@ -13,8 +13,11 @@ all-gather of the outputs (north_star's whole-node run) is timed separately and 
 under "allgather", never inside `value`.
 
 One JSON line on rank 0.  `roofline` is for the fused round-trip kernel, timed with HIP
-events on the launch stream; `cpu_baseline` times the oracle (a scalar C port, all host
-threads) on a bounded sample of the same workload.
+events on the launch stream; `roofline_u8` is the same for the reference's own hot path
+(u8 q32, simd_dct.cpp:2064-2262) on the same plane size; `cpu_baseline` times the oracle (a
+scalar C port, all host threads) on a bounded sample of the bench workload and, under
+`reference_q32`, the REAL reference's q32/AVX2 tier (oracle/_ref, when it travelled) on one
+pinned core and on all host threads over disjoint startY/endY ranges, as BASELINE.md 3 asks.
 """
 import argparse
 import json
@@ -82,23 +85,77 @@ def cpu_baseline(budget_s=12.0):
         "sample": f"oracle/dct_oracle.c orc_roundtrip_i16 (scalar C, -O2 -ffp-contract=off), {threads} threads x {reps} x "
                   f"{W}x{rows_per_thread} int16 stripes = {px / 1e6:.0f} Mpx in {dt:.1f} s",
     }
-    # the reference's own fastest path (u8 q32, AVX2) for orientation, when its build travelled
-    try:
-        if O.reference() is not None:
-            from simd_dct_amd.api import QUANTIZE_BASE
-
-            img = synth.plane_u8_np(W, 512, "photo").reshape(-1)
-            lut = (QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
-            o = np.zeros(W * 512, dtype=np.uint8)
-            best = 1e9
-            for _ in range(5):
-                t0 = time.perf_counter()
-                O.run_behaviour("q32_avx", img, lut, W, 1024, 0, 1024, out=o, use_reference=True)  # sizeY = 2H: whole stripe
-                best = min(best, time.perf_counter() - t0)
-            out["reference_q32_avx2_1core_Mpx_s"] = round(W * 512 / best / 1e6, 1)
-    except Exception as e:  # orientation only
-        out["reference_q32_error"] = str(e)[:120]
+    out["reference_q32"] = reference_q32_baseline(threads)
     return out
+
+
+def reference_q32_baseline(threads, runs=10, warmups=2):
+    """BASELINE.md 3 / SURVEY 8d: the reference's own q32 path (AVX2 tier, simd_dct.cpp:2064, pinned build
+    -O2 -ffp-contract=off) on the GPU box's host cores, whole 8192x8192 plane through the sizeY = 2H call
+    form: (i) ONE pinned core, (ii) ALL host threads, each pinned, over disjoint startY/endY ranges
+    (the reference's own multi-core hook, simd_dct.cpp:2245-2255; main.cpp:252-257 pins the same way).
+    2 warm-ups + >= 10 runs, min and mean +- sigma like print_perf_info (main.cpp:34-80), in Mpx/s of
+    pixels actually transformed.  Falls back to the oracle's restatement of that tier ("port") when
+    oracle/_ref did not travel."""
+    import statistics
+    import threading
+
+    import numpy as np
+
+    import oracle as O
+    from simd_dct_amd import synth
+    from simd_dct_amd.api import QUANTIZE_BASE
+
+    real = O.reference() is not None
+    img = np.ascontiguousarray(synth.plane_u8_np(W, H, "photo").reshape(-1))
+    lut = (QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
+    dst = np.zeros(W * H, dtype=np.uint8)
+    cpus = sorted(os.sched_getaffinity(0))
+    rows = H // 8
+
+    def call(b0, b1):
+        # block rows [b0, b1) in the reference's terms: processed iff startY <= 2y <= endY, y = 8*row
+        O.run_behaviour("q32_avx", img, lut, W, 2 * H, 16 * b0, 16 * b1 - 16, out=dst, use_reference=real)
+
+    def timed(nthreads):
+        cuts = [rows * i // nthreads for i in range(nthreads + 1)]
+        samples = []
+        for it in range(warmups + runs):
+            barrier = threading.Barrier(nthreads + 1)
+
+            def work(i):
+                try:
+                    os.sched_setaffinity(0, {cpus[i % len(cpus)]})  # pins the calling thread
+                except OSError:
+                    pass
+                barrier.wait()
+                call(cuts[i], cuts[i + 1])
+                barrier.wait()
+
+            ts = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+            for t in ts:
+                t.start()
+            barrier.wait()
+            t0 = time.perf_counter()
+            barrier.wait()
+            dt = time.perf_counter() - t0
+            for t in ts:
+                t.join()
+            if it >= warmups:
+                samples.append(W * H / dt / 1e6)
+        return {"threads": nthreads, "min_time_Mpx_s": round(max(samples), 1), "mean_Mpx_s": round(statistics.mean(samples), 1),
+                "sigma_Mpx_s": round(statistics.pstdev(samples), 1), "runs": runs, "warmups": warmups}
+
+    try:
+        cpu_model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), "?")
+    except OSError:
+        cpu_model = "?"
+    res = {"kind": "reference" if real else "port", "unit": "Mpixels/s",
+           "what": ("rainerzufalldererste/simd_dct simdDCT_EncodeQuantize32ReorderBuffer_AVX2_Float, g++ -O2 -ffp-contract=off" if real
+                    else "oracle/dct_oracle.c orc_q32_avx (scalar restatement of the AVX2 tier; oracle/_ref did not travel)"),
+           "sample": f"one {W}x{H} uint8 plane per run (sizeY = 2H call form, whole plane transformed), table x2000",
+           "cpu": cpu_model, "one_pinned_core": timed(1), "all_host_threads": timed(threads)}
+    return res
 
 
 def main():
@@ -168,6 +225,17 @@ def main():
         step(i)
     torch.cuda.synchronize()
     verified = all(torch.equal(s, d) for s, d in zip(srcs, dsts))
+    if dist is not None:  # every rank's planes, not just rank 0's
+        v = torch.tensor([1 if verified else 0], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        verified = bool(v.item())
+    if not verified:  # a broken kernel must not produce a headline number
+        if rank == 0:
+            print(json.dumps({"metric": "Mpixels/s 8x8 fwd+inv int16 DCT, 8192x8192 plane", "value": None, "unit": "Mpixels/s", "n_gpus": world,
+                              "error": "fused forward+inverse round trip is not bit-exact on at least one rank"}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        sys.exit(3)
 
     # Untimed pre-conditioning.  From idle the chip's power management overshoots for the first
     # ~400 launches (63 -> 47.3 us per launch, profiles/r01_transient_from_idle.log) and any idle
@@ -225,8 +293,21 @@ def main():
         lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
         u8s = [synth.plane_u8_torch(W, H, "photo", seed=synth.SEED + 50 + i).reshape(-1) for i in range(NSETS)]
         u8d = [d.view(torch.uint8).reshape(-1)[: W * H] for d in dsts]
+        # the reference's own hot path (u8 q32): checked against the oracle on a stripe, then timed like the others
+        q32_ok = None
+        try:
+            import oracle as O
+
+            M.fwd_quant_u8(u8s[0], u8d[0], lut, W, H, 0, H // 8)
+            torch.cuda.synchronize()
+            stripe = 64  # pixel rows
+            rc, want = O.q32_native(synth.plane_u8_np(W, H, "photo", seed=synth.SEED + 50)[:stripe], lut, W, stripe, 0, stripe // 8)
+            q32_ok = bool(np.array_equal(u8d[0][: W * stripe].cpu().numpy(), want))
+        except Exception as e:
+            q32_ok = f"not checked: {str(e)[:80]}"
         extras["fwd_quant_u8_q32"] = rate(prepared(lambda i: M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, H // 8)), 2 * W * H)
         extras["fwd_quant_u8_q32"]["Mpx_s"] = round(W * H / (extras["fwd_quant_u8_q32"]["ms"] * 1e-3) / 1e6, 0)
+        extras["fwd_quant_u8_q32"]["matches_oracle_on_first_stripe"] = q32_ok
         extras["roundtrip_frac_of_measured_copy"] = round(achieved / extras["stream_copy_roofline"]["GBps"], 3)
         # independent planes on two HIP streams: plane k+1's head overlaps plane k's drain
         # (an extra, never `value`: per-kernel durations and throughput differ once launches overlap)
@@ -262,22 +343,35 @@ def main():
 
     log("extras done")
     if dist is not None and not args.no_extras and args.backend == "nccl":
-        # north_star's whole-node run: every plane's block rows are sharded over the ranks, each rank
-        # transforms its shard (forward int16) and the coefficients are all-gathered over xGMI, in
-        # place (shards are contiguous slabs in rank order).  Three figures over the same NP planes:
-        # compute only, gather only, and pipelined (plane k's gather overlaps plane k+1's kernel:
-        # the collective is asynchronous on RCCL's stream).  Never part of `value`.
+        # north_star's whole-node run at configs[3]'s own shape: a batch of 256 independent 4096x4096 int16 planes,
+        # forward only, sharded over the ranks (whole planes: 256/N per rank -- the same bytes per rank as
+        # 64 of every plane's 512 block rows), coefficients all-gathered over xGMI so that every rank ends up
+        # with the whole batch.  Chunks of 8 planes: one launch per chunk (a stack of planes is one tall
+        # plane) writing straight into this rank's slot of the gather buffer, then an in-place
+        # all_gather_into_tensor of the chunk; pipelined = chunk k's gather (asynchronous, RCCL's stream)
+        # overlaps chunk k+1's kernel.  Three figures: compute only, gather only, pipelined.  Never `value`.
         try:
-            from simd_dct_amd.sharding import shard_rows
+            from simd_dct_amd.sharding import equal_shards, shard_planes
 
-            NP = NSETS
-            rows = H // 8
-            b0, b1 = shard_rows(rows, world, rank)
-            lo, hi = b0 * 8 * W * 2, b1 * 8 * W * 2
-            gath = [d.view(torch.uint8).reshape(-1) for d in dsts[:NP]]
-            fwd = [M.prepare_plane_i16("fwd", srcs[k], dsts[k], W, H, by0=b0, by1=b1) for k in range(NP)]
+            PW = PH = 4096
+            NPL = 256
+            if not equal_shards(NPL, world):
+                raise RuntimeError(f"{NPL} planes do not split evenly over {world} ranks (all_gather_into_tensor needs equal shards)")
+            del srcs, dsts, steps  # 2 x 8 GiB are needed below
+            torch.cuda.empty_cache()
+            p0, p1 = shard_planes(NPL, world, rank)
+            per = p1 - p0
+            chunk = min(8, per)
+            nch = per // chunk
+            src4 = torch.empty((per * PH, PW), dtype=torch.int16, device="cuda")
+            for i in range(per):
+                src4[i * PH:(i + 1) * PH] = synth.plane_i16_torch(PW, PH, "photo", seed=synth.SEED + 1000 + p0 + i)
+            gbuf = torch.zeros((nch, world, chunk * PH, PW), dtype=torch.int16, device="cuda")  # [chunk][owner rank][planes of the chunk]
+            fwd = [M.prepare_plane_i16("fwd", src4[c * chunk * PH:(c + 1) * chunk * PH], gbuf[c, rank], PW, chunk * PH) for c in range(nch)]
+            flat = [gbuf[c].view(torch.uint8).reshape(-1) for c in range(nch)]
+            mine = [gbuf[c, rank].view(torch.uint8).reshape(-1) for c in range(nch)]
 
-            def timed(body, reps=5):
+            def timed(body, reps=3):
                 body()
                 torch.cuda.synchronize()
                 dist.barrier()
@@ -286,30 +380,42 @@ def main():
                     body()
                 torch.cuda.synchronize()
                 dist.barrier()
-                return (time.perf_counter() - t0) / reps / NP
+                t = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return t.item()
 
             def compute_only():
-                for k in range(NP):
-                    fwd[k]()
+                for c in range(nch):
+                    fwd[c]()
 
             def gather_only():
-                for k in range(NP):
-                    dist.all_gather_into_tensor(gath[k], gath[k][lo:hi])
+                for c in range(nch):
+                    dist.all_gather_into_tensor(flat[c], mine[c])
 
             def pipelined():
                 works = []
-                for k in range(NP):
-                    fwd[k]()
-                    works.append(dist.all_gather_into_tensor(gath[k], gath[k][lo:hi], async_op=True))
+                for c in range(nch):
+                    fwd[c]()
+                    works.append(dist.all_gather_into_tensor(flat[c], mine[c], async_op=True))
                 for w in works:
                     w.wait()
 
             tc, tg, tp = timed(compute_only), timed(gather_only), timed(pipelined)
-            plane_bytes = W * H * 2
-            allgather = {"what": f"{NP} planes of 8192x8192 int16, block rows sharded over {world} ranks, forward + in-place all_gather_into_tensor (RCCL)",
-                         "ms_per_plane": {"compute_only": round(tc * 1e3, 4), "gather_only": round(tg * 1e3, 4), "pipelined": round(tp * 1e3, 4)},
-                         "Mpx_s_pipelined": round(W * H / tp / 1e6, 0),
-                         "busbw_GBps_gather_only": round((world - 1) / world * plane_bytes / tg / 1e9, 1)}
+            # every slot every rank now holds must be what its owner computed: compare checksums of all slots
+            sums = gbuf.to(torch.int64).sum(dim=(2, 3))  # [chunk][owner]
+            own = sums[:, rank].contiguous()
+            allown = [torch.empty_like(own) for _ in range(world)]
+            dist.all_gather(allown, own)
+            gathered_ok = all(torch.equal(sums[:, r], allown[r]) for r in range(world))
+            batch_px = NPL * PW * PH
+            out_bytes = batch_px * 2
+            allgather = {"what": f"configs[3]: {NPL} planes of {PW}x{PH} int16, forward only, {per} planes per rank in chunks of {chunk}, "
+                                 f"in-place all_gather_into_tensor (RCCL) of every chunk to all {world} ranks",
+                         "seconds_per_batch": {"compute_only": round(tc, 5), "gather_only": round(tg, 5), "pipelined": round(tp, 5)},
+                         "Mpx_s_whole_batch_pipelined": round(batch_px / tp / 1e6, 0), "Mpx_s_compute_only": round(batch_px / tc / 1e6, 0),
+                         "busbw_GBps_gather_only": round((world - 1) / world * out_bytes / tg / 1e9, 1),
+                         "gathered_checksums_match_owners": bool(gathered_ok)}
+            del src4, gbuf
         except Exception as e:
             allgather = {"error": str(e)[:200]}
 
@@ -317,8 +423,8 @@ def main():
         line = {
             "metric": "Mpixels/s 8x8 fwd+inv int16 DCT, 8192x8192 plane",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "io_dtype": "int16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: single 8192x8192 int16 plane per GPU, forward+inverse 8x8 DCT fused in one kernel",
                        "plane": [W, H], "io": "int16", "planes_per_step_per_gpu": 1, "rotating_plane_sets": NSETS, "untimed_preconditioning_launches": PRECONDITION,
                        "parallelism": f"independent planes x{world}" if world > 1 else "single GPU", "device": info["name"]},
@@ -327,14 +433,28 @@ def main():
                          "algorithmic_bytes_per_launch": px_per_step * ALG_BYTES_PER_PX, "avg_launch_ms": round(kernel_ms, 4)},
             "bit_exact_roundtrip_verified": verified,
         }
+        traffic = {}
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr):
             try:
-                line["roofline"]["traffic"] = json.load(open(tr)).get("k_i16_roundtrip_bytes_per_launch")
+                traffic = json.load(open(tr))
+                line["roofline"]["traffic"] = traffic.get("k_i16_roundtrip_bytes_per_launch")
+                line["roofline"]["traffic_source"] = "profiles/traffic.json (PMC passes of an earlier run of the same kernel, not counters of this run): " + traffic.get("source", "")
             except Exception:
                 pass
         if extras:
             line["extras"] = extras
+            q = extras.get("fwd_quant_u8_q32")
+            if q and "GBps" in q:
+                # the reference's own hot path on the same plane size: 2 algorithmic bytes per pixel
+                copy = extras.get("stream_copy_roofline", {}).get("GBps")
+                line["roofline_u8"] = {"bound": "hbm (co-limited by un-fusable fp32 VALU work, DESIGN.md 4.1)", "kernel": "mdct::k_q32_avx<false, false>",
+                                       "reference": "simdDCT_EncodeQuantize32ReorderBuffer, AVX2 tier, simd_dct.cpp:2064-2262", "achieved": q["GBps"], "peak": HBM_PEAK_GBPS,
+                                       "unit": "GB/s", "frac": round(q["GBps"] / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(q["GBps"] / copy, 3) if copy else None,
+                                       "algorithmic_bytes_per_launch": 2 * W * H, "avg_launch_ms": q["ms"], "Mpx_s": q.get("Mpx_s"),
+                                       "traffic": traffic.get("k_q32_avx_bytes_per_launch"),
+                                       "traffic_source": "profiles/traffic.json: " + traffic.get("source_q32", traffic.get("source", "")) if traffic else None,
+                                       "bit_exact_vs_oracle": q.get("matches_oracle_on_first_stripe")}
         if allgather:
             line["allgather"] = allgather
         if world == 1 and not args.no_cpu_baseline:

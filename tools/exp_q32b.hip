@@ -567,39 +567,29 @@ __global__ __launch_bounds__(256, MINW) void v_pk_dma2(U8Args a, XPkConsts K, Pk
 }
 
 
-// ---- where does the pk kernel's time go: REPS transforms per tile (1 load, 1 store), or no stores / no loads
-template <int REPS>
-__global__ __launch_bounds__(256, 6) void v_pk_compute(U8Args a, XPkConsts K, PkQuant Q)
+// ---- VALU floor of the packed transform: REPS x (load + transform + quantise) on the same tile (L2 hits after the
+// first), results folded into 16 bytes; (t(REPS=3) - t(REPS=1)) / 2 is one compute pass with HBM out of the picture
+template <int REPS, int MINW>
+__global__ __launch_bounds__(256, MINW) void v_pk_reps(U8Args a, XPkConsts K, PkQuant Q)
 {
   const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63;
   const uint32_t row = t / a.bpr, bx = t - row * a.bpr;
   const uint8_t *src = a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)bx * 8;
-  __shared__ __attribute__((aligned(16))) uint8_t lds[4][64 * kQ32RowStride];
-  uint8_t *wl = lds[threadIdx.x >> 6];
-  uint2 rows[8];
-  load_block_rows(src, a.pitch, rows);
-  uint32_t q[64];
+  uint4 acc = make_uint4(0, 0, 0, 0);
 #pragma unroll 1
   for (int i = 0; i < REPS; i++)
   {
+    uint2 rows[8];
+    load_block_rows(src + (acc.x & 8), a.pitch, rows); // address depends on the previous repetition
+    uint32_t q[64];
     transform_quant_pk(K, Q, rows, q);
-    if (i + 1 < REPS)
-    { // feed the result back so that no repetition can be dropped, and pay the LDS reorder every time
 #pragma unroll
-      for (int c = 0; c < 64; c++)
-        wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int r = 0; r < 8; r++)
-        rows[r] = *reinterpret_cast<const uint2 *>(wl + (8 * r) * kQ32RowStride + (lane & 56));
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < 64; c += 4)
+    {
+      acc.x ^= q[c]; acc.y ^= q[c + 1]; acc.z ^= q[c + 2]; acc.w ^= q[c + 3];
     }
   }
-  reorder_store<true>(wl, q, lane, lane, a.to + ((size_t)a.by0 * a.bpr + (t - lane)) * 64);
+  *reinterpret_cast<uint4 *>(a.to + (size_t)t * 64) = acc;
 }
 
 // ---- memory-only shapes: what do 8 B/lane vs 16 B/lane non-temporal row loads cost with no arithmetic?
@@ -697,9 +687,13 @@ int main(int argc, char **argv)
   vs.push_back({"pk dma2 5w 2pass grid 1280", [&](int s) { hipLaunchKernelGGL((v_pk_dma2<5, 2>), dim3(1280), dim3(256), 0, 0, args(a, s), PK, PQ, ntiles); }, {}, true});
   vs.push_back({"pk dma2 6w 2pass grid 1536", [&](int s) { hipLaunchKernelGGL((v_pk_dma2<6, 2>), dim3(1536), dim3(256), 0, 0, args(a, s), PK, PQ, ntiles); }, {}, true});
   vs.push_back({"pk dma2 6w 4pass grid 1536", [&](int s) { hipLaunchKernelGGL((v_pk_dma2<6, 4>), dim3(1536), dim3(256), 0, 0, args(a, s), PK, PQ, ntiles); }, {}, true});
-  vs.push_back({"pk compute x1", [&](int s) { hipLaunchKernelGGL((v_pk_compute<1>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
-  vs.push_back({"pk compute x2", [&](int s) { hipLaunchKernelGGL((v_pk_compute<2>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
-  vs.push_back({"pk compute x4", [&](int s) { hipLaunchKernelGGL((v_pk_compute<4>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
+  vs.push_back({"pk reps x1 6w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<1, 6>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
+  vs.push_back({"pk reps x3 6w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<3, 6>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
+  vs.push_back({"pk reps x5 6w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<5, 6>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
+  vs.push_back({"pk reps x1 5w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<1, 5>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
+  vs.push_back({"pk reps x3 5w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<3, 5>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
+  vs.push_back({"pk reps x1 4w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<1, 4>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
+  vs.push_back({"pk reps x3 4w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<3, 4>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
   // correctness of every variant against the product kernel's bytes
   {
     std::vector<uint8_t> ref(bytes), got(bytes);
