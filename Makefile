@@ -5,14 +5,15 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := simd_dct_amd/csrc
 LIB     := simd_dct_amd/libmdct_hip.so
-# -ffp-contract=off: bit-exactness contract (no FMA).  -fno-slp-vectorize: packed fp32 is half rate on gfx950.
+# -ffp-contract=off: bit-exactness contract (no FMA).  -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar ops
+# with v_mov shuffles; where packing pays (the q32 butterflies) it is written by hand.
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -Wall -Iinclude -I$(CSRC)
 
 all: lib cli oracle
 
 lib: $(LIB)
-$(LIB): $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/mdct_kernels.h include/mdct.h include/simd_dct_shim.h
-	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip -o $@
+$(LIB): $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/mdct_kernels.h include/mdct.h include/simd_dct_shim.h
+	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip -ldl -o $@
 
 cli: tools/simd_dct_cli
 tools/simd_dct_cli: tools/simd_dct_cli.cpp $(LIB)

@@ -145,6 +145,38 @@ typedef struct mdct_plane_i16
 } mdct_plane_i16;
 int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *stream);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------------
+ * The reference has no communication; its only parallelism hook is the caller-side row range
+ * startY/endY (simd_dct.cpp:2245-2255).  Here: every rank transforms its block-row shard in place
+ * in a full-size output buffer (any entry point above with [by0, by1) = mdct_shard_rows(...)), then
+ * one all-gather makes every rank's buffer complete.  RCCL is loaded on first use (librccl.so.1).
+ *
+ * mdct_shard_rows: contiguous, balanced, half-open shard of `n_rows` block rows for `rank`; shards are
+ * in rank order and differ by at most one row (same arithmetic as simd_dct_amd/sharding.py). */
+void mdct_shard_rows(size_t n_rows, int world, int rank, size_t *b0, size_t *b1);
+/* The stereo layout (simd_dct.cpp:1061-1099) scatters a block-row shard over all 64 coefficient
+ * planes: rank `rank` owns `piece_bytes` bytes at `first_offset + k * plane_stride`, k = 0..63.
+ * Pure arithmetic (no device); mdct_allgather_stereo moves exactly these pieces. */
+int mdct_stereo_shard_piece(size_t sizeX, size_t sizeY, int world, int rank,
+                            size_t *first_offset, size_t *plane_stride, size_t *piece_bytes);
+#define MDCT_UNIQUE_ID_BYTES 128
+typedef struct mdct_comm mdct_comm;
+/* rank 0 creates the id and hands its 128 bytes to the other ranks out of band (file, pipe, MPI, ...) */
+int mdct_comm_get_unique_id(void *id128);
+/* collective over all `world` ranks; binds the calling thread's current HIP device (call mdct_init first) */
+int mdct_comm_init(mdct_comm **comm, int rank, int world, const void *id128);
+int mdct_comm_destroy(mdct_comm *comm);
+int mdct_comm_rank(const mdct_comm *comm);
+int mdct_comm_world(const mdct_comm *comm);
+/* Row-strip layouts (Q32, BLOCK, int16 / float32 planes): `buf` holds n_rows strips of row_bytes bytes
+ * (row_bytes = 8 * pitch in bytes); rank r has filled the strips of mdct_shard_rows(n_rows, world, r).
+ * Equal shards: ONE in-place ncclAllGather; ragged: one grouped broadcast per rank.  Asynchronous on
+ * `stream` (the stream the kernels ran on: no extra synchronisation needed). */
+int mdct_allgather_rows(mdct_comm *comm, void *buf, size_t row_bytes, size_t n_rows, void *stream);
+/* Stereo coefficient-planar output of a sizeX x sizeY call sharded by mdct_shard_rows(sizeY / 16, ...):
+ * 64 strided pieces per rank, gathered as 64 collectives inside one RCCL group. */
+int mdct_allgather_stereo(mdct_comm *comm, uint8_t *buf, size_t sizeX, size_t sizeY, void *stream);
+
 /* Measured-roofline helper for bench tools: a read-N/write-N 16 B/lane stream copy on
  * the same stream (what "HBM roofline" means on this box). */
 int mdct_stream_copy(const void *from, void *to, size_t bytes, void *stream);

@@ -62,6 +62,15 @@ SIGNATURES = {
     "mdct_fwd_f32": (c_int, _PLANE_F32),
     "mdct_inv_f32": (c_int, _PLANE_F32),
     "mdct_roundtrip_i16_planes": (c_int, [ctypes.POINTER(PlaneI16), c_int, c_void_p]),
+    "mdct_shard_rows": (None, [c_size_t, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
+    "mdct_stereo_shard_piece": (c_int, [c_size_t, c_size_t, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
+    "mdct_comm_get_unique_id": (c_int, [c_void_p]),
+    "mdct_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p]),
+    "mdct_comm_destroy": (c_int, [c_void_p]),
+    "mdct_comm_rank": (c_int, [c_void_p]),
+    "mdct_comm_world": (c_int, [c_void_p]),
+    "mdct_allgather_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "mdct_allgather_stereo": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mdct_stream_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdct_timer_create": (c_void_p, []),
     "mdct_timer_destroy": (None, [c_void_p]),

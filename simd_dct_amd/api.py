@@ -204,6 +204,59 @@ def roundtrip_i16_planes(planes, stream=None, check=True):
     return rc
 
 
+# ------------------------------------------------------------------------- multi-GPU (RCCL via the C-ABI)
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """rank 0: 128 opaque bytes to hand to the other ranks (mdct_comm_get_unique_id)"""
+    buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+    _check(_lib.load().mdct_comm_get_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """mdct_comm: one per process / GPU; collective construction over all ranks"""
+
+    def __init__(self, rank, world, unique_id):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        ident = ctypes.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        _check(self._lib.mdct_comm_init(ctypes.byref(self._h), int(rank), int(world), ident))
+        self.rank, self.world = rank, world
+
+    def allgather_rows(self, buf, row_bytes, n_rows, stream=None):
+        _check(self._lib.mdct_allgather_rows(self._h, _ptr(buf), row_bytes, n_rows, _stream(stream)))
+
+    def allgather_stereo(self, buf, sizeX, sizeY, stream=None):
+        _check(self._lib.mdct_allgather_stereo(self._h, _ptr(buf), sizeX, sizeY, _stream(stream)))
+
+    def close(self):
+        if self._h:
+            self._lib.mdct_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_rows_c(n_rows, world, rank):
+    """mdct_shard_rows (the C-ABI's own arithmetic; equals sharding.shard_rows)"""
+    b0, b1 = ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.load().mdct_shard_rows(n_rows, world, rank, ctypes.byref(b0), ctypes.byref(b1))
+    return b0.value, b1.value
+
+
+def stereo_shard_piece(sizeX, sizeY, world, rank):
+    """(first_offset, plane_stride, piece_bytes) of rank's shard in the stereo layout"""
+    a, b, c = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+    _check(_lib.load().mdct_stereo_shard_piece(sizeX, sizeY, world, rank, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+    return a.value, b.value, c.value
+
+
 def stream_copy(src, dst, nbytes, stream=None):
     _check(_lib.load().mdct_stream_copy(_ptr(src), _ptr(dst), nbytes, _stream(stream)))
 

@@ -29,6 +29,21 @@ int fail(int code, const char *fmt, ...)
   return code;
 }
 
+} // namespace
+
+// shared with comm.hip; not part of the public ABI
+extern "C" __attribute__((visibility("hidden"))) int mdct_set_error(int code, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace
+{
+
 int hip_fail(hipError_t e, const char *what)
 {
   return fail(MDCT_NOT_SUPPORTED, "%s: %s", what, hipGetErrorString(e));

@@ -624,7 +624,6 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x; // linear block index within the launch
   const bool valid = t < a.nblocks;
-  const uint32_t lane = threadIdx.x & 63;
 
   // block coordinates.  STEREO enumerates (block row, eye, block x): simd_dct.cpp:1089-1099.
   uint32_t by, bx, eye = 0;

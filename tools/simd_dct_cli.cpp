@@ -15,6 +15,11 @@
 #include <hip/hip_runtime_api.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <atomic>
 
 #include <cinttypes>
 #include <cmath>
@@ -87,6 +92,149 @@ Stats stats(const std::vector<double> &ns)
   return s;
 }
 
+// ---- --gpus N: one process per GPU (forked BEFORE any HIP call), block rows sharded with the
+// reference's own startY/endY hook (simd_dct.cpp:2245-2255), coefficients all-gathered over RCCL
+// through the C-ABI (mdct_comm_*, mdct_allgather_*).  Every rank ends up with the whole output.
+struct Shared
+{
+  unsigned char id[MDCT_UNIQUE_ID_BYTES];
+  std::atomic<int> id_ready;
+  double compute_ns[64], gather_ns[64];
+  int rc[64];
+};
+
+int run_rank(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file)
+{
+  if (mdct_init(rank) != MDCT_SUCCESS)
+  {
+    printf("rank %d: mdct_init(%d) failed: %s\n", rank, rank, mdct_last_error());
+    return 2;
+  }
+  if (rank == 0)
+  {
+    if (mdct_comm_get_unique_id(sh->id) != MDCT_SUCCESS)
+    {
+      printf("rank 0: %s\n", mdct_last_error());
+      sh->id_ready.store(-1);
+      return 2;
+    }
+    sh->id_ready.store(1);
+  }
+  while (sh->id_ready.load() == 0)
+    usleep(1000);
+  if (sh->id_ready.load() < 0)
+    return 2;
+  mdct_comm *comm = nullptr;
+  if (mdct_comm_init(&comm, rank, world, sh->id) != MDCT_SUCCESS)
+  {
+    printf("rank %d: %s\n", rank, mdct_last_error());
+    return 2;
+  }
+  const size_t bytes = X * Y;
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  hipStream_t stream;
+  if (hipMalloc((void **)&d_in, bytes) != hipSuccess || hipMalloc((void **)&d_out, bytes) != hipSuccess || hipStreamCreate(&stream) != hipSuccess ||
+      hipMemcpy(d_in, in.data(), bytes, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_out, 0, bytes) != hipSuccess)
+  {
+    printf("rank %d: device allocation failed\n", rank);
+    return 2;
+  }
+  mdct_shim_set_stream(stream);
+  mdct_shim_set_async(1);
+  // whole plane: q32 through the sizeY = 2H call form, stereo as is; shard = block rows [b0, b1)
+  size_t b0, b1;
+  mdct_shard_rows(stereo ? Y / 16 : Y / 8, world, rank, &b0, &b1);
+  double best_c = 1e300, best_g = 1e300;
+  int rc = 0;
+  for (size_t i = 0; i < runs + 1 && rc == 0; i++) // first run warms up
+  {
+    const double t0 = now_ns();
+    simdDctResult r = sdr_Success;
+    if (b1 > b0)
+      r = stereo ? simdDCT_EncodeQuantizeReorderStereoBuffer(d_in, d_out, table, X, Y, 16 * b0, 16 * (b1 - 1))
+                 : simdDCT_EncodeQuantize32ReorderBuffer(d_in, d_out, table, X, 2 * Y, 16 * b0, 16 * (b1 - 1));
+    if (r != sdr_Success || hipStreamSynchronize(stream) != hipSuccess)
+    {
+      printf("rank %d: %s\n", rank, mdct_last_error());
+      rc = 3;
+      break;
+    }
+    const double t1 = now_ns();
+    const int g = stereo ? mdct_allgather_stereo(comm, d_out, X, Y, stream) : mdct_allgather_rows(comm, d_out, 8 * X, Y / 8, stream);
+    if (g != MDCT_SUCCESS || hipStreamSynchronize(stream) != hipSuccess)
+    {
+      printf("rank %d: %s\n", rank, mdct_last_error());
+      rc = 3;
+      break;
+    }
+    const double t2 = now_ns();
+    if (i > 0)
+    {
+      best_c = t1 - t0 < best_c ? t1 - t0 : best_c;
+      best_g = t2 - t1 < best_g ? t2 - t1 : best_g;
+    }
+  }
+  sh->compute_ns[rank] = best_c;
+  sh->gather_ns[rank] = best_g;
+  if (rc == 0 && out_file && rank == 0)
+  {
+    std::vector<uint8_t> out(bytes);
+    FILE *f = fopen(out_file, "wb");
+    if (hipMemcpy(out.data(), d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess || !f || fwrite(out.data(), 1, bytes, f) != bytes)
+      rc = 1;
+    if (f)
+      fclose(f);
+  }
+  mdct_comm_destroy(comm);
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file)
+{
+  if (world > 64)
+  {
+    puts("Invalid Parameter.");
+    return 1;
+  }
+  Shared *sh = (Shared *)mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  if (sh == MAP_FAILED)
+    return 2;
+  new (sh) Shared();
+  sh->id_ready.store(0);
+  std::vector<pid_t> kids;
+  for (int r = 0; r < world; r++)
+  {
+    const pid_t p = fork(); // nothing has touched HIP yet in this process
+    if (p == 0)
+      _exit(run_rank(sh, r, world, in, X, Y, table, stereo, runs, out_file));
+    kids.push_back(p);
+  }
+  int rc = 0;
+  for (pid_t p : kids)
+  {
+    int st = 0;
+    waitpid(p, &st, 0);
+    const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 4;
+    rc = code > rc ? code : rc;
+  }
+  if (rc == 0)
+  {
+    double c = 0, g = 0;
+    for (int r = 0; r < world; r++)
+    {
+      c = sh->compute_ns[r] > c ? sh->compute_ns[r] : c;
+      g = sh->gather_ns[r] > g ? sh->gather_ns[r] : g;
+    }
+    const double px = (double)X * Y;
+    printf("%s over %d GPU(s): block rows sharded, RCCL all-gather via the C-ABI | result sdr_Success | slowest rank: transform %.1f us, all-gather %.1f us | %.1f Mpx/s incl. gather, %.1f Mpx/s transform only | gather bus %.1f GB/s\n",
+           stereo ? "enc-quant-stereo" : "enc-quant32", world, c * 1e-3, g * 1e-3, px / ((c + g) * 1e-9) / 1e6, px / (c * 1e-9) / 1e6, world > 1 ? px * (world - 1) / world / g : 0.0);
+  }
+  munmap(sh, sizeof(Shared));
+  return rc;
+}
+
 const char *result_name(int r) { return r == 0 ? "sdr_Success" : (r == 1 ? "sdr_InvalidParameter" : "sdr_NotSupported"); }
 
 } // namespace
@@ -105,6 +253,7 @@ int main(int argc, char **argv)
     puts("\t--resident\t\t\tKeep input and output in HBM (device pointers through the same API).");
     puts("\t--pin\t\t\t\tPage-lock the host buffers once (mdct_shim_pin): host-pointer calls then DMA in place.");
     puts("\t--device <n>\t\t\tHIP device ordinal.");
+    puts("\t--gpus <n>\t\t\tOne process per GPU: block rows sharded, coefficients all-gathered over RCCL (enc-quant32 or enc-quant-stereo, device-resident).");
     return 1;
   }
   const std::string filename = argv[1];
@@ -118,7 +267,7 @@ int main(int argc, char **argv)
   size_t runs = 128; // main.cpp:21
   float quality = 1.0f;
   bool resident = false, pin = false;
-  int device = 0, max_simd = MDCT_SIMD_AVX2;
+  int device = 0, max_simd = MDCT_SIMD_AVX2, gpus = 0;
   bool m_encq = false, m_q32 = false, m_stereo = false;
   for (int i = 4; i < argc; i++)
   {
@@ -130,6 +279,7 @@ int main(int argc, char **argv)
     else if (a == "--resident") resident = true;
     else if (a == "--pin") pin = true;
     else if (a == "--device") device = atoi(next());
+    else if (a == "--gpus") gpus = atoi(next());
     else if (a == "--mode")
     {
       const std::string m = next();
@@ -188,6 +338,16 @@ int main(int argc, char **argv)
   for (float &t : table)
     t *= quality;
 
+  if (gpus > 0)
+  { // must fork before the first HIP call of this process
+    if (m_stereo == m_q32 || m_encq)
+    {
+      puts("--gpus needs exactly one of --mode enc-quant32 / enc-quant-stereo.");
+      return 1;
+    }
+    mdct_shim_set_max_simd(max_simd);
+    return run_multi_gpu(gpus, in, X, Y, table, m_stereo, runs, out_file);
+  }
   if (mdct_init(device) != MDCT_SUCCESS)
   {
     printf("mdct_init failed: %s\n", mdct_last_error());
