@@ -12,8 +12,8 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -std
 all: lib cli oracle
 
 lib: $(LIB)
-$(LIB): $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/mdct_kernels.h include/mdct.h include/simd_dct_shim.h
-	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip -ldl -o $@
+$(LIB): $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/stages.hip $(CSRC)/mdct_kernels.h include/mdct.h include/simd_dct_shim.h
+	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/stages.hip -ldl -o $@
 
 cli: tools/simd_dct_cli
 tools/simd_dct_cli: tools/simd_dct_cli.cpp $(LIB)

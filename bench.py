@@ -461,6 +461,44 @@ def main():
             log("cpu baseline (oracle port) ...")
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
+    if dist is not None and not args.no_extras and args.backend == "nccl":
+        # The same gather through the C-ABI's own RCCL leg (mdct_comm_* / mdct_allgather_rows, csrc/comm.hip),
+        # i.e. what a C++ host would call.  Runs AFTER the JSON line (stdout stays one line whatever happens
+        # here); its result goes to stderr.
+        try:
+            ident = [M.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            comm = M.Comm(rank, world, ident[0])
+            PW = PH = 4096
+            NPL = 64  # a quarter of configs[3]'s batch is enough for a rate
+            rows = NPL * PH // 8
+            buf = torch.zeros((NPL * PH, PW), dtype=torch.int16, device="cuda")
+            src = synth.plane_i16_torch(PW, PH, "photo", seed=synth.SEED + 7)
+            b0, b1 = M.shard_rows_c(rows, world, rank)
+            srcs4 = src.repeat(((b1 - b0) * 8 + PH - 1) // PH + 1, 1)[: (b1 - b0) * 8]
+            M.fwd_i16(srcs4, buf[b0 * 8:b1 * 8], PW, (b1 - b0) * 8)  # this rank's block rows, in place in the full buffer
+            comm.allgather_rows(buf, 8 * PW * 2, rows)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                comm.allgather_rows(buf, 8 * PW * 2, rows)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = (time.perf_counter() - t0) / reps
+            # every plane of the gathered buffer is the same picture's coefficients: compare all shards with this rank's own
+            want = buf[b0 * 8:b0 * 8 + PH] if (b0 * 8) % PH == 0 else None
+            ok = bool(all(torch.equal(buf[p * PH:(p + 1) * PH], want) for p in range(NPL))) if want is not None else None
+            if rank == 0:
+                nbytes = NPL * PW * PH * 2
+                print("[bench cabi-gather] " + json.dumps({"what": f"{NPL} planes of {PW}x{PH} int16 coefficients, block rows sharded over {world} ranks, mdct_allgather_rows (RCCL via the C-ABI)",
+                                                          "seconds": round(tg, 6), "busbw_GBps": round((world - 1) / world * nbytes / tg / 1e9, 1),
+                                                          "all_planes_complete_on_rank0": ok}), file=sys.stderr, flush=True)
+            comm.close()
+        except Exception as e:
+            if rank == 0:
+                print("[bench cabi-gather] " + json.dumps({"error": str(e)[:200]}), file=sys.stderr, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

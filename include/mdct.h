@@ -145,6 +145,33 @@ typedef struct mdct_plane_i16
 } mdct_plane_i16;
 int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *stream);
 
+/* ---- the stages either side of the transform (no reference counterpart: its pipeline starts from a
+ * ready-made plane, main.cpp:475-493, and ends at the reorder store, simd_dct.cpp:2221-2230) ----------
+ * After the quantiser: zig-zag scan (ITU-T T.81 Figure A.6) and run/level pairs (T.81 F.1.2.2) of every
+ * block, one fixed-stride record per block, block index = by * (sizeX/8) + bx over the whole plane:
+ *   levels[blk*64 + i], runs[blk*64 + i]  i-th non-zero coefficient in scan order (all 64 positions,
+ *                                         DC included) and the number of zeros that precede it;
+ *                                         zero beyond counts[blk]
+ *   counts[blk]                           number of pairs; the coefficients after the last pair are
+ *                                         zero (end of block)
+ * runs == NULL (counts ignored): plain scan, levels[blk*64 + k] = coefficient at scan position k.
+ * Sources: an int16 coefficient plane as written by mdct_fwd_i16 / mdct_fwd_u8_i16 (pitch in elements),
+ * or the reference's q32 byte layout as written by mdct_fwd_quant_u8(MDCT_LAYOUT_Q32) / simd_dct.h:31,
+ * whose bytes carry a +127 bias (simd_dct.cpp:2224): level = byte - 127.  Only block rows [by0, by1)
+ * are read and only their records written.  Arrays 16-byte aligned. */
+int mdct_zigzag_rle_i16(const int16_t *coef, size_t pitch, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                        int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
+int mdct_zigzag_rle_q32(const uint8_t *q32, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                        int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
+/* the scan order used above: zz[k] = natural index v*8+u of scan position k (host function) */
+void mdct_zigzag_table(uint8_t *zz64);
+/* Before the transform (feeds mdct_roundtrip_i16_planes / BASELINE.json configs[2]): interleaved 8-bit
+ * Y Cb Cr (3 bytes per pixel, pitch in bytes) -> three int16 planes level-shifted by -128; Y at full
+ * resolution, Cb / Cr subsampled 2x2 by the rounded box average (a+b+c+d+2) >> 2 (JFIF centred siting).
+ * sizeX, sizeY multiples of 16; pitches of the int16 planes in elements. */
+int mdct_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr,
+                     size_t pitch_y, size_t pitch_c, void *stream);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------------
  * The reference has no communication; its only parallelism hook is the caller-side row range
  * startY/endY (simd_dct.cpp:2245-2255).  Here: every rank transforms its block-row shard in place

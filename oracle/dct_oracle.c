@@ -704,3 +704,147 @@ int orc_fwd_f64ref(const float *from, double *to, size_t pi, size_t po, size_t W
     }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Stages either side of the codec core [no reference counterpart: the
+ * reference's pipeline ends at the reorder store, simd_dct.cpp:2221-2230, :1034-1052].
+ * Published definitions restated here: the zig-zag scan of ITU-T T.81 (JPEG) Figure A.6 /
+ * Figure 5, generated by walking the anti-diagonals (the product carries the table as
+ * literals, so the two check each other), run/level pairs as in T.81 F.1.2.2 (a run is the
+ * number of zero coefficients preceding a non-zero one in zig-zag order; trailing zeros are the
+ * end of block), and 4:2:0 chroma siting as in JFIF (2x2 box average, centred).
+ * ---------------------------------------------------------------------------------------- */
+void orc_zigzag_table(uint8_t *zz)
+{ /* zz[k] = natural index v*8+u of the k-th coefficient of the scan */
+  int v = 0, u = 0;
+  for (int k = 0; k < 64; k++)
+  {
+    zz[k] = (uint8_t)(v * 8 + u);
+    if ((v + u) % 2 == 0)
+    { /* moving up-right */
+      if (u == 7)
+        v++;
+      else if (v == 0)
+        u++;
+      else
+      {
+        v--;
+        u++;
+      }
+    }
+    else
+    { /* moving down-left */
+      if (v == 7)
+        u++;
+      else if (u == 0)
+        v++;
+      else
+      {
+        v++;
+        u--;
+      }
+    }
+  }
+}
+
+/* one block's 64 values in natural order -> scan order, then (run, level) pairs.
+ * runs == NULL: plain zig-zag scan (levels = all 64 values in scan order). */
+static void scan_block(const int *nat, int16_t *levels, uint8_t *runs, uint8_t *count)
+{
+  uint8_t zz[64];
+  orc_zigzag_table(zz);
+  if (!runs)
+  {
+    for (int k = 0; k < 64; k++)
+      levels[k] = (int16_t)nat[zz[k]];
+    return;
+  }
+  int n = 0, run = 0;
+  memset(levels, 0, 64 * sizeof(int16_t));
+  memset(runs, 0, 64);
+  for (int k = 0; k < 64; k++)
+  {
+    const int c = nat[zz[k]];
+    if (c != 0)
+    {
+      levels[n] = (int16_t)c;
+      runs[n] = (uint8_t)run;
+      n++;
+      run = 0;
+    }
+    else
+      run++;
+  }
+  *count = (uint8_t)n;
+}
+
+/* int16 coefficient plane (coefficient (v,u) of block (by,bx) at (by*8+v, bx*8+u)) -> records of
+ * block by*bpr+bx: levels[blk*64 ..], runs[blk*64 ..], counts[blk] */
+int orc_zigzag_rle_i16(const int16_t *coef, size_t pitch, size_t W, size_t H, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts)
+{
+  if (!coef || !levels || (runs && !counts))
+    return 1;
+  if (W % 8 || H % 8)
+    return 2;
+  if (pitch < W || by0 > by1 || by1 > H / 8)
+    return 1;
+  const size_t bpr = W / 8;
+  for (size_t by = by0; by < by1; by++)
+    for (size_t bx = 0; bx < bpr; bx++)
+    {
+      int nat[64];
+      for (int i = 0; i < 64; i++)
+        nat[i] = coef[(by * 8 + (size_t)(i >> 3)) * pitch + bx * 8 + (size_t)(i & 7)];
+      const size_t blk = by * bpr + bx;
+      scan_block(nat, levels + blk * 64, runs ? runs + blk * 64 : NULL, counts ? counts + blk : NULL);
+    }
+  return 0;
+}
+
+/* the reference's q32 layout (simd_dct.cpp:2221-2230): byte [coef*8 + b] of the 512-byte group; the
+ * stored byte carries the +127 bias of :2224, so level = byte - 127 */
+int orc_zigzag_rle_q32(const uint8_t *q32, size_t W, size_t H, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts)
+{
+  if (!q32 || !levels || (runs && !counts))
+    return 1;
+  if (W % 64 || H % 8)
+    return 2;
+  if (by0 > by1 || by1 > H / 8)
+    return 1;
+  const size_t bpr = W / 8;
+  for (size_t by = by0; by < by1; by++)
+    for (size_t bx = 0; bx < bpr; bx++)
+    {
+      int nat[64];
+      const uint8_t *grp = q32 + by * 8 * W + (bx / 8) * 512;
+      for (int i = 0; i < 64; i++)
+        nat[i] = (int)grp[(size_t)i * 8 + bx % 8] - 127;
+      const size_t blk = by * bpr + bx;
+      scan_block(nat, levels + blk * 64, runs ? runs + blk * 64 : NULL, counts ? counts + blk : NULL);
+    }
+  return 0;
+}
+
+/* interleaved 8-bit Y Cb Cr (3 bytes per pixel) -> three int16 planes, level-shifted by -128:
+ * Y at full resolution, Cb / Cr subsampled 2x2 by the rounded box average (a+b+c+d+2) >> 2. */
+int orc_split420_u8(const uint8_t *ycc, size_t pitch, size_t W, size_t H, int16_t *y, int16_t *cb, int16_t *cr, size_t pitch_y, size_t pitch_c)
+{
+  if (!ycc || !y || !cb || !cr)
+    return 1;
+  if (W % 16 || H % 16)
+    return 2;
+  if (pitch < 3 * W || pitch_y < W || pitch_c < W / 2)
+    return 1;
+  for (size_t r = 0; r < H; r++)
+    for (size_t c = 0; c < W; c++)
+      y[r * pitch_y + c] = (int16_t)((int)ycc[r * pitch + 3 * c] - 128);
+  for (size_t r = 0; r < H / 2; r++)
+    for (size_t c = 0; c < W / 2; c++)
+      for (int k = 1; k <= 2; k++)
+      {
+        const uint8_t *p0 = ycc + (2 * r) * pitch + 3 * (2 * c) + (size_t)k, *p1 = p0 + pitch;
+        const int s = (int)p0[0] + (int)p0[3] + (int)p1[0] + (int)p1[3];
+        (k == 1 ? cb : cr)[r * pitch_c + c] = (int16_t)(((s + 2) >> 2) - 128);
+      }
+  return 0;
+}

@@ -18,6 +18,8 @@
  *             path at all; these restate the engine's OWN arithmetic definition):
  *               orc_fwd_i16, orc_inv_i16, orc_roundtrip_i16, orc_fwd_u8_i16, orc_inv_i16_u8,
  *               orc_fwd_f32, orc_inv_f32, orc_fwd_f64ref
+ *             (and, restating published definitions of ITU-T T.81 rather than engine arithmetic:
+ *               orc_zigzag_table, orc_zigzag_rle_i16, orc_zigzag_rle_q32, orc_split420_u8)
  *
  * All arithmetic is IEEE-754 binary32, one rounding per written operation, no FMA
  * (compile with -ffp-contract=off, never -ffast-math).
@@ -85,6 +87,17 @@ int orc_fwd_f64ref(const float *from, double *to, size_t pitch_in, size_t pitch_
  * C-ABI (mdct_fwd_quant_u8) rather than the reference-semantics shim. */
 int orc_q32_native(const uint8_t *from, uint8_t *to, size_t pitch_in, const float *lut,
                    size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+
+/* Stages either side of the codec core, engine-own, defined against ITU-T T.81:
+ * zig-zag scan (Figure A.6) + run/level pairs of an int16 coefficient plane or of the reference's
+ * q32 byte layout, and the 4:2:0 split / subsample that feeds BASELINE.json configs[2]. */
+void orc_zigzag_table(uint8_t *zz64);
+int orc_zigzag_rle_i16(const int16_t *coef, size_t pitch, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                       int16_t *levels, uint8_t *runs, uint8_t *counts);
+int orc_zigzag_rle_q32(const uint8_t *q32, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                       int16_t *levels, uint8_t *runs, uint8_t *counts);
+int orc_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr,
+                    size_t pitch_y, size_t pitch_c);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,10 @@ SIGNATURES = {
     "mdct_fwd_f32": (c_int, _PLANE_F32),
     "mdct_inv_f32": (c_int, _PLANE_F32),
     "mdct_roundtrip_i16_planes": (c_int, [ctypes.POINTER(PlaneI16), c_int, c_void_p]),
+    "mdct_zigzag_rle_i16": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdct_zigzag_rle_q32": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdct_zigzag_table": (None, [c_void_p]),
+    "mdct_split420_u8": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mdct_shard_rows": (None, [c_size_t, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "mdct_stereo_shard_piece": (c_int, [c_size_t, c_size_t, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "mdct_comm_get_unique_id": (c_int, [c_void_p]),

@@ -204,6 +204,40 @@ def roundtrip_i16_planes(planes, stream=None, check=True):
     return rc
 
 
+# ------------------------------------------------------------------------- stages either side of the transform
+def zigzag_table():
+    """scan position k -> natural index v*8+u (ITU-T T.81 Figure A.6)"""
+    zz = np.zeros(64, dtype=np.uint8)
+    _lib.load().mdct_zigzag_table(zz.ctypes.data)
+    return zz
+
+
+def zigzag_rle_i16(coef, sizeX, sizeY, levels, runs=None, counts=None, by0=0, by1=None, pitch=None, stream=None, check=True):
+    """zig-zag scan (+ run/level pairs when runs/counts are given) of an int16 coefficient plane"""
+    rc = _lib.load().mdct_zigzag_rle_i16(_ptr(coef), sizeX if pitch is None else pitch, sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1,
+                                         _ptr(levels), _ptr(runs), _ptr(counts), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+def zigzag_rle_q32(q32, sizeX, sizeY, levels, runs=None, counts=None, by0=0, by1=None, stream=None, check=True):
+    """the same from the reference's q32 byte layout (level = byte - 127)"""
+    rc = _lib.load().mdct_zigzag_rle_q32(_ptr(q32), sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, _ptr(levels), _ptr(runs), _ptr(counts), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+def split420_u8(ycc, sizeX, sizeY, y, cb, cr, pitch=None, pitch_y=None, pitch_c=None, stream=None, check=True):
+    """interleaved 8-bit Y Cb Cr -> level-shifted int16 Y (full) and Cb / Cr (2x2 box average) planes"""
+    rc = _lib.load().mdct_split420_u8(_ptr(ycc), 3 * sizeX if pitch is None else pitch, sizeX, sizeY, _ptr(y), _ptr(cb), _ptr(cr),
+                                      sizeX if pitch_y is None else pitch_y, sizeX // 2 if pitch_c is None else pitch_c, _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
 # ------------------------------------------------------------------------- multi-GPU (RCCL via the C-ABI)
 UNIQUE_ID_BYTES = 128
 

@@ -40,6 +40,10 @@ def oracle():
             getattr(lib, n).argtypes = [vp, vp, sz, sz, f32p, ctypes.c_int, sz, sz, sz, sz]
         for n in ("orc_fwd_f32", "orc_inv_f32", "orc_fwd_f64ref"):
             getattr(lib, n).argtypes = [vp, vp, sz, sz, sz, sz, sz, sz]
+        lib.orc_zigzag_table.argtypes = [vp]
+        lib.orc_zigzag_rle_i16.argtypes = [vp, sz, sz, sz, sz, sz, vp, vp, vp]
+        lib.orc_zigzag_rle_q32.argtypes = [vp, sz, sz, sz, sz, vp, vp, vp]
+        lib.orc_split420_u8.argtypes = [vp, sz, sz, sz, vp, vp, vp, sz, sz]
         lib.orc_dct8.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_int]
         lib.orc_idct8_own.argtypes = [vp, ctypes.c_ssize_t]
         _orc = lib
@@ -235,3 +239,39 @@ def f32_par(mode, src, W, H, threads=None):
     fn = getattr(oracle(), {"fwd": "orc_fwd_f32", "inv": "orc_inv_f32", "f64ref": "orc_fwd_f64ref"}[mode])
     _par_rows(lambda a, b: fn(src.ctypes.data, out.ctypes.data, W, W, W, H, a, b), H // 8, threads)
     return out
+
+
+# ------------------------------------------------------------------ stages either side of the transform
+def zigzag_table():
+    zz = np.zeros(64, dtype=np.uint8)
+    oracle().orc_zigzag_table(zz.ctypes.data)
+    return zz
+
+
+def zigzag_rle(kind, src, W, H, rle=True, by0=0, by1=None, pitch=None, fill=0):
+    """kind 'i16' (int16 plane [H, pitch]) or 'q32' (bytes).  Returns (levels [nblk, 64], runs, counts); arrays pre-filled with `fill`."""
+    nblk = (W // 8) * (H // 8)
+    levels = np.full((nblk, 64), fill, dtype=np.int16)
+    runs = np.full((nblk, 64), fill & 0xFF, dtype=np.uint8) if rle else None
+    counts = np.full(nblk, fill & 0xFF, dtype=np.uint8) if rle else None
+    by1 = H // 8 if by1 is None else by1
+    rp = runs.ctypes.data if rle else None
+    cp = counts.ctypes.data if rle else None
+    if kind == "i16":
+        src = np.ascontiguousarray(src, dtype=np.int16)
+        rc = oracle().orc_zigzag_rle_i16(src.ctypes.data, W if pitch is None else pitch, W, H, by0, by1, levels.ctypes.data, rp, cp)
+    else:
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        rc = oracle().orc_zigzag_rle_q32(src.ctypes.data, W, H, by0, by1, levels.ctypes.data, rp, cp)
+    assert rc == 0, rc
+    return levels, runs, counts
+
+
+def split420(ycc, W, H):
+    ycc = np.ascontiguousarray(ycc, dtype=np.uint8)
+    y = np.zeros((H, W), dtype=np.int16)
+    cb = np.zeros((H // 2, W // 2), dtype=np.int16)
+    cr = np.zeros((H // 2, W // 2), dtype=np.int16)
+    rc = oracle().orc_split420_u8(ycc.ctypes.data, 3 * W, W, H, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, W, W // 2)
+    assert rc == 0, rc
+    return y, cb, cr

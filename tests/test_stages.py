@@ -1,0 +1,212 @@
+"""The stages either side of the transform (include/mdct.h): zig-zag scan + run/level
+records after the quantiser, 4:2:0 split / subsample before config 3's transform.  CPU: the checker
+against the published table of ITU-T T.81 Figure A.6, against a numpy restatement, and the product's
+own table; GPU: the kernels bit-exact against the checker, plus reconstruction at full size."""
+import numpy as np
+import pytest
+
+import oracle as O
+from simd_dct_amd import api, synth
+
+# ITU-T T.81 (09/92) Figure A.6 "Zig-zag sequence of quantized DCT coefficients": the number printed in cell
+# (row v, column u) is the position of that coefficient in the scan.
+T81_FIGURE_A6 = np.array([
+    [0, 1, 5, 6, 14, 15, 27, 28],
+    [2, 4, 7, 13, 16, 26, 29, 42],
+    [3, 8, 12, 17, 25, 30, 41, 43],
+    [9, 11, 18, 24, 31, 40, 44, 53],
+    [10, 19, 23, 32, 39, 45, 52, 54],
+    [20, 22, 33, 38, 46, 51, 55, 60],
+    [21, 34, 37, 47, 50, 56, 59, 61],
+    [35, 36, 48, 49, 57, 58, 62, 63]])
+
+
+def test_zigzag_tables_are_t81_figure_a6():
+    want = np.argsort(T81_FIGURE_A6.reshape(-1))  # scan position k -> natural index
+    assert np.array_equal(O.zigzag_table(), want)      # the checker walks the anti-diagonals
+    assert np.array_equal(api.zigzag_table(), want)    # the product carries literals
+
+
+def _numpy_records(nat):
+    """nat: [nblk, 64] natural-order coefficients -> (levels, runs, counts) by definition"""
+    zz = np.argsort(T81_FIGURE_A6.reshape(-1))
+    scan = nat[:, zz]
+    levels = np.zeros_like(scan, dtype=np.int16)
+    runs = np.zeros(scan.shape, dtype=np.uint8)
+    counts = np.zeros(scan.shape[0], dtype=np.uint8)
+    for b in range(scan.shape[0]):
+        nzpos = np.flatnonzero(scan[b])
+        counts[b] = len(nzpos)
+        levels[b, :len(nzpos)] = scan[b, nzpos]
+        runs[b, :len(nzpos)] = np.diff(np.concatenate(([-1], nzpos))) - 1
+    return scan.astype(np.int16), levels, runs, counts
+
+
+def _blocks_i16(plane, W, H):
+    return plane.reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+
+
+def test_oracle_scan_and_rle_by_definition():
+    W, H = 128, 48
+    rng = np.random.default_rng(4)
+    coef = (rng.integers(-300, 300, (H, W)) * (rng.random((H, W)) < 0.15)).astype(np.int16)
+    coef[:8, :8] = 0            # an all-zero block: count 0
+    coef[8:16, :8] = 7          # a full block: 64 pairs, all runs 0
+    scan, lv, rn, ct = _numpy_records(_blocks_i16(coef, W, H))
+    got_lv, got_rn, got_ct = O.zigzag_rle("i16", coef, W, H)
+    assert np.array_equal(got_lv, lv) and np.array_equal(got_rn, rn) and np.array_equal(got_ct, ct)
+    assert ct[0] == 0 and ct[W // 8] == 64
+    plain, _, _ = O.zigzag_rle("i16", coef, W, H, rle=False)
+    assert np.array_equal(plain, scan)
+    # the q32 byte layout of the same coefficients (bias +127, 8 blocks interleaved: simd_dct.cpp:2221-2230)
+    small = np.clip(coef, -127, 128)
+    nat = _blocks_i16(small, W, H)
+    q32 = (nat + 127).astype(np.uint8).reshape(H // 8, W // 64, 8, 64).transpose(0, 1, 3, 2).reshape(-1)
+    scan, lv, rn, ct = _numpy_records(nat)
+    got_lv, got_rn, got_ct = O.zigzag_rle("q32", q32, W, H)
+    assert np.array_equal(got_lv, lv) and np.array_equal(got_rn, rn) and np.array_equal(got_ct, ct)
+
+
+def _ycc(W, H, seed=1):
+    y = synth.plane_u8_np(W, H, "photo", seed=seed)
+    cb = synth.plane_u8_np(W, H, "noise", seed=seed + 1)
+    cr = synth.plane_u8_np(W, H, "photo", seed=seed + 2)[::-1]
+    return np.ascontiguousarray(np.stack([y, cb, cr], axis=-1))
+
+
+def test_oracle_split420_by_definition():
+    W, H = 64, 32
+    ycc = _ycc(W, H)
+    y, cb, cr = O.split420(ycc, W, H)
+    assert np.array_equal(y, ycc[:, :, 0].astype(np.int16) - 128)
+    for k, got in ((1, cb), (2, cr)):
+        c = ycc[:, :, k].astype(np.int32)
+        box = c[0::2, 0::2] + c[0::2, 1::2] + c[1::2, 0::2] + c[1::2, 1::2]
+        assert np.array_equal(got, ((box + 2) >> 2) - 128)
+
+
+def test_stage_argument_checks_without_device():
+    a = np.zeros((16, 64), dtype=np.int16)
+    lv = np.zeros((16, 64), dtype=np.int16)
+    rn = np.zeros((16, 64), dtype=np.uint8)
+    ct = np.zeros(16, dtype=np.uint8)
+    assert api.zigzag_rle_i16(None, 64, 16, lv, check=False) == 1
+    assert api.zigzag_rle_i16(a, 60, 16, lv, check=False) == 2
+    assert api.zigzag_rle_i16(a, 64, 16, lv, rn, None, check=False) == 1      # runs without counts
+    assert api.zigzag_rle_i16(a, 64, 16, lv, rn, ct, by1=3, check=False) == 1  # range beyond the plane
+    assert api.zigzag_rle_q32(a.view(np.uint8), 56, 16, lv, check=False) == 2  # q32 needs sizeX % 64
+    ycc = np.zeros((16, 16, 3), dtype=np.uint8)
+    y = np.zeros((16, 16), dtype=np.int16)
+    c = np.zeros((8, 8), dtype=np.int16)
+    assert api.split420_u8(ycc, 24, 16, y, c, c, check=False) == 2
+    assert api.split420_u8(ycc, 16, 16, y, c, c, pitch=40, check=False) == 1
+
+
+# ------------------------------------------------------------------------------------------ GPU
+torch = pytest.importorskip("torch")
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+def test_scan_and_rle_match_the_checker():
+    api.init(0)
+    rng = np.random.default_rng(12)
+    lut = (api.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
+    for (W, H) in ((64, 8), (128, 48), (320, 40), (1024, 256)):
+        nblk = (W // 8) * (H // 8)
+        # int16 coefficients: real quantised DCT output (sparse) and random dense / saturating values
+        src = synth.plane_i16_np(W, H, "photo", seed=W)
+        coefs = [O.i16("fwd", src, W, H, lut=(api.QUANTIZE_BASE * np.float32(60)).astype(np.float32)),
+                 rng.integers(-32768, 32768, (H, W), dtype=np.int16),
+                 np.zeros((H, W), dtype=np.int16)]
+        for coef in coefs:
+            for rle in (True, False):
+                for (b0, b1) in ((0, H // 8), (H // 16, H // 8)):
+                    lv = torch.full((nblk, 64), 0x1111, dtype=torch.int16, device="cuda")
+                    rn = torch.full((nblk, 64), 0x11, dtype=torch.uint8, device="cuda") if rle else None
+                    ct = torch.full((nblk,), 0x11, dtype=torch.uint8, device="cuda") if rle else None
+                    api.zigzag_rle_i16(_dev(coef), W, H, lv, rn, ct, by0=b0, by1=b1)
+                    want = O.zigzag_rle("i16", coef, W, H, rle=rle, by0=b0, by1=b1, fill=0x1111)
+                    assert np.array_equal(lv.cpu().numpy(), want[0]), (W, H, rle, b0)
+                    if rle:
+                        assert np.array_equal(rn.cpu().numpy(), want[1]) and np.array_equal(ct.cpu().numpy(), want[2]), (W, H, b0)
+        if W % 64 == 0:  # the reference's own product as the source: GPU q32 bytes -> records
+            img = synth.plane_u8_np(W, H, "photo", seed=W + 1)
+            q = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
+            api.fwd_quant_u8(_dev(img), q, lut, W, H, 0, H // 8)
+            rc, qh = O.q32_native(img, lut, W, H, 0, H // 8)
+            for rle in (True, False):
+                lv = torch.zeros((nblk, 64), dtype=torch.int16, device="cuda")
+                rn = torch.zeros((nblk, 64), dtype=torch.uint8, device="cuda") if rle else None
+                ct = torch.zeros((nblk,), dtype=torch.uint8, device="cuda") if rle else None
+                api.zigzag_rle_q32(q, W, H, lv, rn, ct)
+                want = O.zigzag_rle("q32", qh, W, H, rle=rle)
+                assert np.array_equal(lv.cpu().numpy(), want[0]), (W, H, rle)
+                if rle:
+                    assert np.array_equal(rn.cpu().numpy(), want[1]) and np.array_equal(ct.cpu().numpy(), want[2])
+
+
+@pytest.mark.gpu
+def test_records_reconstruct_the_plane_at_full_size():
+    """8192x8192: JPEG-luma-quantised coefficients -> records; expanding the records (torch, on the device)
+    gives back every coefficient; sampled block rows equal the checker"""
+    api.init(0)
+    W = H = 8192
+    luma = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                     18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+    img = synth.plane_u8_torch(W, H, "photo")
+    coef = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    api.fwd_u8_i16(img, coef, W, H, lut=luma)
+    nblk = (W // 8) * (H // 8)
+    lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
+    rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
+    ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
+    api.zigzag_rle_i16(coef, W, H, lv, rn, ct)
+    # expand: scan position of pair i = cumsum(run + 1) - 1
+    pos = torch.cumsum(rn.to(torch.int64) + 1, dim=1) - 1
+    live = torch.arange(64, device="cuda")[None, :] < ct[:, None].to(torch.int64)
+    scan = torch.zeros((nblk, 65), dtype=torch.int16, device="cuda")
+    scan.scatter_(1, torch.where(live, pos, torch.full_like(pos, 64)), lv)
+    zz = torch.from_numpy(api.zigzag_table().astype(np.int64)).cuda()
+    nat = torch.zeros((nblk, 64), dtype=torch.int16, device="cuda")
+    nat[:, zz] = scan[:, :64]
+    back = nat.reshape(H // 8, W // 8, 8, 8).permute(0, 2, 1, 3).reshape(H, W)
+    assert torch.equal(back, coef)
+    assert int(ct.max().item()) <= 64 and float(ct.float().mean().item()) < 32  # quantised photo content is sparse
+    host = coef[:64].cpu().numpy()
+    want = O.zigzag_rle("i16", host, W, 64)
+    n = (W // 8) * 8
+    assert np.array_equal(lv[:n].cpu().numpy(), want[0]) and np.array_equal(rn[:n].cpu().numpy(), want[1]) and np.array_equal(ct[:n].cpu().numpy(), want[2])
+
+
+@pytest.mark.gpu
+def test_split420_matches_the_checker_and_feeds_config3():
+    api.init(0)
+    for (W, H) in ((16, 16), (64, 32), (1008, 48), (1920, 1088)):
+        ycc = _ycc(W, H, seed=W)
+        y = torch.full((H, W), 77, dtype=torch.int16, device="cuda")
+        cb = torch.full((H // 2, W // 2), 77, dtype=torch.int16, device="cuda")
+        cr = torch.full((H // 2, W // 2), 77, dtype=torch.int16, device="cuda")
+        api.split420_u8(_dev(ycc), W, H, y, cb, cr)
+        wy, wcb, wcr = O.split420(ycc, W, H)
+        assert np.array_equal(y.cpu().numpy(), wy) and np.array_equal(cb.cpu().numpy(), wcb) and np.array_equal(cr.cpu().numpy(), wcr), (W, H)
+    # BASELINE.json configs[2] end to end: 7680x4320 interleaved frame -> split -> the three planes through
+    # mdct_roundtrip_i16_planes with per-plane tables in one call; the luma plane equals the single-plane entry point
+    W, H = 7680, 4320 + 16 - (4320 % 16 or 16)  # heights are multiples of 16 here (4320 is)
+    ycc = torch.stack([synth.plane_u8_torch(W, H, "photo", seed=s) for s in (1, 2, 3)], dim=-1).contiguous()
+    y = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    cb = torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda")
+    cr = torch.empty_like(cb)
+    api.split420_u8(ycc, W, H, y, cb, cr)
+    assert torch.equal(y, ycc[:, :, 0].to(torch.int16) - 128)
+    c = ycc[:, :, 1].to(torch.int32)
+    assert torch.equal(cb.to(torch.int32), ((c[0::2, 0::2] + c[0::2, 1::2] + c[1::2, 0::2] + c[1::2, 1::2] + 2) >> 2) - 128)
+    lut = (api.QUANTIZE_BASE * np.float32(60)).astype(np.float32)
+    outs = [torch.empty_like(t) for t in (y, cb, cr)]
+    api.roundtrip_i16_planes([(y, outs[0], W, H, lut), (cb, outs[1], W // 2, H // 2, lut), (cr, outs[2], W // 2, H // 2, lut)])
+    single = torch.empty_like(y)
+    api.roundtrip_i16(y, single, W, H, lut=lut)
+    assert torch.equal(single, outs[0])
