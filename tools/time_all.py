@@ -45,6 +45,27 @@ cases = [
     ("u8 encq / SSE tier", 2, W * H, [Q(u8[i], o8[i], lut8, W, H, 0, H // 8, layout=M.LAYOUT_BLOCK_SSE, profile=M.PROFILE_REF_SSE) for i in range(NS)]),
     ("u8 encq / scalar tier", 2, W * H, [Q(u8[i], o8[i], lut8, W, H, 0, H // 8, layout=M.LAYOUT_BLOCK, profile=M.PROFILE_REF_SCALAR) for i in range(NS)]),
 ]
+# stages either side of the transform: algorithmic bytes per pixel = what must cross HBM once
+lut60 = (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32)
+qcoef = [torch.empty_like(s) for s in i16]
+for i in range(NS):
+    M.fwd_i16(i16[i], qcoef[i], W, H, lut=lut60)  # sparse, photo-like quantised coefficients
+    M.fwd_quant_u8(u8[i], o8[i], lut2000, W, H, 0, H // 8)
+q32b = [o.clone() for o in o8]
+nblk = (W // 8) * (H // 8)
+lv = [torch.empty((nblk, 64), dtype=torch.int16, device="cuda") for _ in range(2)]
+rn = [torch.empty((nblk, 64), dtype=torch.uint8, device="cuda") for _ in range(2)]
+ct = [torch.empty((nblk,), dtype=torch.uint8, device="cuda") for _ in range(2)]
+ycc = [torch.stack([u8[(i + k) % NS].reshape(H, W) for k in range(3)], dim=-1).contiguous() for i in range(2)]
+sy = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in range(2)]
+scb = [torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda") for _ in range(2)]
+scr = [torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda") for _ in range(2)]
+cases += [
+    ("zig-zag scan, i16 (2+2 B/px)", 4, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2]) for i in range(NS)]),
+    ("zig-zag + run/level, i16 (2+3)", 5.016, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
+    ("zig-zag + run/level, q32 (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_q32(q32b[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
+    ("4:2:0 split (3+3 B/px)", 6, W * H, [lambda i=i: M.split420_u8(ycc[i], W, H, sy[i], scb[i], scr[i]) for i in range(2)]),
+]
 # config 4 on one GPU: 256 independent 4096x4096 int16 planes, forward only.  Blocks are
 # independent, so a batch stacked in memory IS one tall plane: one launch, no per-plane drain.
 NB = 256
