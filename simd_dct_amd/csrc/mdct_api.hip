@@ -321,20 +321,26 @@ static int fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_
   for (int i = 0; i < 64; i++) // simd_dct.cpp:2239, :910 (x255 tiers) / :192 (scalar tiers)
     a.qt.q[i] = profile == MDCT_PROFILE_REF_SCALAR ? 1.f / (lut[i] * vr) : 255.0f / (lut[i] * vr);
   const bool safe = profile != MDCT_PROFILE_REF_SCALAR && table_needs_safe(a.qt.q);
-  if (profile == MDCT_PROFILE_REF_AVX)
-  { // the packed-fp32 kernel wants the multipliers in its register-pair order, negated for the fast quantiser
+  { // the packed-fp32 kernels want the multipliers in their register-pair order (mdct_kernels.hip: encode_block_*_pk):
+    // pair (m, j) = coefficients (kPairA[j], kPairB[j]) of the FIRST pass at index m of the SECOND pass.
+    // Q32 stores v*8+u with rows first (first-pass index = u); the encq layouts store u*8+v with rows first;
+    // the stereo layout stores v*8+u with columns first (first-pass index = v).
     static const int pa[4] = {0, 2, 1, 5}, pb[4] = {4, 6, 3, 7}; // == mdct::kPairA / kPairB
+    const bool q32 = layout == MDCT_LAYOUT_Q32;
     float t[64];
-    for (int v = 0; v < 8; v++)
+    for (int m = 0; m < 8; m++)
       for (int j = 0; j < 4; j++)
       {
-        t[(v * 4 + j) * 2] = a.qt.q[v * 8 + pa[j]];
-        t[(v * 4 + j) * 2 + 1] = a.qt.q[v * 8 + pb[j]];
+        t[(m * 4 + j) * 2] = a.qt.q[q32 ? m * 8 + pa[j] : pa[j] * 8 + m];
+        t[(m * 4 + j) * 2 + 1] = a.qt.q[q32 ? m * 8 + pb[j] : pb[j] * 8 + m];
       }
+    const bool negate = q32 && !safe; // the q32 fast quantiser works on -v (complement trick)
     for (int i = 0; i < 64; i++)
-      a.qt.q[i] = safe ? t[i] : -t[i];
+      a.qt.q[i] = negate ? -t[i] : t[i];
     const mdct::DctConsts &c = a.consts;
-    a.pk = mdct::PkConstsArg{{c.a, c.f}, {c.c, c.d}, {c.b, c.e}, {c.n, c.magic23 + 128.0f}};
+    a.pk = mdct::PkConstsArg{{c.a, c.f}, {c.c, c.d}, {c.b, c.e}, {c.n, q32 ? c.magic23 + 128.0f : c.magic23},
+                             {c.d, c.a}, {c.f, c.d}, {c.f, c.c}, {c.c, c.a},
+                             {profile == MDCT_PROFILE_REF_SCALAR ? 127.0f / 255.0f : 1.f / (float)0xFF, profile == MDCT_PROFILE_REF_SCALAR ? 255.0f : 127.0f}};
   }
   a.pitch = pitch_in;
   a.sizeX = sizeX;

@@ -62,14 +62,16 @@ struct OwnTables
 struct PkConstsArg
 {
   float af[2], cd[2], be[2], nm[2];
+  float da[2], fd[2], fc[2], ca[2]; // scalar tiers (K_TRUE): (Cd,Ca) (Cf,Cd) (Cf,Cc) (Cc,Ca)
+  float bias[2];                    // SSE tiers: (1/255, 127.0f); scalar tiers: (127/255, 255.0f)
 };
 
 struct U8Args
 {
   const uint8_t *from;
   uint8_t *to;
-  QuantTable qt;       // REF_AVX: in the packed kernel's pair order (mdct_api.hip)
-  PkConstsArg pk;      // REF_AVX only
+  QuantTable qt;       // in the packed kernels' register-pair order (mdct_api.hip: pair_order)
+  PkConstsArg pk;      // butterfly constants as the packed kernels consume them (mdct_api.hip)
   DctConsts consts;
   size_t pitch;        // input row pitch, bytes
   size_t sizeX;        // plane width, bytes (output addressing)

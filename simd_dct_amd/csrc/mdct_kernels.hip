@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mdct_kernels.h"
 
 #pragma clang fp contract(off)
@@ -29,59 +31,6 @@ namespace mdct
 // ~2000 straight-line VALU instructions per wave.
 
 enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2 }; // the reference's three 1-D kernels (the engine-own one is aan_fwd8 below)
-
-// ---------------------------------------------------------------------------------------
-// 1-D 8-point forward kernel on eight registers.
-// ---------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ void dct8(const DctConsts &C, float &p0, float &p1, float &p2, float &p3, float &p4, float &p5, float &p6, float &p7)
-{
-  const float kCa = C.a, kCb = C.b, kCc = C.c, kCd = C.d, kCe = C.e, kCf = C.f, kCn = C.n;
-  const float x07p = p0 + p7, x16p = p1 + p6, x25p = p2 + p5, x34p = p3 + p4;
-  const float x07m = p0 - p7, x61m = p6 - p1, x25m = p2 - p5, x43m = p4 - p3;
-  const float pp = x07p + x34p, pm = x07p - x34p;
-  const float qp = x16p + x25p, qm = x16p - x25p;
-
-  const float o0 = pp + qp;
-  const float o4 = pp - qp;
-  float o1, o2, o3, o5, o6, o7;
-
-  if constexpr (K == K_TRUE)
-  { // left-to-right association (:163-171)
-    o2 = kCb * pm + kCe * qm;
-    o6 = kCe * pm - kCb * qm;
-    o1 = ((kCa * x07m - kCc * x61m) + kCd * x25m) - kCf * x43m;
-    o3 = ((kCc * x07m + kCf * x61m) - kCa * x25m) + kCd * x43m;
-    o5 = ((kCd * x07m + kCa * x61m) + kCf * x25m) - kCc * x43m;
-    o7 = ((kCf * x07m + kCd * x61m) + kCc * x25m) + kCa * x43m;
-  }
-  else
-  { // pairwise association; a + (-b) == a - b and (-c)*x == -(c*x) exactly in IEEE,
-    // so only the k=1 (K_SSE, :550) and k=3 (K_AVX, :2181) sign quirks differ.
-    o2 = (kCb * pm) + (kCe * qm);
-    o6 = (kCe * pm) - (kCb * qm);
-    const float t1 = (kCa * x07m) - (kCc * x61m);
-    const float t3 = (kCc * x07m) + (kCf * x61m);
-    const float t5 = (kCd * x07m) + (kCa * x61m);
-    const float t7 = (kCf * x07m) + (kCd * x61m);
-    if constexpr (K == K_SSE)
-    {
-      o1 = t1 + ((kCd * x25m) + (kCf * x43m)); // quirk: +Cf
-      o3 = t3 + ((kCd * x43m) - (kCa * x25m)); // ((-Ca)*x25m) + (Cd*x43m)
-    }
-    else
-    {
-      static_assert(K == K_AVX, "unknown 1-D kernel");
-      o1 = t1 + ((kCd * x25m) - (kCf * x43m));
-      o3 = t3 - ((kCa * x25m) + (kCd * x43m)); // quirk: -Cd
-    }
-    o5 = t5 + ((kCf * x25m) - (kCc * x43m));
-    o7 = t7 + ((kCc * x25m) + (kCa * x43m));
-  }
-
-  p0 = kCn * o0; p1 = kCn * o1; p2 = kCn * o2; p3 = kCn * o3;
-  p4 = kCn * o4; p5 = kCn * o5; p6 = kCn * o6; p7 = kCn * o7;
-}
 
 // ---------------------------------------------------------------------------------------
 // Engine-own 1-D kernels (int16 / float32 paths; no reference counterpart): the scaled
@@ -160,22 +109,6 @@ __device__ __forceinline__ void raw_inv(const DctConsts &C, float (&b)[8][8])
     aan_inv8(C, b[r][0], b[r][1], b[r][2], b[r][3], b[r][4], b[r][5], b[r][6], b[r][7]);
 }
 
-template <int K>
-__device__ __forceinline__ void pass_rows(const DctConsts &C, float (&b)[8][8])
-{
-#pragma unroll
-  for (int r = 0; r < 8; r++)
-    dct8<K>(C, b[r][0], b[r][1], b[r][2], b[r][3], b[r][4], b[r][5], b[r][6], b[r][7]);
-}
-
-template <int K>
-__device__ __forceinline__ void pass_cols(const DctConsts &C, float (&b)[8][8])
-{
-#pragma unroll
-  for (int c = 0; c < 8; c++)
-    dct8<K>(C, b[0][c], b[1][c], b[2][c], b[3][c], b[4][c], b[5][c], b[6][c], b[7][c]);
-}
-
 // ---------------------------------------------------------------------------------------
 // K_AVX on packed fp32 (v_pk_add_f32 / v_pk_mul_f32): 28 instead of 56 instructions per 8-point
 // transform, identical bits.  Each half of a packed op is an individually rounded IEEE op, and
@@ -208,14 +141,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct PkConsts
 {
   f32x2 af, cd, be, nm; // (Ca,Cf) (Cc,Cd) (Cb,Ce) (Cn, rounding constant)
+  f32x2 da, fd, fc, ca; // K_TRUE only: (Cd,Ca) (Cf,Cd) (Cf,Cc) (Cc,Ca)
+  f32x2 bias;           // SSE tiers: (1/255, 127.0f);  scalar tiers: (127/255, 255.0f)
 };
-
 static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernels.h) is the kernel-argument image of PkConsts");
 
-// one block row held in 4 pairs -> (o0,o4) (o2,o6) (o1,o3) (o5,o7), each already times Cn
-__device__ __forceinline__ void dct8_avx_h(const PkConsts &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o13, f32x2 &o57)
+// one block row (or column) held in 4 pairs -> (o0,o4) (o2,o6) (o1,o3) (o5,o7), each already times Cn.
+// K selects the reference 1-D kernel being reproduced; they differ in the odd part only:
+//   K_AVX  :2176-2183  o1 = t1 + (Cd x25m - Cf x43m)       o3 = t3 - (Ca x25m + Cd x43m)   (k=3 quirk)
+//   K_SSE  :547-577    o1 = t1 + (Cd x25m + Cf x43m) (k=1 quirk)  o3 = t3 + (Cd x43m - Ca x25m)
+//   K_TRUE :163-171    left to right: o1 = (t1 + Cd x25m) - Cf x43m, o3 = (t3 - Ca x25m) + Cd x43m, ...
+template <int K1D>
+__device__ __forceinline__ void dct8_h(const PkConsts &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o13, f32x2 &o57)
 {
-  f32x2 s1, s2, d, e, pqp, pqm, r, t, m1, m2, m3, m4, n1, n2, n3, n4, t13, t57, u13, u57;
+  f32x2 s1, s2, d, e, pqp, pqm, r, t, m1, m2, m3, m4, t13, t57;
   MDCT_PKA(s1, a01, a67, MDCT_X);                                  // (p0+p7, p1+p6)
   MDCT_PKA(s2, a23, a45, MDCT_X);                                  // (p2+p5, p3+p4)
   MDCT_PKA(d, a01, a67, MDCT_X " neg_lo:[0,1] neg_hi:[1,0]");      // (p0-p7, p6-p1)
@@ -232,22 +171,48 @@ __device__ __forceinline__ void dct8_avx_h(const PkConsts &K, f32x2 a01, f32x2 a
   MDCT_PKM(m4, d, K.af, MDCT_K_HL);                                // (Cf x07m, Ca x61m)
   MDCT_PKA(t13, m1, m2, MDCT_X " neg_lo:[0,1]");                   // (Ca x07m - Cc x61m, Cf x61m + Cc x07m)
   MDCT_PKA(t57, m3, m4, MDCT_X);                                   // (Cd x07m + Ca x61m, Cd x61m + Cf x07m)
-  MDCT_PKM(n1, e, K.cd, MDCT_K_HH);                                // (Cd x25m, Cd x43m)
-  MDCT_PKM(n2, e, K.af, MDCT_K_LH);                                // (Ca x25m, Cf x43m)
-  MDCT_PKM(n3, e, K.af, MDCT_K_HL);                                // (Cf x25m, Ca x43m)
-  MDCT_PKM(n4, e, K.cd, MDCT_K_LL);                                // (Cc x25m, Cc x43m)
-  MDCT_PKA(u13, n1, n2, MDCT_X " neg_lo:[0,1]");                   // (Cd x25m - Cf x43m, Cd x43m + Ca x25m)
-  MDCT_PKA(u57, n3, n4, MDCT_X " neg_lo:[0,1]");                   // (Cf x25m - Cc x43m, Ca x43m + Cc x25m)
-  MDCT_PKA(o13, t13, u13, "neg_hi:[0,1]");                         // (t1 + u1, t3 - u3): the k=3 quirk of :2181
-  MDCT_PKA(o57, t57, u57, "");                                     // (t5 + u5, t7 + u7)
+  if constexpr (K1D == K_TRUE)
+  { // sequential association: two more terms added one after the other
+    f32x2 g1, g2, g3, g4, h13, h57;
+    MDCT_PKM(g1, e, K.da, "op_sel:[0,0] op_sel_hi:[0,1]");         // (Cd x25m, Ca x25m)
+    MDCT_PKM(g2, e, K.fd, "op_sel:[1,0] op_sel_hi:[1,1]");         // (Cf x43m, Cd x43m)
+    MDCT_PKM(g3, e, K.fc, "op_sel:[0,0] op_sel_hi:[0,1]");         // (Cf x25m, Cc x25m)
+    MDCT_PKM(g4, e, K.ca, "op_sel:[1,0] op_sel_hi:[1,1]");         // (Cc x43m, Ca x43m)
+    MDCT_PKA(h13, t13, g1, "neg_hi:[0,1]");                        // (t1 + Cd x25m, t3 - Ca x25m)
+    MDCT_PKA(o13, h13, g2, "neg_lo:[0,1]");                        // (.. - Cf x43m, .. + Cd x43m)
+    MDCT_PKA(h57, t57, g3, "");                                    // (t5 + Cf x25m, t7 + Cc x25m)
+    MDCT_PKA(o57, h57, g4, "neg_lo:[0,1]");                        // (.. - Cc x43m, .. + Ca x43m)
+  }
+  else
+  {
+    f32x2 n1, n2, n3, n4, u13, u57;
+    MDCT_PKM(n1, e, K.cd, MDCT_K_HH);                              // (Cd x25m, Cd x43m)
+    MDCT_PKM(n2, e, K.af, MDCT_K_LH);                              // (Ca x25m, Cf x43m)
+    MDCT_PKM(n3, e, K.af, MDCT_K_HL);                              // (Cf x25m, Ca x43m)
+    MDCT_PKM(n4, e, K.cd, MDCT_K_LL);                              // (Cc x25m, Cc x43m)
+    MDCT_PKA(u57, n3, n4, MDCT_X " neg_lo:[0,1]");                 // (Cf x25m - Cc x43m, Ca x43m + Cc x25m)
+    if constexpr (K1D == K_AVX)
+    {
+      MDCT_PKA(u13, n1, n2, MDCT_X " neg_lo:[0,1]");               // (Cd x25m - Cf x43m, Cd x43m + Ca x25m)
+      MDCT_PKA(o13, t13, u13, "neg_hi:[0,1]");                     // (t1 + u1, t3 - u3): the k=3 quirk of :2181
+    }
+    else
+    {
+      static_assert(K1D == K_SSE, "unknown 1-D kernel");
+      MDCT_PKA(u13, n1, n2, MDCT_X " neg_hi:[0,1]");               // (Cd x25m + Cf x43m [k=1 quirk, :550], Cd x43m - Ca x25m)
+      MDCT_PKA(o13, t13, u13, "");
+    }
+    MDCT_PKA(o57, t57, u57, "");                                   // (t5 + u5, t7 + u7)
+  }
   MDCT_PKM(o04, o04, K.nm, MDCT_K_LL);
   MDCT_PKM(o26, o26, K.nm, MDCT_K_LL);
   MDCT_PKM(o13, o13, K.nm, MDCT_K_LL);
   MDCT_PKM(o57, o57, K.nm, MDCT_K_LL);
 }
 
-// the same transform down a column PAIR, p[r] = (B[r][u1], B[r][u2]), in place
-__device__ __forceinline__ void dct8_avx_v(const PkConsts &K, f32x2 (&p)[8])
+// the same transform down a PAIR of independent columns (or rows), p[r] = (B[r][u1], B[r][u2]), in place
+template <int K1D>
+__device__ __forceinline__ void dct8_v(const PkConsts &K, f32x2 (&p)[8])
 {
   f32x2 x07p, x16p, x25p, x34p, x07m, x61m, x25m, x43m, pp, pm, qp, qm, o0, o4, a, b, o2, o6;
   MDCT_PKA(x07p, p[0], p[7], ""); MDCT_PKA(x16p, p[1], p[6], ""); MDCT_PKA(x25p, p[2], p[5], ""); MDCT_PKA(x34p, p[3], p[4], "");
@@ -258,17 +223,37 @@ __device__ __forceinline__ void dct8_avx_v(const PkConsts &K, f32x2 (&p)[8])
   MDCT_PKA(o0, pp, qp, ""); MDCT_PKA(o4, pp, qp, MDCT_NEG_B);
   MDCT_PKM(a, pm, K.be, MDCT_K_LL); MDCT_PKM(b, qm, K.be, MDCT_K_HH); MDCT_PKA(o2, a, b, "");          // Cb pm + Ce qm
   MDCT_PKM(a, pm, K.be, MDCT_K_HH); MDCT_PKM(b, qm, K.be, MDCT_K_LL); MDCT_PKA(o6, a, b, MDCT_NEG_B);  // Ce pm - Cb qm
-  f32x2 t1, t3, t5, t7, u1, u3, u5, u7, c, dd;
+  f32x2 t1, t3, t5, t7, c, dd, o1, o3, o5, o7;
   MDCT_PKM(a, x07m, K.af, MDCT_K_LL); MDCT_PKM(b, x61m, K.cd, MDCT_K_LL); MDCT_PKA(t1, a, b, MDCT_NEG_B);   // Ca x07m - Cc x61m
   MDCT_PKM(a, x07m, K.cd, MDCT_K_LL); MDCT_PKM(b, x61m, K.af, MDCT_K_HH); MDCT_PKA(t3, a, b, "");           // Cc x07m + Cf x61m
   MDCT_PKM(a, x07m, K.cd, MDCT_K_HH); MDCT_PKM(b, x61m, K.af, MDCT_K_LL); MDCT_PKA(t5, a, b, "");           // Cd x07m + Ca x61m
   MDCT_PKM(a, x07m, K.af, MDCT_K_HH); MDCT_PKM(b, x61m, K.cd, MDCT_K_HH); MDCT_PKA(t7, a, b, "");           // Cf x07m + Cd x61m
-  MDCT_PKM(c, x25m, K.cd, MDCT_K_HH); MDCT_PKM(dd, x43m, K.af, MDCT_K_HH); MDCT_PKA(u1, c, dd, MDCT_NEG_B); // Cd x25m - Cf x43m
-  MDCT_PKM(c, x25m, K.af, MDCT_K_LL); MDCT_PKM(dd, x43m, K.cd, MDCT_K_HH); MDCT_PKA(u3, c, dd, "");         // Ca x25m + Cd x43m
-  MDCT_PKM(c, x25m, K.af, MDCT_K_HH); MDCT_PKM(dd, x43m, K.cd, MDCT_K_LL); MDCT_PKA(u5, c, dd, MDCT_NEG_B); // Cf x25m - Cc x43m
-  MDCT_PKM(c, x25m, K.cd, MDCT_K_LL); MDCT_PKM(dd, x43m, K.af, MDCT_K_LL); MDCT_PKA(u7, c, dd, "");         // Cc x25m + Ca x43m
-  f32x2 o1, o3, o5, o7;
-  MDCT_PKA(o1, t1, u1, ""); MDCT_PKA(o3, t3, u3, MDCT_NEG_B); MDCT_PKA(o5, t5, u5, ""); MDCT_PKA(o7, t7, u7, "");
+  if constexpr (K1D == K_TRUE)
+  { // ((t + c1 x25m) +- c2 x43m), :166-171
+    MDCT_PKM(c, x25m, K.cd, MDCT_K_HH); MDCT_PKA(t1, t1, c, "");         MDCT_PKM(dd, x43m, K.af, MDCT_K_HH); MDCT_PKA(o1, t1, dd, MDCT_NEG_B);
+    MDCT_PKM(c, x25m, K.af, MDCT_K_LL); MDCT_PKA(t3, t3, c, MDCT_NEG_B); MDCT_PKM(dd, x43m, K.cd, MDCT_K_HH); MDCT_PKA(o3, t3, dd, "");
+    MDCT_PKM(c, x25m, K.af, MDCT_K_HH); MDCT_PKA(t5, t5, c, "");         MDCT_PKM(dd, x43m, K.cd, MDCT_K_LL); MDCT_PKA(o5, t5, dd, MDCT_NEG_B);
+    MDCT_PKM(c, x25m, K.cd, MDCT_K_LL); MDCT_PKA(t7, t7, c, "");         MDCT_PKM(dd, x43m, K.af, MDCT_K_LL); MDCT_PKA(o7, t7, dd, "");
+  }
+  else
+  {
+    f32x2 u1, u3, u5, u7;
+    MDCT_PKM(c, x25m, K.af, MDCT_K_HH); MDCT_PKM(dd, x43m, K.cd, MDCT_K_LL); MDCT_PKA(u5, c, dd, MDCT_NEG_B); // Cf x25m - Cc x43m
+    MDCT_PKM(c, x25m, K.cd, MDCT_K_LL); MDCT_PKM(dd, x43m, K.af, MDCT_K_LL); MDCT_PKA(u7, c, dd, "");         // Cc x25m + Ca x43m
+    if constexpr (K1D == K_AVX)
+    {
+      MDCT_PKM(c, x25m, K.cd, MDCT_K_HH); MDCT_PKM(dd, x43m, K.af, MDCT_K_HH); MDCT_PKA(u1, c, dd, MDCT_NEG_B); // Cd x25m - Cf x43m
+      MDCT_PKM(c, x25m, K.af, MDCT_K_LL); MDCT_PKM(dd, x43m, K.cd, MDCT_K_HH); MDCT_PKA(u3, c, dd, "");         // Ca x25m + Cd x43m
+      MDCT_PKA(o1, t1, u1, ""); MDCT_PKA(o3, t3, u3, MDCT_NEG_B);
+    }
+    else
+    {
+      MDCT_PKM(c, x25m, K.cd, MDCT_K_HH); MDCT_PKM(dd, x43m, K.af, MDCT_K_HH); MDCT_PKA(u1, c, dd, "");         // Cd x25m + Cf x43m (quirk)
+      MDCT_PKM(c, x43m, K.cd, MDCT_K_HH); MDCT_PKM(dd, x25m, K.af, MDCT_K_LL); MDCT_PKA(u3, c, dd, MDCT_NEG_B); // Cd x43m - Ca x25m
+      MDCT_PKA(o1, t1, u1, ""); MDCT_PKA(o3, t3, u3, "");
+    }
+    MDCT_PKA(o5, t5, u5, ""); MDCT_PKA(o7, t7, u7, "");
+  }
   MDCT_PKM(p[0], o0, K.nm, MDCT_K_LL); MDCT_PKM(p[1], o1, K.nm, MDCT_K_LL); MDCT_PKM(p[2], o2, K.nm, MDCT_K_LL); MDCT_PKM(p[3], o3, K.nm, MDCT_K_LL);
   MDCT_PKM(p[4], o4, K.nm, MDCT_K_LL); MDCT_PKM(p[5], o5, K.nm, MDCT_K_LL); MDCT_PKM(p[6], o6, K.nm, MDCT_K_LL); MDCT_PKM(p[7], o7, K.nm, MDCT_K_LL);
 }
@@ -298,42 +283,6 @@ __device__ __forceinline__ int32_t cvtps_epi32_exact(float v)
 
 __device__ __forceinline__ int32_t clamp255(int32_t v) { return min(max(v, 0), 255); } // v_med3_i32
 
-// B1 :2224  clamp(127 + rne(f*q), 0, 255)   (wrapping int32 add, like _mm256_add_epi32)
-template <bool SAFE>
-__device__ __forceinline__ uint32_t quant_avx(float f, float q, float magic23)
-{
-  const float v = f * q;
-  if constexpr (SAFE)
-    return (uint32_t)clamp255((int32_t)((uint32_t)cvtps_epi32_exact(v) + 127u));
-  else
-    return __float_as_uint(__builtin_amdgcn_fmed3f(v, -127.0f, 128.0f) + magic23) + 127u;
-}
-
-// B2/B3 :1020  clamp(rne(f*q + 127.0f), 0, 255)
-template <bool SAFE>
-__device__ __forceinline__ uint32_t quant_sse(float f, float q, float magic23)
-{
-  const float v = (f * q) + 127.0f;
-  if constexpr (SAFE)
-    return (uint32_t)clamp255(cvtps_epi32_exact(v));
-  else
-    return __float_as_uint(__builtin_amdgcn_fmed3f(v, 0.0f, 255.0f) + magic23);
-}
-
-// B4/B5 :245, :362  (uint8_t)roundf(_clamp(f*qs + 127/255, 0, 1) * 255)
-// roundf (half away from zero) of x in [0, 255] without libm: r = rne(x) by the magic add, and
-// the two differ only at an exact tie that rne resolved downwards (x - r == +0.5), where roundf
-// wants r + 1.  x - r is exact (|x - r| <= 0.5 and both are multiples of ulp(x)).
-__device__ __forceinline__ uint32_t quant_scalar(float f, float qs, float magic23)
-{
-  float v = (f * qs) + (127.0f / 255.0f);
-  v = v > 0.f ? (v < 1.f ? v : 1.f) : 0.f; // _clamp(v, 0, 1) of :50-54, NaN -> 0
-  const float x = v * 255.f;
-  const float t = x + magic23;
-  const float r = t - magic23;
-  return __float_as_uint(t) + ((x - r) == 0.5f ? 1u : 0u);
-}
-
 // ---------------------------------------------------------------------------------------
 // u8 forward + quantise + reorder.
 // ---------------------------------------------------------------------------------------
@@ -362,105 +311,12 @@ __device__ __forceinline__ float ubyte_to_float(uint32_t w)
   return f;
 }
 
-template <int PROFILE>
-__device__ __forceinline__ float px_to_float(float f)
-{
-  if constexpr (PROFILE == MDCT_PROFILE_REF_AVX)
-    return f; // :2143, raw 0..255
-  else if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
-    return (1.f / (float)0xFF) * f; // :949
-  else
-    return f / 255.f; // :222, :343 (true division)
-}
-
-// Loads the lane's block, runs both passes in the profile's order and returns the 64
-// quantised bytes as int values q[v][u] (natural index) for the AVX/stereo layouts or
-// q[u][v]-transposed-stored semantics handled by the caller.
 // the lane's block as eight 8-byte rows, all eight loads in flight together
 __device__ __forceinline__ void load_block_rows(const uint8_t *src, size_t pitch, uint2 (&rows)[8])
 {
 #pragma unroll
   for (int r = 0; r < 8; r++)
     rows[r] = load8(src + (size_t)r * pitch);
-}
-
-// convert (consumes `rows`), both passes in the profile's order, quantise: out[s] = word whose low
-// byte is the coefficient at stored index s
-template <int PROFILE, int LAYOUT, bool SAFE>
-__device__ __forceinline__ void encode_rows(const DctConsts &C, const uint2 (&rows)[8], const QuantTable &qt, const float *px_div255, float (&b)[8][8])
-{
-#pragma unroll
-  for (int r = 0; r < 8; r++)
-  {
-    const uint2 v = rows[r];
-    if constexpr (PROFILE == MDCT_PROFILE_REF_SCALAR)
-    { // px / 255.f (:222, :343) has only 256 possible results: looked up, not divided (see kernel)
-      b[r][0] = px_div255[v.x & 0xFF];
-      b[r][1] = px_div255[(v.x >> 8) & 0xFF];
-      b[r][2] = px_div255[(v.x >> 16) & 0xFF];
-      b[r][3] = px_div255[v.x >> 24];
-      b[r][4] = px_div255[v.y & 0xFF];
-      b[r][5] = px_div255[(v.y >> 8) & 0xFF];
-      b[r][6] = px_div255[(v.y >> 16) & 0xFF];
-      b[r][7] = px_div255[v.y >> 24];
-    }
-    else
-    {
-      b[r][0] = px_to_float<PROFILE>(ubyte_to_float<0>(v.x));
-      b[r][1] = px_to_float<PROFILE>(ubyte_to_float<1>(v.x));
-      b[r][2] = px_to_float<PROFILE>(ubyte_to_float<2>(v.x));
-      b[r][3] = px_to_float<PROFILE>(ubyte_to_float<3>(v.x));
-      b[r][4] = px_to_float<PROFILE>(ubyte_to_float<0>(v.y));
-      b[r][5] = px_to_float<PROFILE>(ubyte_to_float<1>(v.y));
-      b[r][6] = px_to_float<PROFILE>(ubyte_to_float<2>(v.y));
-      b[r][7] = px_to_float<PROFILE>(ubyte_to_float<3>(v.y));
-    }
-  }
-
-  (void)C; (void)qt;
-}
-
-template <int PROFILE, int LAYOUT, bool SAFE>
-__device__ __forceinline__ void transform_quantise(const DctConsts &C, float (&b)[8][8], const QuantTable &qt, uint32_t (&out)[64])
-{
-  constexpr int K = PROFILE == MDCT_PROFILE_REF_AVX ? K_AVX : (PROFILE == MDCT_PROFILE_REF_SSE ? K_SSE : K_TRUE);
-  // STEREO tiers transpose first (T, rows, T, rows == columns then rows, :961-1004, :225-241);
-  // Q32 and the encq tiers run rows then columns (:2158/:2189, :347-358, :1608-1636).
-  if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
-  {
-    pass_cols<K>(C, b);
-    pass_rows<K>(C, b);
-  }
-  else
-  {
-    pass_rows<K>(C, b);
-    pass_cols<K>(C, b);
-  }
-
-  // Stored index s: natural v*8+u for Q32/STEREO, transposed u*8+v for the encq tiers,
-  // with the quantiser taken AT THE STORED INDEX (:362, :1651).
-#pragma unroll
-  for (int s = 0; s < 64; s++)
-  {
-    const int hi = s >> 3, lo = s & 7;
-    const float f = (LAYOUT == MDCT_LAYOUT_BLOCK || LAYOUT == MDCT_LAYOUT_BLOCK_SSE) ? b[lo][hi] : b[hi][lo];
-    if constexpr (PROFILE == MDCT_PROFILE_REF_AVX)
-      out[s] = quant_avx<SAFE>(f, qt.q[s], C.magic23);
-    else if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
-      out[s] = quant_sse<SAFE>(f, qt.q[s], C.magic23);
-    else
-      out[s] = quant_scalar(f, qt.q[s], C.magic23);
-  }
-}
-
-template <int PROFILE, int LAYOUT, bool SAFE>
-__device__ __forceinline__ void encode_block(const DctConsts &C, const uint8_t *src, size_t pitch, const QuantTable &qt, const float *px_div255, uint32_t (&out)[64])
-{
-  uint2 rows[8];
-  load_block_rows(src, pitch, rows);
-  float b[8][8];
-  encode_rows<PROFILE, LAYOUT, SAFE>(C, rows, qt, px_div255, b);
-  transform_quantise<PROFILE, LAYOUT, SAFE>(C, b, qt, out);
 }
 
 // B1 on packed fp32: raw bytes -> both passes -> quantise; out[v*8+u] = word whose low byte is the
@@ -485,12 +341,12 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
     const f32x2 a23 = {ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
     const f32x2 a45 = {ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)};
     const f32x2 a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
-    dct8_avx_h(K, a01, a23, a45, a67, col[0][r], col[1][r], col[2][r], col[3][r]);
+    dct8_h<K_AVX>(K, a01, a23, a45, a67, col[0][r], col[1][r], col[2][r], col[3][r]);
   }
 #pragma unroll
   for (int j = 0; j < 4; j++)
   {
-    dct8_avx_v(K, col[j]);
+    dct8_v<K_AVX>(K, col[j]);
 #pragma unroll
     for (int v = 0; v < 8; v++)
     {
@@ -510,6 +366,98 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
         MDCT_PKA(t, m, K.nm, MDCT_K_HH); // + (magic, magic)
         out[v * 8 + kPairA[j]] = __float_as_uint(t.x);
         out[v * 8 + kPairB[j]] = __float_as_uint(t.y);
+      }
+    }
+  }
+}
+
+// B2..B5 on packed fp32.  The first pass runs "horizontally" over the 8 lines of the block (rows for the
+// encq tiers, :347-358 / :1608-1636; columns for the stereo tiers, which transpose first, :961-1004 /
+// :225-241), leaving the pairs (0,4)(2,6)(1,3)(5,7) of first-pass coefficients side by side; the second
+// pass runs "vertically" on those four pairs.  P[j][m] then holds coefficients (kPairA[j], m) and
+// (kPairB[j], m) in (first-pass index, second-pass index) terms, and both layouts store index
+// first*8 + second: u*8+v for the encq tiers (:362, :1651), v*8+u for the stereo tiers.  `qt` holds the
+// multipliers in that pair order, (m*4+j)*2 + {0,1} (mdct_api.hip).  Same bits as encode_block.
+template <int PROFILE, int LAYOUT, bool SAFE>
+__device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (&rows)[8], const QuantTable &qt, const float *px_div255, uint32_t (&out)[64])
+{
+  constexpr int K1D = PROFILE == MDCT_PROFILE_REF_SSE ? K_SSE : K_TRUE;
+  constexpr bool COLS_FIRST = LAYOUT == MDCT_LAYOUT_STEREO;
+  // pixel (r, c) as the tier's float: byte c of row r
+  auto px = [&](auto r_, auto c_) {
+    constexpr int r = decltype(r_)::value, c = decltype(c_)::value;
+    const uint32_t w = c < 4 ? rows[r].x : rows[r].y;
+    if constexpr (PROFILE == MDCT_PROFILE_REF_SCALAR)
+      return px_div255[(w >> (8 * (c & 3))) & 0xFF]; // px / 255.f (:222, :343), one of 256 values (see kernel)
+    else
+      return ubyte_to_float<(c & 3)>(w);
+  };
+  f32x2 P[4][8];
+  auto line = [&](auto i_) {
+    constexpr int i = decltype(i_)::value;
+    auto at = [&](auto k_) { // k-th value of line i
+      if constexpr (COLS_FIRST)
+        return px(k_, i_);
+      else
+        return px(i_, k_);
+    };
+    using std::integral_constant;
+    f32x2 a01 = {at(integral_constant<int, 0>{}), at(integral_constant<int, 1>{})};
+    f32x2 a23 = {at(integral_constant<int, 2>{}), at(integral_constant<int, 3>{})};
+    f32x2 a45 = {at(integral_constant<int, 4>{}), at(integral_constant<int, 5>{})};
+    f32x2 a67 = {at(integral_constant<int, 6>{}), at(integral_constant<int, 7>{})};
+    if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
+    { // px * (1.0f / 255.0f), :949
+      MDCT_PKM(a01, a01, K.bias, MDCT_K_LL);
+      MDCT_PKM(a23, a23, K.bias, MDCT_K_LL);
+      MDCT_PKM(a45, a45, K.bias, MDCT_K_LL);
+      MDCT_PKM(a67, a67, K.bias, MDCT_K_LL);
+    }
+    dct8_h<K1D>(K, a01, a23, a45, a67, P[0][i], P[1][i], P[2][i], P[3][i]);
+  };
+  line(std::integral_constant<int, 0>{}); line(std::integral_constant<int, 1>{}); line(std::integral_constant<int, 2>{}); line(std::integral_constant<int, 3>{});
+  line(std::integral_constant<int, 4>{}); line(std::integral_constant<int, 5>{}); line(std::integral_constant<int, 6>{}); line(std::integral_constant<int, 7>{});
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    dct8_v<K1D>(K, P[j]);
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+    {
+      const f32x2 qp = reinterpret_cast<const f32x2 *>(qt.q)[m * 4 + j];
+      const int sa = kPairA[j] * 8 + m, sb = kPairB[j] * 8 + m;
+      f32x2 v;
+      MDCT_PKM(v, P[j][m], qp, MDCT_K_LH);
+      if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
+      { // B2/B3 :1020  clamp(rne(f*q + 127.0f), 0, 255)
+        MDCT_PKA(v, v, K.bias, MDCT_K_HH);
+        if constexpr (SAFE)
+        {
+          out[sa] = (uint32_t)clamp255(cvtps_epi32_exact(v.x));
+          out[sb] = (uint32_t)clamp255(cvtps_epi32_exact(v.y));
+        }
+        else
+        {
+          f32x2 t;
+          v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 255.0f);
+          v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 255.0f);
+          MDCT_PKA(t, v, K.nm, MDCT_K_HH);
+          out[sa] = __float_as_uint(t.x);
+          out[sb] = __float_as_uint(t.y);
+        }
+      }
+      else
+      { // B4/B5 :245, :362  (uint8_t)roundf(_clamp(f*qs + 127/255, 0, 1) * 255), see quant_scalar
+        f32x2 x, t, r, d;
+        MDCT_PKA(v, v, K.bias, MDCT_K_LL);
+        v.x = v.x > 0.f ? (v.x < 1.f ? v.x : 1.f) : 0.f;
+        v.y = v.y > 0.f ? (v.y < 1.f ? v.y : 1.f) : 0.f;
+        MDCT_PKM(x, v, K.bias, MDCT_K_HH);
+        MDCT_PKA(t, x, K.nm, MDCT_K_HH);
+        MDCT_PKA(r, t, K.nm, MDCT_K_HH " " MDCT_NEG_B);
+        MDCT_PKA(d, x, r, MDCT_NEG_B);
+        out[sa] = __float_as_uint(t.x) + (d.x == 0.5f ? 1u : 0u);
+        out[sb] = __float_as_uint(t.y) + (d.y == 0.5f ? 1u : 0u);
       }
     }
   }
@@ -613,11 +561,16 @@ __global__ __launch_bounds__(kWG, (SAFE || GENERAL) ? 1 : MDCT_Q32_MINW) void k_
   }
 }
 
-// The other tiers / layouts.
+// The other tiers / layouts.  Occupancy steering, measured optimum of {default, 3..6} waves/SIMD
+// (profiles/r02_u8_tiers_waves_per_eu.log): the SSE encq tier's half-written 4-byte stores like few
+// waves (38.8 us at 3, 42.7 unsteered), the scalar stereo tier 4 (46.1 vs 49.5); the others are best
+// left to the compiler (stereo/SSE 31.4 us unsteered, 34-36 steered).
 #ifdef MDCT_U8_WAVES
 #define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8_WAVES, MDCT_U8_WAVES)))
 #else
-#define MDCT_U8_ATTR __launch_bounds__(kWG)
+constexpr int u8_waves_lo(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 3 : ((layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR) ? 4 : 1); }
+constexpr int u8_waves_hi(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 3 : ((layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR) ? 4 : 8); }
+#define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(u8_waves_lo(PROFILE, LAYOUT), u8_waves_hi(PROFILE, LAYOUT))))
 #endif
 template <int PROFILE, int LAYOUT, bool SAFE>
 __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
@@ -657,7 +610,9 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
     const uint8_t *src = a.from + (size_t)by * 8 * a.pitch + (size_t)bx * 8;
     if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
       src += (size_t)eye * a.eye_offset;
-    encode_block<PROFILE, LAYOUT, SAFE>(a.consts, src, a.pitch, a.qt, px_div255, q);
+    uint2 rows[8];
+    load_block_rows(src, a.pitch, rows);
+    encode_block_pk<PROFILE, LAYOUT, SAFE>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, px_div255, q);
   }
 
   if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)

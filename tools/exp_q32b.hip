@@ -7,6 +7,7 @@
 //   v_dma      v_not + persistent waves, next tile prefetched by LDS-DMA (global_load_lds_dwordx4)
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -Iinclude -Isimd_dct_amd/csrc tools/exp_q32b.hip -o tools/exp_q32b
 #include "../simd_dct_amd/csrc/mdct_kernels.hip"
+#include "scalar_forms.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>

@@ -13,6 +13,7 @@ lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
 calls = {
     "q32": [M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, H // 8) for i in range(4)],
     "stereo_sse": [M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, H // 16, layout=M.LAYOUT_STEREO, profile=M.PROFILE_REF_SSE) for i in range(4)],
+    "stereo_scalar": [M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, H // 16, layout=M.LAYOUT_STEREO, profile=M.PROFILE_REF_SCALAR) for i in range(4)],
     "encq_scalar": [M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, H // 8, layout=M.LAYOUT_BLOCK, profile=M.PROFILE_REF_SCALAR) for i in range(4)],
     "encq_sse": [M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, H // 8, layout=M.LAYOUT_BLOCK_SSE, profile=M.PROFILE_REF_SSE) for i in range(4)],
 }
