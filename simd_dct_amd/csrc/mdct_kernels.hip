@@ -450,8 +450,9 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
       { // B4/B5 :245, :362  (uint8_t)roundf(_clamp(f*qs + 127/255, 0, 1) * 255), see quant_scalar
         f32x2 x, t, r, d;
         MDCT_PKA(v, v, K.bias, MDCT_K_LL);
-        v.x = v.x > 0.f ? (v.x < 1.f ? v.x : 1.f) : 0.f;
-        v.y = v.y > 0.f ? (v.y < 1.f ? v.y : 1.f) : 0.f;
+        // _clamp(v, 0, 1) of :50-54 with NaN -> 0: v_med3_f32 returns min3 when an operand is NaN, and min ignores NaN
+        v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 1.0f);
+        v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 1.0f);
         MDCT_PKM(x, v, K.bias, MDCT_K_HH);
         MDCT_PKA(t, x, K.nm, MDCT_K_HH);
         MDCT_PKA(r, t, K.nm, MDCT_K_HH " " MDCT_NEG_B);
