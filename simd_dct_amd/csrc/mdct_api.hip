@@ -155,7 +155,9 @@ void aan_tables(float *fwd, float *inv)
 }
 
 // forward multiplier = (1/lut) * scale, inverse multiplier = lut * scale, each one float op
-int make_own_tables(const float *lut, mdct::OwnTables &tb)
+// pair_order: the fused round trip runs on packed fp32 and wants both tables in the register-pair order of its
+// column pass, (v*4 + j)*2 + {0,1} = (v, kAanPairA[j]) / (v, kAanPairB[j])  (mdct_kernels.hip: i16_roundtrip_pk)
+int make_own_tables(const float *lut, mdct::OwnTables &tb, bool pair_order = false)
 {
   float ft[64], it[64];
   aan_tables(ft, it);
@@ -165,6 +167,19 @@ int make_own_tables(const float *lut, mdct::OwnTables &tb)
       return fail(MDCT_INVALID_PARAMETER, "quantisation table entry %d is %g; the int16 paths need finite non-zero entries", i, (double)lut[i]);
     tb.qf[i] = lut ? (1.0f / lut[i]) * ft[i] : ft[i];
     tb.dq[i] = lut ? lut[i] * it[i] : it[i];
+  }
+  if (pair_order)
+  {
+    static const int pa[4] = {0, 2, 5, 1}, pb[4] = {4, 6, 3, 7}; // == mdct::kAanPairA / kAanPairB
+    mdct::OwnTables t = tb;
+    for (int v = 0; v < 8; v++)
+      for (int j = 0; j < 4; j++)
+      {
+        tb.qf[(v * 4 + j) * 2] = t.qf[v * 8 + pa[j]];
+        tb.qf[(v * 4 + j) * 2 + 1] = t.qf[v * 8 + pb[j]];
+        tb.dq[(v * 4 + j) * 2] = t.dq[v * 8 + pa[j]];
+        tb.dq[(v * 4 + j) * 2 + 1] = t.dq[v * 8 + pb[j]];
+      }
   }
   return MDCT_SUCCESS;
 }
@@ -187,7 +202,7 @@ int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t 
   a.by0 = (uint32_t)by0;
   if ((r = count_blocks(sizeX / 8, by1 - by0, &a.nblocks)))
     return r;
-  if ((r = make_own_tables(lut, a.tb)))
+  if ((r = make_own_tables(lut, a.tb, mode == mdct::MODE_ROUNDTRIP)))
     return r;
   const hipError_t e = mdct::launch_i16(a, mode, lut != nullptr, (hipStream_t)stream);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "i16 kernel launch");

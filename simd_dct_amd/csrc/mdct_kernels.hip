@@ -14,6 +14,7 @@
 //   1-D kernels   K_AVX :2158-2184   K_SSE :434-654   K_TRUE :138-172
 //   block drivers B1 :2064-2262  B2 :896-1103  B3 :1540-1704  B4 :177-298  B5 :300-395
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -792,6 +793,190 @@ __device__ __forceinline__ void i16_block(const DctConsts &C, const int16_t *src
     store_i16x8<SHIFT>(C, dst + (size_t)r * pitch_out, b[r]);
 }
 
+// The AAN butterflies on packed fp32 (fused round trip; profiles/r02_exp_i16_packed.log).  Same idea as the u8
+// tiers above: rows "horizontally" on 4 register pairs with op_sel / neg modifiers, columns "vertically" on pairs of
+// columns.  AAN's flow graph leaves 6 (forward) / 12 (inverse) operations per horizontal transform without a
+// partner; they stay scalar.  Every packed or scalar operation is the individually rounded IEEE operation of
+// aan_fwd8 / aan_inv8, so the results are bit-identical (and are tested as such against the CPU checker).
+// The first ten floats of DctConsts are laid out as the pairs these functions consume.
+struct AanPk
+{
+  f32x2 c707_382;   // (cos(pi/4), cos(3pi/8))
+  f32x2 c541_1306;  // (cos(pi/8)-cos(3pi/8), cos(pi/8)+cos(3pi/8))
+  f32x2 c1414_1847; // (sqrt 2, 2cos(pi/8))
+  f32x2 c1082_2613;
+  f32x2 magic;      // (1.5*2^23, 1.5*2^29)
+};
+static_assert(offsetof(DctConsts, c707) == 0 && offsetof(DctConsts, c382) == 4 && offsetof(DctConsts, c541) == 8 && offsetof(DctConsts, c1306) == 12 &&
+                  offsetof(DctConsts, c1414) == 16 && offsetof(DctConsts, c1847) == 20 && offsetof(DctConsts, c1082) == 24 && offsetof(DctConsts, c2613) == 28 &&
+                  offsetof(DctConsts, magic23) == 32 && offsetof(DctConsts, magic29) == 36,
+              "AanPk views the head of DctConsts");
+
+#define MDCT_LOLO "op_sel:[0,0] op_sel_hi:[0,0]"
+#define MDCT_HIHI "op_sel:[1,1] op_sel_hi:[1,1]"
+#define MDCT_LOHI "op_sel:[0,1] op_sel_hi:[0,1]" // src0.lo with src1.hi, for both halves
+#define MDCT_HILO "op_sel:[1,0] op_sel_hi:[1,0]"
+#define MDCT_SUMDIFF "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" // (a.lo + a.hi, a.lo - a.hi) when both sources are a
+
+// forward, one line in natural pairs (p0,p1)(p2,p3)(p4,p5)(p6,p7) -> (y0,y4) (y2,y6) (y5,y3) (y1,y7)
+__device__ __forceinline__ void aan_fwd_h(const AanPk &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o53, f32x2 &o17)
+{
+  f32x2 t01, t23, t76, t54, e01, e32, w, o, z13, z24, z1113;
+  MDCT_PKA(t01, a01, a67, MDCT_X);                   // (t0, t1) = (p0+p7, p1+p6)
+  MDCT_PKA(t23, a23, a45, MDCT_X);                   // (t2, t3) = (p2+p5, p3+p4)
+  MDCT_PKA(t76, a01, a67, MDCT_X " " MDCT_NEG_B);    // (t7, t6) = (p0-p7, p1-p6)
+  MDCT_PKA(t54, a23, a45, MDCT_X " " MDCT_NEG_B);    // (t5, t4) = (p2-p5, p3-p4)
+  MDCT_PKA(e01, t01, t23, MDCT_X);                   // (e10, e11) = (t0+t3, t1+t2)
+  MDCT_PKA(e32, t01, t23, MDCT_X " " MDCT_NEG_B);    // (e13, e12) = (t0-t3, t1-t2)
+  MDCT_PKA(o04, e01, e01, MDCT_SUMDIFF);                  // (e10+e11, e10-e11)
+  w.x = e32.y + e32.x;                               // e12 + e13
+  w.y = t54.x + t76.y;                               // o11 = t5 + t6
+  o.x = t54.y + t54.x;                               // o10 = t4 + t5
+  o.y = t76.y + t76.x;                               // o12 = t6 + t7
+  f32x2 z5;
+  z5.x = (o.x - o.y) * K.c707_382.y;                 // z5 = (o10 - o12) * c382
+  MDCT_PKM(z13, w, K.c707_382, MDCT_K_LL);           // (z1, z3) = (e12+e13, o11) * c707
+  MDCT_PKM(z24, o, K.c541_1306, MDCT_K_LH);          // (c541 o10, c1306 o12)
+  MDCT_PKA(z24, z24, z5, "op_sel:[0,0] op_sel_hi:[1,0]"); // (z2, z4) = (.. + z5, .. + z5)
+  MDCT_PKA(z1113, t76, z13, MDCT_LOHI " neg_hi:[0,1]"); // (z11, z13) = (t7+z3, t7-z3)
+  MDCT_PKA(o26, e32, z13, MDCT_LOLO " neg_hi:[0,1]");   // (e13+z1, e13-z1)
+  MDCT_PKA(o53, z1113, z24, MDCT_HILO " neg_hi:[0,1]"); // (z13+z2, z13-z2)
+  MDCT_PKA(o17, z1113, z24, MDCT_LOHI " neg_hi:[0,1]"); // (z11+z4, z11-z4)
+}
+
+// forward down a pair of columns, in place (direct image of aan_fwd8)
+__device__ __forceinline__ void aan_fwd_v(const AanPk &K, f32x2 (&p)[8])
+{
+  f32x2 t0, t7, t1, t6, t2, t5, t3, t4, e10, e13, e11, e12, z1, o10, o11, o12, z5, z2, z4, z3, z11, z13;
+  MDCT_PKA(t0, p[0], p[7], ""); MDCT_PKA(t7, p[0], p[7], MDCT_NEG_B); MDCT_PKA(t1, p[1], p[6], ""); MDCT_PKA(t6, p[1], p[6], MDCT_NEG_B);
+  MDCT_PKA(t2, p[2], p[5], ""); MDCT_PKA(t5, p[2], p[5], MDCT_NEG_B); MDCT_PKA(t3, p[3], p[4], ""); MDCT_PKA(t4, p[3], p[4], MDCT_NEG_B);
+  MDCT_PKA(e10, t0, t3, ""); MDCT_PKA(e13, t0, t3, MDCT_NEG_B); MDCT_PKA(e11, t1, t2, ""); MDCT_PKA(e12, t1, t2, MDCT_NEG_B);
+  MDCT_PKA(z1, e12, e13, ""); MDCT_PKM(z1, z1, K.c707_382, MDCT_K_LL);
+  MDCT_PKA(o10, t4, t5, ""); MDCT_PKA(o11, t5, t6, ""); MDCT_PKA(o12, t6, t7, "");
+  MDCT_PKA(z5, o10, o12, MDCT_NEG_B); MDCT_PKM(z5, z5, K.c707_382, MDCT_K_HH);
+  MDCT_PKM(z2, o10, K.c541_1306, MDCT_K_LL); MDCT_PKA(z2, z2, z5, "");
+  MDCT_PKM(z4, o12, K.c541_1306, MDCT_K_HH); MDCT_PKA(z4, z4, z5, "");
+  MDCT_PKM(z3, o11, K.c707_382, MDCT_K_LL);
+  MDCT_PKA(z11, t7, z3, ""); MDCT_PKA(z13, t7, z3, MDCT_NEG_B);
+  MDCT_PKA(p[0], e10, e11, ""); MDCT_PKA(p[4], e10, e11, MDCT_NEG_B);
+  MDCT_PKA(p[2], e13, z1, ""); MDCT_PKA(p[6], e13, z1, MDCT_NEG_B);
+  MDCT_PKA(p[5], z13, z2, ""); MDCT_PKA(p[3], z13, z2, MDCT_NEG_B);
+  MDCT_PKA(p[1], z11, z4, ""); MDCT_PKA(p[7], z11, z4, MDCT_NEG_B);
+}
+
+// inverse down a pair of columns, in place (direct image of aan_inv8)
+__device__ __forceinline__ void aan_inv_v(const AanPk &K, f32x2 (&p)[8])
+{
+  f32x2 e10, e11, e13, e12, t0, t3, t1, t2, z13, z10, z11, z12, t7, o11, z5, o10, o12, t6, t5, t4, m;
+  MDCT_PKA(e10, p[0], p[4], ""); MDCT_PKA(e11, p[0], p[4], MDCT_NEG_B);
+  MDCT_PKA(e13, p[2], p[6], "");
+  MDCT_PKA(e12, p[2], p[6], MDCT_NEG_B); MDCT_PKM(e12, e12, K.c1414_1847, MDCT_K_LL); MDCT_PKA(e12, e12, e13, MDCT_NEG_B);
+  MDCT_PKA(t0, e10, e13, ""); MDCT_PKA(t3, e10, e13, MDCT_NEG_B); MDCT_PKA(t1, e11, e12, ""); MDCT_PKA(t2, e11, e12, MDCT_NEG_B);
+  MDCT_PKA(z13, p[5], p[3], ""); MDCT_PKA(z10, p[5], p[3], MDCT_NEG_B); MDCT_PKA(z11, p[1], p[7], ""); MDCT_PKA(z12, p[1], p[7], MDCT_NEG_B);
+  MDCT_PKA(t7, z11, z13, "");
+  MDCT_PKA(o11, z11, z13, MDCT_NEG_B); MDCT_PKM(o11, o11, K.c1414_1847, MDCT_K_LL);
+  MDCT_PKA(z5, z10, z12, ""); MDCT_PKM(z5, z5, K.c1414_1847, MDCT_K_HH);
+  MDCT_PKM(m, z12, K.c1082_2613, MDCT_K_LL); MDCT_PKA(o10, m, z5, MDCT_NEG_B);
+  MDCT_PKM(m, z10, K.c1082_2613, MDCT_K_HH); MDCT_PKA(o12, z5, m, MDCT_NEG_B);
+  MDCT_PKA(t6, o12, t7, MDCT_NEG_B); MDCT_PKA(t5, o11, t6, MDCT_NEG_B); MDCT_PKA(t4, o10, t5, "");
+  MDCT_PKA(p[0], t0, t7, ""); MDCT_PKA(p[7], t0, t7, MDCT_NEG_B);
+  MDCT_PKA(p[1], t1, t6, ""); MDCT_PKA(p[6], t1, t6, MDCT_NEG_B);
+  MDCT_PKA(p[2], t2, t5, ""); MDCT_PKA(p[5], t2, t5, MDCT_NEG_B);
+  MDCT_PKA(p[4], t3, t4, ""); MDCT_PKA(p[3], t3, t4, MDCT_NEG_B);
+}
+
+// inverse, one line given as (c0,c4) (c2,c6) (c5,c3) (c1,c7) -> (x0,x7) (x1,x6) (x2,x5) (x4,x3)
+__device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, f32x2 i53, f32x2 i17, f32x2 &o07, f32x2 &o16, f32x2 &o25, f32x2 &o43)
+{
+  f32x2 e, f, t03, t12, z3, z1, td, u, v;
+  MDCT_PKA(e, i04, i04, MDCT_SUMDIFF);                    // (e10, e11) = (c0+c4, c0-c4)
+  MDCT_PKA(f, i26, i26, MDCT_SUMDIFF);                    // (e13, c2-c6)
+  f.y = (f.y * K.c1414_1847.x) - f.x;                // e12 = (c2-c6)*sqrt2 - e13
+  MDCT_PKA(t03, e, f, MDCT_LOLO " neg_hi:[0,1]");       // (t0, t3) = (e10+e13, e10-e13)
+  MDCT_PKA(t12, e, f, MDCT_HIHI " neg_hi:[0,1]");       // (t1, t2) = (e11+e12, e11-e12)
+  MDCT_PKA(z3, i53, i53, MDCT_SUMDIFF);                   // (z13, z10) = (c5+c3, c5-c3)
+  MDCT_PKA(z1, i17, i17, MDCT_SUMDIFF);                   // (z11, z12) = (c1+c7, c1-c7)
+  MDCT_PKA(td, z1, z3, MDCT_LOLO " neg_hi:[0,1]");      // (t7, z11-z13)
+  td.y = td.y * K.c1414_1847.x;                      // o11
+  const float z5 = (z3.y + z1.y) * K.c1414_1847.y;   // (z10 + z12) * c1847
+  const float o10 = (K.c1082_2613.x * z1.y) - z5;
+  const float o12 = z5 - (K.c1082_2613.y * z3.y);
+  u.x = o12 - td.x;                                  // t6
+  u.y = td.y - u.x;                                  // t5
+  v.x = o10 + u.y;                                   // t4
+  MDCT_PKA(o07, t03, td, MDCT_LOLO " neg_hi:[0,1]");    // (t0+t7, t0-t7)
+  MDCT_PKA(o16, t12, u, MDCT_LOLO " neg_hi:[0,1]");     // (t1+t6, t1-t6)
+  MDCT_PKA(o25, t12, u, MDCT_HIHI " neg_hi:[0,1]");     // (t2+t5, t2-t5)
+  MDCT_PKA(o43, t03, v, MDCT_HILO " neg_hi:[0,1]");     // (t3+t4, t3-t4)
+}
+
+
+// Fused round trip on packed fp32: forward rows (h), forward columns (v), [quantise -> dequantise], inverse columns (v),
+// inverse rows (h).  With a table, `tb` holds the multipliers in the pair order of the column pass,
+// (v*4 + j)*2 + {0,1} = coefficient (v, kAanPairA[j]) / (v, kAanPairB[j])  (mdct_api.hip).
+constexpr int kAanPairA[4] = {0, 2, 5, 1}, kAanPairB[4] = {4, 6, 3, 7};
+template <bool HAS_LUT>
+__device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16_t *src, int16_t *dst, size_t pitch_in, size_t pitch_out, const OwnTables &tb)
+{
+  const AanPk &K = reinterpret_cast<const AanPk &>(C);
+  uint4 in[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    in[r] = ld_stream16(src + (size_t)r * pitch_in);
+  f32x2 P[4][8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    const f32x2 a01 = {(float)(int16_t)(in[r].x & 0xFFFF), (float)(int16_t)(in[r].x >> 16)};
+    const f32x2 a23 = {(float)(int16_t)(in[r].y & 0xFFFF), (float)(int16_t)(in[r].y >> 16)};
+    const f32x2 a45 = {(float)(int16_t)(in[r].z & 0xFFFF), (float)(int16_t)(in[r].z >> 16)};
+    const f32x2 a67 = {(float)(int16_t)(in[r].w & 0xFFFF), (float)(int16_t)(in[r].w >> 16)};
+    aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    aan_fwd_v(K, P[j]);
+    if constexpr (HAS_LUT)
+    { // c = sat_i16(rne(y * qf)); z = c * dq  (rne_i16_float), on both halves
+#pragma unroll
+      for (int v = 0; v < 8; v++)
+      {
+        const f32x2 qf = reinterpret_cast<const f32x2 *>(tb.qf)[v * 4 + j], dq = reinterpret_cast<const f32x2 *>(tb.dq)[v * 4 + j];
+        f32x2 m;
+        MDCT_PKM(m, P[j][v], qf, MDCT_K_LH);
+        m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
+        m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
+        MDCT_PKA(m, m, K.magic, MDCT_K_LL);
+        MDCT_PKA(m, m, K.magic, MDCT_K_LL " " MDCT_NEG_B);
+        MDCT_PKM(P[j][v], m, dq, MDCT_K_LH);
+      }
+    }
+    aan_inv_v(K, P[j]);
+  }
+  // without a table forward-scale * inverse-scale == 1/64 exactly and rides in the final rounding (rne_i16_bits<6>)
+  constexpr float scale = HAS_LUT ? 1.0f : 64.0f;
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    f32x2 o07, o16, o25, o43;
+    aan_inv_h(K, P[0][r], P[1][r], P[2][r], P[3][r], o07, o16, o25, o43);
+    auto fin = [&](f32x2 v) {
+      f32x2 t;
+      v.x = __builtin_amdgcn_fmed3f(v.x, -32768.0f * scale, 32767.0f * scale);
+      v.y = __builtin_amdgcn_fmed3f(v.y, -32768.0f * scale, 32767.0f * scale);
+      if constexpr (HAS_LUT)
+        MDCT_PKA(t, v, K.magic, MDCT_K_LL);
+      else
+        MDCT_PKA(t, v, K.magic, MDCT_K_HH);
+      return t;
+    };
+    const f32x2 b07 = fin(o07), b16 = fin(o16), b25 = fin(o25), b43 = fin(o43);
+    st_stream16(dst + (size_t)r * pitch_out, pack_lo16(__float_as_uint(b07.x), __float_as_uint(b16.x)), pack_lo16(__float_as_uint(b25.x), __float_as_uint(b43.y)),
+                pack_lo16(__float_as_uint(b43.x), __float_as_uint(b25.y)), pack_lo16(__float_as_uint(b16.y), __float_as_uint(b07.y)));
+  }
+}
+
 // The compiler's register/scheduling heuristic is steered per mode with amdgpu_waves_per_eu; the
 // values are the measured optimum of {2..6} on MI355X, ROCm 7.2 (profiles/r01_waves_per_eu.log):
 // forward 44.0 us with 2 (46.6 with 4), inverse 45.7 us with 4 (47.8 with 2), fused round trip
@@ -807,7 +992,12 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
   const uint32_t row = t / a.bpr;
   const uint32_t bx = t - row * a.bpr;
   const size_t by = a.by0 + row;
-  i16_block<MODE, HAS_LUT>(a.consts, a.from + by * 8 * a.pitch_in + (size_t)bx * 8, a.to + by * 8 * a.pitch_out + (size_t)bx * 8, a.pitch_in, a.pitch_out, a.tb);
+  const int16_t *src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
+  int16_t *dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
+  if constexpr (MODE == MODE_ROUNDTRIP)
+    i16_roundtrip_pk<HAS_LUT>(a.consts, src, dst, a.pitch_in, a.pitch_out, a.tb);
+  else
+    i16_block<MODE, HAS_LUT>(a.consts, src, dst, a.pitch_in, a.pitch_out, a.tb);
 }
 
 // 8-bit pixels <-> int16 coefficients (JPEG-style pair): u8 rows are 8 B per lane (512 B per wave
@@ -883,8 +1073,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_
 // Several planes (each with its own table) in one launch: linear block index over the
 // concatenation of the planes; prefix[] is the exclusive scan of per-plane block counts.
 // LUTMODE: 0 no plane has a table, 1 every plane has one, 2 mixed (branch per wave)
+#ifndef MDCT_PLANES_WAVES
+#define MDCT_PLANES_WAVES 4 // the one-op-per-line round trip (i16_block): with per-plane tables indexed at run time the packed form is slower here (41.6-45 vs 38 us on the 4:2:0 frame, profiles/r02_planes_waves.log)
+#endif
 template <int LUTMODE>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_i16_planes(PlaneBatchArgs a)
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_PLANES_WAVES, MDCT_PLANES_WAVES))) void k_i16_planes(PlaneBatchArgs a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x;
   // plane index from the wave's first block: wave-uniform, so the table reads stay scalar
