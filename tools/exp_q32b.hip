@@ -568,6 +568,79 @@ __global__ __launch_bounds__(256, MINW) void v_pk_dma2(U8Args a, XPkConsts K, Pk
 }
 
 
+// ---- v_pk_dma3: v_pk_dma2 with scheduling barriers after every line of the row pass and every column pair, so that
+// the compiler cannot hoist the LDS reads / spread the live ranges (register pressure); scalar (SGPR) tile bookkeeping, rows read from LDS just in time during the row pass, the next
+// tile's DMA issued AFTER the row pass (it still has the column pass + quantise + reorder to land)
+template <int MINW, int NPASS>
+__global__ __launch_bounds__(256, MINW) void v_pk_dma3(U8Args a, XPkConsts K, PkQuant Q, uint32_t ntiles)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t stage[4][(64 / NPASS) * kQ32RowStride];
+  __shared__ __attribute__((aligned(16))) uint8_t inbuf[4][8 * 512];
+  const uint32_t lane = threadIdx.x & 63, half = lane >> 5, l32 = lane & 31;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint8_t *wl = stage[w];
+  uint8_t *in = inbuf[w];
+  const uint32_t total_waves = gridDim.x * 4;
+  uint32_t tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
+  if (tile >= ntiles)
+    return;
+  const uint32_t lane_in = half * (uint32_t)a.pitch + l32 * 16; // per-lane part of the source address (plane < 4 GiB)
+  auto issue = [&](uint32_t tl) {
+    const uint32_t t0 = tl * 64;
+    const uint32_t row = t0 / a.bpr, bx0 = t0 - row * a.bpr;
+    const uint8_t *base = a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)bx0 * 8; // wave-uniform
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + (size_t)(2 * k) * a.pitch + lane_in),
+                                       (__attribute__((address_space(3))) void *)(in + k * 1024), 16, 0, 0);
+  };
+  issue(tile);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (;;)
+  {
+    f2 col[4][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      const uint2 rw = *reinterpret_cast<const uint2 *>(in + r * 512 + lane * 8);
+      f2 a01 = {ubyte_to_float<0>(rw.x), ubyte_to_float<1>(rw.x)};
+      f2 a23 = {ubyte_to_float<2>(rw.x), ubyte_to_float<3>(rw.x)};
+      f2 a45 = {ubyte_to_float<0>(rw.y), ubyte_to_float<1>(rw.y)};
+      f2 a67 = {ubyte_to_float<2>(rw.y), ubyte_to_float<3>(rw.y)};
+      x_dct8_avx_h(K, a01, a23, a45, a67, col[0][r], col[1][r], col[2][r], col[3][r]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const uint32_t next = tile + total_waves;
+    const bool more = next < ntiles;
+    if (more)
+      issue(next); // every LDS read of the input buffer has been consumed by the row pass above
+    uint32_t q[64];
+    constexpr int ua[4] = {0, 2, 1, 5}, ub[4] = {4, 6, 3, 7};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      x_dct8_avx_v(K, col[j]);
+#pragma unroll
+      for (int v = 0; v < 8; v++)
+      {
+        f2 m, t;
+        PKM(m, col[j][v], Q.nq[v * 4 + j], K_LH);
+        m.x = __builtin_amdgcn_fmed3f(m.x, -128.0f, 127.0f);
+        m.y = __builtin_amdgcn_fmed3f(m.y, -128.0f, 127.0f);
+        PKA(t, m, K.nm, "op_sel:[0,1] op_sel_hi:[1,1]");
+        q[v * 8 + ua[j]] = __float_as_uint(t.x);
+        q[v * 8 + ub[j]] = __float_as_uint(t.y);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    reorder_store_passes<NPASS>(wl, q, lane, lane, a.to + ((size_t)a.by0 * a.bpr + (size_t)tile * 64) * 64);
+    if (!more)
+      break;
+    tile = next;
+  }
+}
+
+
 // ---- VALU floor of the packed transform: REPS x (load + transform + quantise) on the same tile (L2 hits after the
 // first), results folded into 16 bytes; (t(REPS=3) - t(REPS=1)) / 2 is one compute pass with HBM out of the picture
 template <int REPS, int MINW>
@@ -591,6 +664,33 @@ __global__ __launch_bounds__(256, MINW) void v_pk_reps(U8Args a, XPkConsts K, Pk
     }
   }
   *reinterpret_cast<uint4 *>(a.to + (size_t)t * 64) = acc;
+}
+
+
+// ---- static priorities by wave slot: the waves a SIMD hosts start together and, arbitrated round-robin, finish
+// together; distinct priorities serialise them (the highest finishes first, its successor starts loading early)
+__device__ __forceinline__ void prio_by_slot(int mode)
+{
+  const uint32_t slot = __builtin_amdgcn_s_getreg(0x1804) & 15; // HW_REG_HW_ID[3:0]: wave slot within the SIMD
+  const uint32_t k = mode == 0 ? (slot & 3) : (mode == 1 ? (slot & 1) : ((slot >> 1) & 3));
+  if (k == 1) __builtin_amdgcn_s_setprio(1);
+  else if (k == 2) __builtin_amdgcn_s_setprio(2);
+  else if (k == 3) __builtin_amdgcn_s_setprio(3);
+}
+template <int MINW, int MODE>
+__global__ __launch_bounds__(256, MINW) void v_pk_prio(U8Args a, XPkConsts K, PkQuant Q)
+{
+  prio_by_slot(MODE);
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t row = t / a.bpr, bx = t - row * a.bpr;
+  const uint8_t *src = a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)bx * 8;
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4][64 * kQ32RowStride];
+  uint2 rows[8];
+  load_block_rows(src, a.pitch, rows);
+  uint32_t q[64];
+  transform_quant_pk(K, Q, rows, q);
+  reorder_store<true>(lds[threadIdx.x >> 6], q, lane, lane, a.to + ((size_t)a.by0 * a.bpr + (t - lane)) * 64);
 }
 
 // ---- memory-only shapes: what do 8 B/lane vs 16 B/lane non-temporal row loads cost with no arithmetic?
@@ -695,6 +795,13 @@ int main(int argc, char **argv)
   vs.push_back({"pk reps x3 5w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<3, 5>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
   vs.push_back({"pk reps x1 4w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<1, 4>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
   vs.push_back({"pk reps x3 4w", [&](int s) { hipLaunchKernelGGL((v_pk_reps<3, 4>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, false});
+  vs.push_back({"pk 6w prio slot&3", [&](int s) { hipLaunchKernelGGL((v_pk_prio<6, 0>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, true});
+  vs.push_back({"pk 6w prio slot&1", [&](int s) { hipLaunchKernelGGL((v_pk_prio<6, 1>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, true});
+  vs.push_back({"pk 6w prio (slot>>1)&3", [&](int s) { hipLaunchKernelGGL((v_pk_prio<6, 2>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, true});
+  vs.push_back({"pk 5w prio slot&3", [&](int s) { hipLaunchKernelGGL((v_pk_prio<5, 0>), dim3(nwg), dim3(256), 0, 0, args(a, s), PK, PQ); }, {}, true});
+  vs.push_back({"pk dma3 5w 2pass grid 1280", [&](int s) { hipLaunchKernelGGL((v_pk_dma3<5, 2>), dim3(1280), dim3(256), 0, 0, args(a, s), PK, PQ, ntiles); }, {}, true});
+  vs.push_back({"pk dma3 6w 2pass grid 1536", [&](int s) { hipLaunchKernelGGL((v_pk_dma3<6, 2>), dim3(1536), dim3(256), 0, 0, args(a, s), PK, PQ, ntiles); }, {}, true});
+  vs.push_back({"pk dma3 4w 1pass grid 1024", [&](int s) { hipLaunchKernelGGL((v_pk_dma3<4, 1>), dim3(1024), dim3(256), 0, 0, args(a, s), PK, PQ, ntiles); }, {}, true});
   // correctness of every variant against the product kernel's bytes
   {
     std::vector<uint8_t> ref(bytes), got(bytes);
