@@ -163,6 +163,15 @@ int mdct_zigzag_rle_i16(const int16_t *coef, size_t pitch, size_t sizeX, size_t 
                         int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
 int mdct_zigzag_rle_q32(const uint8_t *q32, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
                         int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
+/* The same from any of the reference's three intact byte layouts (all carry the +127 bias):
+ *   MDCT_LAYOUT_Q32     as above
+ *   MDCT_LAYOUT_STEREO  the 64 coefficient planes of simd_dct.h:30 -- the streams the layout was made for;
+ *                       block index = stream position (by*2 + eye) * (sizeX/8) + bx, [by0, by1) in units of
+ *                       16 pixel rows (sizeY/16 of them), sizeX % 16 == 0
+ *   MDCT_LAYOUT_BLOCK   the scalar encq tier's 64 bytes per block with coefficients stored transposed (u*8+v)
+ * MDCT_LAYOUT_BLOCK_SSE stores only half of every block (simd_dct.cpp:1662-1676) and is refused. */
+int mdct_zigzag_rle_u8(const uint8_t *coef, int layout, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                       int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
 /* the scan order used above: zz[k] = natural index v*8+u of scan position k (host function) */
 void mdct_zigzag_table(uint8_t *zz64);
 /* Before the transform (feeds mdct_roundtrip_i16_planes / BASELINE.json configs[2]): interleaved 8-bit

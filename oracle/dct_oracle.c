@@ -848,3 +848,30 @@ int orc_split420_u8(const uint8_t *ycc, size_t pitch, size_t W, size_t H, int16_
       }
   return 0;
 }
+
+/* the same from the stereo layout (64 coefficient planes, simd_dct.cpp:1061-1099; block index = stream
+ * position (by*2+eye)*bpr + bx, ranges in units of 16 pixel rows) and from the scalar encq tier's block
+ * layout (:347-362, coefficient (v,u) at u*8+v); both carry the +127 bias */
+int orc_zigzag_rle_u8(const uint8_t *coef, int layout, size_t W, size_t H, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts)
+{
+  if (layout == 0)
+    return orc_zigzag_rle_q32(coef, W, H, by0, by1, levels, runs, counts);
+  if (!coef || !levels || (runs && !counts))
+    return 1;
+  if (layout != 1 && layout != 2)
+    return 2;
+  const size_t ymul = layout == 1 ? 16 : 8;
+  if (W % (layout == 1 ? 16 : 8) || H % ymul)
+    return 2;
+  if (by0 > by1 || by1 > H / ymul)
+    return 1;
+  const size_t bpr = (layout == 1 ? 2 : 1) * (W / 8), plane = W * H / 64;
+  for (size_t blk = by0 * bpr; blk < by1 * bpr; blk++)
+  {
+    int nat[64];
+    for (int i = 0; i < 64; i++)
+      nat[i] = layout == 1 ? (int)coef[(size_t)i * plane + blk] - 127 : (int)coef[blk * 64 + (size_t)((i & 7) * 8 + (i >> 3))] - 127;
+    scan_block(nat, levels + blk * 64, runs ? runs + blk * 64 : NULL, counts ? counts + blk : NULL);
+  }
+  return 0;
+}

@@ -96,6 +96,8 @@ int orc_zigzag_rle_i16(const int16_t *coef, size_t pitch, size_t sizeX, size_t s
                        int16_t *levels, uint8_t *runs, uint8_t *counts);
 int orc_zigzag_rle_q32(const uint8_t *q32, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
                        int16_t *levels, uint8_t *runs, uint8_t *counts);
+int orc_zigzag_rle_u8(const uint8_t *coef, int layout /* 0 q32, 1 stereo, 2 block */, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                      int16_t *levels, uint8_t *runs, uint8_t *counts);
 int orc_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr,
                     size_t pitch_y, size_t pitch_c);
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mdct_roundtrip_i16_planes": (c_int, [ctypes.POINTER(PlaneI16), c_int, c_void_p]),
     "mdct_zigzag_rle_i16": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdct_zigzag_rle_q32": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdct_zigzag_rle_u8": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdct_zigzag_table": (None, [c_void_p]),
     "mdct_split420_u8": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mdct_shard_rows": (None, [c_size_t, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),

@@ -229,6 +229,16 @@ def zigzag_rle_q32(q32, sizeX, sizeY, levels, runs=None, counts=None, by0=0, by1
     return rc
 
 
+def zigzag_rle_u8(coef, layout, sizeX, sizeY, levels, runs=None, counts=None, by0=0, by1=None, stream=None, check=True):
+    """the same from the q32, stereo (64 coefficient planes) or scalar-encq block layout"""
+    if by1 is None:
+        by1 = sizeY // (16 if layout == LAYOUT_STEREO else 8)
+    rc = _lib.load().mdct_zigzag_rle_u8(_ptr(coef), layout, sizeX, sizeY, by0, by1, _ptr(levels), _ptr(runs), _ptr(counts), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
 def split420_u8(ycc, sizeX, sizeY, y, cb, cr, pitch=None, pitch_y=None, pitch_c=None, stream=None, check=True):
     """interleaved 8-bit Y Cb Cr -> level-shifted int16 Y (full) and Cb / Cr (2x2 box average) planes"""
     rc = _lib.load().mdct_split420_u8(_ptr(ycc), 3 * sizeX if pitch is None else pitch, sizeX, sizeY, _ptr(y), _ptr(cb), _ptr(cr),

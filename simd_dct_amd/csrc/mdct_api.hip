@@ -170,7 +170,7 @@ int make_own_tables(const float *lut, mdct::OwnTables &tb, bool pair_order = fal
   }
   if (pair_order)
   {
-    static const int pa[4] = {0, 2, 5, 1}, pb[4] = {4, 6, 3, 7}; // == mdct::kAanPairA / kAanPairB
+    static const int pa[4] = {0, 2, 5, 1}, pb[4] = {4, 6, 3, 7}; // the pairs aan_fwd_h produces (mdct_kernels.hip)
     mdct::OwnTables t = tb;
     for (int v = 0; v < 8; v++)
       for (int j = 0; j < 4; j++)

@@ -913,8 +913,8 @@ __device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, 
 
 // Fused round trip on packed fp32: forward rows (h), forward columns (v), [quantise -> dequantise], inverse columns (v),
 // inverse rows (h).  With a table, `tb` holds the multipliers in the pair order of the column pass,
-// (v*4 + j)*2 + {0,1} = coefficient (v, kAanPairA[j]) / (v, kAanPairB[j])  (mdct_api.hip).
-constexpr int kAanPairA[4] = {0, 2, 5, 1}, kAanPairB[4] = {4, 6, 3, 7};
+// (v*4 + j)*2 + {0,1} = coefficient (v, A[j]) / (v, B[j]) with A = {0,2,5,1}, B = {4,6,3,7}: the pairs aan_fwd_h
+// produces and aan_inv_h consumes (mdct_api.hip: make_own_tables).
 template <bool HAS_LUT>
 __device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16_t *src, int16_t *dst, size_t pitch_in, size_t pitch_out, const OwnTables &tb)
 {

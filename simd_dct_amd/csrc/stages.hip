@@ -26,16 +26,16 @@ namespace mdct
 constexpr int kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
                              35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-enum { SRC_I16 = 0, SRC_Q32 = 1 };
+enum { SRC_I16 = 0, SRC_Q32 = 1, SRC_STEREO = 2, SRC_BLOCK = 3 };
 
 struct ScanArgs
 {
-  const void *src;   // int16 plane (SRC_I16) or q32 bytes (SRC_Q32)
+  const void *src;   // int16 plane (SRC_I16) or the bytes of one of the reference's layouts
   int16_t *levels;   // [block][64]
   uint8_t *runs;     // [block][64]   (RLE only)
   uint8_t *counts;   // [block]       (RLE only)
-  size_t pitch;      // SRC_I16: elements
-  uint32_t bpr, by0, nblocks;
+  size_t pitch;      // SRC_I16: elements;  SRC_STEREO: bytes per coefficient plane
+  uint32_t bpr, by0, nblocks; // blocks per (stereo: double) block row, first row, blocks in the launch
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -43,7 +43,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWG = 256;
 constexpr int kLvRow = 144; // 64 int16 + 16 B: slot 64 (inside the pad) takes the writes of zero coefficients
 constexpr int kRnRow = 80;  // 64 u8 + 16 B, same trick
-constexpr int kQ32Grp = 516; // staged q32 group: 512 B + 4 so that the 8 groups start in different banks
+constexpr int kQ32Grp = 520; // staged q32 group: 512 B + 8: a byte read of coefficient c touches banks 2g + 2c + {0,1}, distinct for the 8 groups
 
 template <int SRC, bool RLE>
 __global__ __launch_bounds__(kWG) void k_scan(ScanArgs a)
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kWG) void k_scan(ScanArgs a)
       }
     }
   }
-  else
+  else if constexpr (SRC == SRC_Q32)
   { // the wave's 64 blocks are 8 consecutive q32 groups = 4096 contiguous bytes [group][coef][8 blocks]
     const uint8_t *p = static_cast<const uint8_t *>(a.src) + blk0 * 64;
 #pragma unroll
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kWG) void k_scan(ScanArgs a)
       if (o < nvalid * 64)
       {
         const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + o));
-        uint32_t *d = reinterpret_cast<uint32_t *>(lv + o + 4 * (o >> 9));
+        uint32_t *d = reinterpret_cast<uint32_t *>(lv + o + (kQ32Grp - 512) * (o >> 9));
         d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
       }
     }
@@ -103,6 +103,32 @@ __global__ __launch_bounds__(kWG) void k_scan(ScanArgs a)
       val[c] = (int)g[c * 8] - 127; // simd_dct.cpp:2224: the stored byte carries a +127 bias
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the staging area is reused for the records below
     __builtin_amdgcn_wave_barrier();
+  }
+
+  else if constexpr (SRC == SRC_STEREO)
+  { // 64 coefficient planes (simd_dct.cpp:1061-1099): coefficient c of stream position p at c * plane + p, so the
+    // wave's 64 blocks are 64 consecutive bytes of every plane; bias +127 as in the q32 tier (:1020)
+    const uint8_t *p = static_cast<const uint8_t *>(a.src) + blk0 + (valid ? lane : 0);
+#pragma unroll
+    for (int c = 0; c < 64; c++)
+      val[c] = (int)p[(size_t)c * a.pitch] - 127;
+  }
+  else
+  { // SRC_BLOCK (simd_dct.cpp:347-362): 64 contiguous bytes per block, coefficient (v,u) stored at u*8+v, bias +127/255*255
+    const uint8_t *p = static_cast<const uint8_t *>(a.src) + (blk0 + (valid ? lane : 0)) * 64;
+    uint32_t w[16];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + j * 16));
+      w[4 * j] = q.x; w[4 * j + 1] = q.y; w[4 * j + 2] = q.z; w[4 * j + 3] = q.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+    {
+      const int st = (i & 7) * 8 + (i >> 3); // natural v*8+u lives at stored u*8+v
+      val[i] = (int)((w[st >> 2] >> (8 * (st & 3))) & 0xFF) - 127;
+    }
   }
 
   // ---- scan order; RLE: compact the non-zero levels to the front of the lane's record
@@ -232,14 +258,17 @@ int scan_launch(int src, const void *coef, size_t pitch, size_t sizeX, size_t si
 {
   if (coef == nullptr || levels == nullptr || (runs != nullptr && counts == nullptr))
     return mdct_set_error(MDCT_INVALID_PARAMETER, "null pointer (runs without counts?)");
-  const size_t xmul = src == mdct::SRC_Q32 ? 64 : 8;
-  if (sizeX == 0 || sizeX % xmul != 0 || sizeY % 8 != 0)
-    return mdct_set_error(MDCT_NOT_SUPPORTED, "plane %zux%zu: width must be a multiple of %zu and height of 8", sizeX, sizeY, xmul);
-  if ((src == mdct::SRC_I16 && pitch < sizeX) || by0 > by1 || by1 > sizeY / 8)
-    return mdct_set_error(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows", by0, by1, sizeY / 8);
-  if (((uintptr_t)coef | (uintptr_t)levels | (uintptr_t)runs | (src == mdct::SRC_I16 ? pitch * 2 : 0)) & 15)
+  const size_t xmul = src == mdct::SRC_Q32 ? 64 : (src == mdct::SRC_STEREO ? 16 : 8);
+  const size_t ymul = src == mdct::SRC_STEREO ? 16 : 8;
+  if (sizeX == 0 || sizeX % xmul != 0 || sizeY % ymul != 0)
+    return mdct_set_error(MDCT_NOT_SUPPORTED, "plane %zux%zu: width must be a multiple of %zu and height of %zu", sizeX, sizeY, xmul, ymul);
+  if ((src == mdct::SRC_I16 && pitch < sizeX) || by0 > by1 || by1 > sizeY / ymul)
+    return mdct_set_error(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows", by0, by1, sizeY / ymul);
+  if (((uintptr_t)levels | (uintptr_t)runs | (src == mdct::SRC_STEREO ? 0 : (uintptr_t)coef) | (src == mdct::SRC_I16 ? pitch * 2 : 0)) & 15)
     return mdct_set_error(MDCT_INVALID_PARAMETER, "coefficient rows and record arrays must be 16-byte aligned");
-  const size_t bpr = sizeX / 8, n = bpr * (by1 - by0);
+  if (src == mdct::SRC_STEREO)
+    pitch = sizeX * sizeY / 64; // bytes per coefficient plane
+  const size_t bpr = (src == mdct::SRC_STEREO ? 2 : 1) * (sizeX / 8), n = bpr * (by1 - by0);
   if (n > 0x7FFFFFFFull)
     return mdct_set_error(MDCT_NOT_SUPPORTED, "more than 2^31 blocks in one call; split the row range");
   if (n == 0)
@@ -255,14 +284,22 @@ int scan_launch(int src, const void *coef, size_t pitch, size_t sizeX, size_t si
   a.nblocks = (uint32_t)n;
   const dim3 g((uint32_t)((n + mdct::kWG - 1) / mdct::kWG)), b(mdct::kWG);
   hipStream_t s = (hipStream_t)stream;
-  if (src == mdct::SRC_I16 && runs)
-    hipLaunchKernelGGL((mdct::k_scan<mdct::SRC_I16, true>), g, b, 0, s, a);
-  else if (src == mdct::SRC_I16)
-    hipLaunchKernelGGL((mdct::k_scan<mdct::SRC_I16, false>), g, b, 0, s, a);
-  else if (runs)
-    hipLaunchKernelGGL((mdct::k_scan<mdct::SRC_Q32, true>), g, b, 0, s, a);
-  else
-    hipLaunchKernelGGL((mdct::k_scan<mdct::SRC_Q32, false>), g, b, 0, s, a);
+#define MDCT_SCAN(SRC) \
+  do \
+  { \
+    if (runs) \
+      hipLaunchKernelGGL((mdct::k_scan<SRC, true>), g, b, 0, s, a); \
+    else \
+      hipLaunchKernelGGL((mdct::k_scan<SRC, false>), g, b, 0, s, a); \
+  } while (0)
+  switch (src)
+  {
+  case mdct::SRC_I16: MDCT_SCAN(mdct::SRC_I16); break;
+  case mdct::SRC_Q32: MDCT_SCAN(mdct::SRC_Q32); break;
+  case mdct::SRC_STEREO: MDCT_SCAN(mdct::SRC_STEREO); break;
+  default: MDCT_SCAN(mdct::SRC_BLOCK); break;
+  }
+#undef MDCT_SCAN
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? MDCT_SUCCESS : mdct_set_error(MDCT_NOT_SUPPORTED, "scan kernel launch: %s", hipGetErrorString(e));
 }
@@ -282,9 +319,17 @@ int mdct_zigzag_rle_i16(const int16_t *coef, size_t pitch, size_t sizeX, size_t 
   return scan_launch(mdct::SRC_I16, coef, pitch, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
 }
 
+int mdct_zigzag_rle_u8(const uint8_t *coef, int layout, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream)
+{
+  const int src = layout == MDCT_LAYOUT_Q32 ? mdct::SRC_Q32 : (layout == MDCT_LAYOUT_STEREO ? mdct::SRC_STEREO : (layout == MDCT_LAYOUT_BLOCK ? mdct::SRC_BLOCK : -1));
+  if (src < 0)
+    return mdct_set_error(MDCT_NOT_SUPPORTED, "layout %d has no scan (the SSE encq tier stores only half of every block, simd_dct.cpp:1662-1676)", layout);
+  return scan_launch(src, coef, sizeX, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
+}
+
 int mdct_zigzag_rle_q32(const uint8_t *q32, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream)
 {
-  return scan_launch(mdct::SRC_Q32, q32, sizeX, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
+  return mdct_zigzag_rle_u8(q32, MDCT_LAYOUT_Q32, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
 }
 
 int mdct_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr, size_t pitch_y, size_t pitch_c, void *stream)

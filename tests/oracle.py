@@ -43,6 +43,7 @@ def oracle():
         lib.orc_zigzag_table.argtypes = [vp]
         lib.orc_zigzag_rle_i16.argtypes = [vp, sz, sz, sz, sz, sz, vp, vp, vp]
         lib.orc_zigzag_rle_q32.argtypes = [vp, sz, sz, sz, sz, vp, vp, vp]
+        lib.orc_zigzag_rle_u8.argtypes = [vp, ctypes.c_int, sz, sz, sz, sz, vp, vp, vp]
         lib.orc_split420_u8.argtypes = [vp, sz, sz, sz, vp, vp, vp, sz, sz]
         lib.orc_dct8.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_int]
         lib.orc_idct8_own.argtypes = [vp, ctypes.c_ssize_t]
@@ -249,20 +250,23 @@ def zigzag_table():
 
 
 def zigzag_rle(kind, src, W, H, rle=True, by0=0, by1=None, pitch=None, fill=0):
-    """kind 'i16' (int16 plane [H, pitch]) or 'q32' (bytes).  Returns (levels [nblk, 64], runs, counts); arrays pre-filled with `fill`."""
+    """kind 'i16' (int16 plane [H, pitch]), 'q32', 'stereo' or 'block' (bytes).  Returns (levels [nblk, 64], runs, counts); arrays pre-filled with `fill`."""
     nblk = (W // 8) * (H // 8)
     levels = np.full((nblk, 64), fill, dtype=np.int16)
     runs = np.full((nblk, 64), fill & 0xFF, dtype=np.uint8) if rle else None
     counts = np.full(nblk, fill & 0xFF, dtype=np.uint8) if rle else None
-    by1 = H // 8 if by1 is None else by1
+    by1 = H // (16 if kind == "stereo" else 8) if by1 is None else by1
     rp = runs.ctypes.data if rle else None
     cp = counts.ctypes.data if rle else None
     if kind == "i16":
         src = np.ascontiguousarray(src, dtype=np.int16)
         rc = oracle().orc_zigzag_rle_i16(src.ctypes.data, W if pitch is None else pitch, W, H, by0, by1, levels.ctypes.data, rp, cp)
-    else:
+    elif kind == "q32":
         src = np.ascontiguousarray(src, dtype=np.uint8)
         rc = oracle().orc_zigzag_rle_q32(src.ctypes.data, W, H, by0, by1, levels.ctypes.data, rp, cp)
+    else:
+        src = np.ascontiguousarray(src, dtype=np.uint8)
+        rc = oracle().orc_zigzag_rle_u8(src.ctypes.data, {"stereo": 1, "block": 2}[kind], W, H, by0, by1, levels.ctypes.data, rp, cp)
     assert rc == 0, rc
     return levels, runs, counts
 

@@ -67,6 +67,26 @@ def test_oracle_scan_and_rle_by_definition():
     assert np.array_equal(got_lv, lv) and np.array_equal(got_rn, rn) and np.array_equal(got_ct, ct)
 
 
+def test_oracle_scan_of_the_stereo_and_block_layouts():
+    """the checker's stereo / block-layout scans against the layouts' definitions (numpy), fed with the pinned
+    oracle's own bytes for those tiers"""
+    W, H = 128, 64
+    img = synth.plane_u8_np(W, H, "photo")
+    lut = (api.QUANTIZE_BASE * np.float32(8)).astype(np.float32)
+    # stereo: 64 planes, stream position p; natural index i at plane i
+    rc, st = O.run_behaviour("stereo_sse", img, lut, W, H, 0, H)
+    nat = st.reshape(64, -1).T.astype(np.int32) - 127  # [position][coef]
+    scan, lv, rn, ct = _numpy_records(nat)
+    got = O.zigzag_rle("stereo", st, W, H)
+    assert np.array_equal(got[0], lv) and np.array_equal(got[1], rn) and np.array_equal(got[2], ct)
+    # scalar encq: 64 bytes per block, stored transposed; only the top half of the plane is written (SURVEY 2.3-1)
+    rc, bl = O.run_behaviour("encq_scalar", img, lut, W, H, 0, H)
+    nat = bl.reshape(-1, 8, 8).transpose(0, 2, 1).reshape(-1, 64).astype(np.int32) - 127
+    scan, lv, rn, ct = _numpy_records(nat)
+    got = O.zigzag_rle("block", bl, W, H)
+    assert np.array_equal(got[0], lv) and np.array_equal(got[1], rn) and np.array_equal(got[2], ct)
+
+
 def _ycc(W, H, seed=1):
     y = synth.plane_u8_np(W, H, "photo", seed=seed)
     cb = synth.plane_u8_np(W, H, "noise", seed=seed + 1)
@@ -147,6 +167,34 @@ def test_scan_and_rle_match_the_checker():
                 assert np.array_equal(lv.cpu().numpy(), want[0]), (W, H, rle)
                 if rle:
                     assert np.array_equal(rn.cpu().numpy(), want[1]) and np.array_equal(ct.cpu().numpy(), want[2])
+
+
+@pytest.mark.gpu
+def test_scan_of_the_stereo_and_block_layouts():
+    """the reordered streams the reference's other two functions produce, consumed in place: GPU stereo / scalar-encq
+    output -> records, against the checker; sub-ranges leave the other records alone"""
+    api.init(0)
+    lut = (api.QUANTIZE_BASE * np.float32(8)).astype(np.float32)
+    for (W, H) in ((16, 16), (128, 64), (1040, 48), (2048, 512)):
+        img = synth.plane_u8_np(W, H, "photo", seed=H)
+        nblk = (W // 8) * (H // 8)
+        for kind, layout, profile, beh, rows in (("stereo", api.LAYOUT_STEREO, api.PROFILE_REF_SSE, "stereo_sse", H // 16), ("block", api.LAYOUT_BLOCK, api.PROFILE_REF_SCALAR, "encq_scalar", H // 8)):
+            out = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
+            api.fwd_quant_u8(_dev(img), out, lut, W, H, 0, rows, layout=layout, profile=profile)
+            host = out.cpu().numpy()
+            for rle in (True, False):
+                for (b0, b1) in ((0, rows), (rows // 2, rows)):
+                    lv = torch.full((nblk, 64), 0x1111, dtype=torch.int16, device="cuda")
+                    rn = torch.full((nblk, 64), 0x11, dtype=torch.uint8, device="cuda") if rle else None
+                    ct = torch.full((nblk,), 0x11, dtype=torch.uint8, device="cuda") if rle else None
+                    api.zigzag_rle_u8(out, layout, W, H, lv, rn, ct, by0=b0, by1=b1)
+                    want = O.zigzag_rle(kind, host, W, H, rle=rle, by0=b0, by1=b1, fill=0x1111)
+                    assert np.array_equal(lv.cpu().numpy(), want[0]), (kind, W, H, rle, b0)
+                    if rle:
+                        assert np.array_equal(rn.cpu().numpy(), want[1]) and np.array_equal(ct.cpu().numpy(), want[2]), (kind, W, H, b0)
+    a = torch.zeros(64 * 16, dtype=torch.uint8, device="cuda")
+    lv = torch.zeros((16, 64), dtype=torch.int16, device="cuda")
+    assert api.zigzag_rle_u8(a, api.LAYOUT_BLOCK_SSE, 64, 16, lv, check=False) == 2
 
 
 @pytest.mark.gpu
