@@ -458,7 +458,7 @@ int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *
       if (run > 0x7FFFFFFFull)
         return fail(MDCT_NOT_SUPPORTED, "plane batch exceeds the 2^31 block limit");
       a.has_lut[i] = p.lut != nullptr;
-      if ((r = make_own_tables(p.lut, a.tb[i])))
+      if ((r = make_own_tables(p.lut, a.tb[i], true)))
         return r;
     }
     a.prefix[a.n] = (uint32_t)run;

@@ -145,6 +145,7 @@ struct PkConsts
   f32x2 da, fd, fc, ca; // K_TRUE only: (Cd,Ca) (Cf,Cd) (Cf,Cc) (Cc,Ca)
   f32x2 bias;           // SSE tiers: (1/255, 127.0f);  scalar tiers: (127/255, 255.0f)
 };
+static_assert(kMaxPlanes == 4, "k_i16_planes switches over four plane slots");
 static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernels.h) is the kernel-argument image of PkConsts");
 
 // one block row (or column) held in 4 pairs -> (o0,o4) (o2,o6) (o1,o3) (o5,o7), each already times Cn.
@@ -1074,7 +1075,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_
 // concatenation of the planes; prefix[] is the exclusive scan of per-plane block counts.
 // LUTMODE: 0 no plane has a table, 1 every plane has one, 2 mixed (branch per wave)
 #ifndef MDCT_PLANES_WAVES
-#define MDCT_PLANES_WAVES 4 // the one-op-per-line round trip (i16_block): with per-plane tables indexed at run time the packed form is slower here (41.6-45 vs 38 us on the 4:2:0 frame, profiles/r02_planes_waves.log)
+#define MDCT_PLANES_WAVES 3
 #endif
 template <int LUTMODE>
 __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_PLANES_WAVES, MDCT_PLANES_WAVES))) void k_i16_planes(PlaneBatchArgs a)
@@ -1099,9 +1100,19 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_PLANES
   const int16_t *src = a.from[p] + (size_t)row * 8 * pin + (size_t)bx * 8;
   int16_t *dst = a.to[p] + (size_t)row * 8 * pout + (size_t)bx * 8;
   if (LUTMODE == 1 || (LUTMODE == 2 && a.has_lut[p]))
-    i16_block<MODE_ROUNDTRIP, true>(a.consts, src, dst, pin, pout, a.tb[p]);
+  { // One copy of the packed round trip per plane slot, chosen by a scalar branch: with a STATIC table address the
+    // 128 multiplier pairs arrive in a few batched scalar loads; indexed by p at run time they became 69 separate
+    // s_load_dwordx2 with a wait each (41.6-45 us instead of 36-38 on the 4:2:0 frame, profiles/r02_planes_waves.log).
+    switch (p)
+    {
+    case 0: i16_roundtrip_pk<true>(a.consts, src, dst, pin, pout, a.tb[0]); break;
+    case 1: i16_roundtrip_pk<true>(a.consts, src, dst, pin, pout, a.tb[1]); break;
+    case 2: i16_roundtrip_pk<true>(a.consts, src, dst, pin, pout, a.tb[2]); break;
+    default: i16_roundtrip_pk<true>(a.consts, src, dst, pin, pout, a.tb[3]); break;
+    }
+  }
   else
-    i16_block<MODE_ROUNDTRIP, false>(a.consts, src, dst, pin, pout, a.tb[p]);
+    i16_roundtrip_pk<false>(a.consts, src, dst, pin, pout, a.tb[0]);
 }
 
 // float32 rows are 32 B per block: if every lane fetched its own 2 x 16 B, each wave load would
