@@ -172,6 +172,20 @@ int mdct_zigzag_rle_q32(const uint8_t *q32, size_t sizeX, size_t sizeY, size_t b
  * MDCT_LAYOUT_BLOCK_SSE stores only half of every block (simd_dct.cpp:1662-1676) and is refused. */
 int mdct_zigzag_rle_u8(const uint8_t *coef, int layout, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
                        int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
+/* Entropy stage: baseline Huffman coding of those records (ITU-T T.81 Annex C code construction, F.1.2.1 DC
+ * difference categories, F.1.2.2 RRRRSSSS with ZRL / EOB, the typical tables of Annex K.3.3 -- `chroma` selects
+ * Tables K.4 / K.6 instead of K.3 / K.5).  One independently decodable segment per block row: the row is a
+ * restart interval of sizeX/8 blocks (E.1.4: DC predictor 0 at its start), byte-aligned, last byte padded with
+ * 1-bits (F.1.2.3), written at out + by * seg_stride with its length in seg_bytes[by].  The bytes are NOT
+ * stuffed (B.1.1.5) and carry no markers: the container writer does both (simd_dct_amd/jfif.py writes a JFIF
+ * file any decoder opens; the tests decode it with libjpeg).  Levels are those of 8-bit baseline JPEG (DC
+ * differences within +-2047, AC within +-1023; larger values saturate).  seg_stride: multiple of 4,
+ * >= 208 * (sizeX/8) + 8 (the worst case of F.1.2); sizeX/8 <= 65535. */
+int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *counts, size_t sizeX, size_t sizeY,
+                      size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, void *stream);
+/* BITS (16 counts) and HUFFVAL of the table as a DHT marker segment carries them (host function).
+ * which: 0 DC luminance (K.3), 1 AC luminance (K.5), 2 DC chrominance (K.4), 3 AC chrominance (K.6). */
+int mdct_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals);
 /* the scan order used above: zz[k] = natural index v*8+u of scan position k (host function) */
 void mdct_zigzag_table(uint8_t *zz64);
 /* Before the transform (feeds mdct_roundtrip_i16_planes / BASELINE.json configs[2]): interleaved 8-bit

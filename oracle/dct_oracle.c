@@ -875,3 +875,156 @@ int orc_zigzag_rle_u8(const uint8_t *coef, int layout, size_t W, size_t H, size_
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Baseline Huffman coding of the run/level records (SURVEY.md 8 f4 "entropy stage") [no reference
+ * counterpart].  Restates ITU-T T.81: code construction Annex C, coding procedures F.1.2.1 (DC:
+ * DIFF category + amplitude) and F.1.2.2 (AC: RRRRSSSS with ZRL and EOB), the typical tables of
+ * Annex K.3.3 (Tables K.3-K.6).  One byte-aligned, independently decodable segment per block row:
+ * the DC predictor starts at 0 in every row (a restart interval of sizeX/8 blocks, E.1.4) and the
+ * last byte is padded with 1-bits (F.1.2.3).  Bytes are NOT stuffed (B.1.1.5): whoever writes the
+ * file inserts 0x00 after every 0xFF and the RSTm markers between rows.
+ * ---------------------------------------------------------------------------------------- */
+static const uint8_t kDcLumaBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+static const uint8_t kDcChromaBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+static const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t kAcLumaBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+static const uint8_t kAcLumaVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1,
+    0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a,
+    0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3,
+    0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+static const uint8_t kAcChromaBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+static const uint8_t kAcChromaVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1,
+    0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+    0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca,
+    0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+/* BITS (16) and HUFFVAL of the table, as a DHT segment carries them.  which: 0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma */
+int orc_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals)
+{
+  const uint8_t *b = which == 0 ? kDcLumaBits : (which == 1 ? kAcLumaBits : (which == 2 ? kDcChromaBits : kAcChromaBits));
+  const uint8_t *v = which == 1 ? kAcLumaVals : (which == 3 ? kAcChromaVals : kDcVals);
+  if (which < 0 || which > 3)
+    return 1;
+  int n = 0;
+  for (int i = 0; i < 16; i++)
+  {
+    bits16[i] = b[i];
+    n += b[i];
+  }
+  memcpy(vals, v, (size_t)n);
+  *nvals = n;
+  return 0;
+}
+
+/* Annex C: code[sym] and size[sym] from BITS / HUFFVAL; table entry = size << 16 | code (0 = symbol absent) */
+static void huff_build(const uint8_t *bits, const uint8_t *vals, uint32_t *tab256)
+{
+  memset(tab256, 0, 256 * sizeof(uint32_t));
+  uint32_t code = 0;
+  int k = 0;
+  for (int len = 1; len <= 16; len++)
+  {
+    for (int i = 0; i < bits[len - 1]; i++)
+      tab256[vals[k++]] = ((uint32_t)len << 16) | code++;
+    code <<= 1;
+  }
+}
+
+void orc_huffman_tables(int chroma, uint32_t *dc256, uint32_t *ac256)
+{
+  huff_build(chroma ? kDcChromaBits : kDcLumaBits, kDcVals, dc256);
+  huff_build(chroma ? kAcChromaBits : kAcLumaBits, chroma ? kAcChromaVals : kAcLumaVals, ac256);
+}
+
+typedef struct
+{
+  uint8_t *p;
+  uint64_t acc; /* bits not yet written, right-aligned */
+  int n;
+  size_t bytes;
+} bitw;
+
+static void put_bits(bitw *w, uint32_t code, int len)
+{
+  w->acc = (w->acc << len) | (code & ((1u << len) - 1u));
+  w->n += len;
+  while (w->n >= 8)
+  {
+    w->p[w->bytes++] = (uint8_t)(w->acc >> (w->n - 8));
+    w->n -= 8;
+  }
+}
+
+static int bit_size(int v)
+{
+  int a = v < 0 ? -v : v, s = 0;
+  while (a)
+  {
+    s++;
+    a >>= 1;
+  }
+  return s;
+}
+
+int orc_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *counts, size_t W, size_t H, size_t by0, size_t by1, int chroma, uint8_t *out,
+                     size_t seg_stride, uint32_t *seg_bytes)
+{
+  if (!levels || !runs || !counts || !out || !seg_bytes)
+    return 1;
+  if (W % 8 || H % 8)
+    return 2;
+  const size_t bpr = W / 8;
+  if (by0 > by1 || by1 > H / 8 || seg_stride < bpr * 208 + 8)
+    return 1;
+  uint32_t dct[256], act[256];
+  orc_huffman_tables(chroma, dct, act);
+  for (size_t by = by0; by < by1; by++)
+  {
+    bitw w = {out + by * seg_stride, 0, 0, 0};
+    int pred = 0;
+    for (size_t bx = 0; bx < bpr; bx++)
+    {
+      const size_t blk = by * bpr + bx;
+      const int16_t *lv = levels + blk * 64;
+      const uint8_t *rn = runs + blk * 64;
+      const int n = counts[blk];
+      int i = 0, dc = 0;
+      if (n > 0 && rn[0] == 0)
+        dc = lv[i++]; /* the first pair sits at scan position 0 */
+      int diff = dc - pred;
+      pred = dc;
+      diff = diff > 2047 ? 2047 : (diff < -2047 ? -2047 : diff); /* 8-bit baseline: categories 0..11 (F.1.2.1.1) */
+      int s = bit_size(diff);
+      put_bits(&w, dct[s] & 0xFFFF, (int)(dct[s] >> 16));
+      if (s)
+        put_bits(&w, (uint32_t)(diff < 0 ? diff - 1 : diff), s);
+      int q = 0, p = (n > 0 && rn[0] == 0) ? 0 : -1; /* q: previous coded position, p: position of pair i-1 */
+      for (; i < n; i++)
+      {
+        p += rn[i] + 1;
+        int r = p - q - 1, l = lv[i];
+        q = p;
+        l = l > 1023 ? 1023 : (l < -1023 ? -1023 : l); /* categories 1..10 (F.1.2.2.1) */
+        for (; r > 15; r -= 16)
+          put_bits(&w, act[0xF0] & 0xFFFF, (int)(act[0xF0] >> 16)); /* ZRL */
+        s = bit_size(l);
+        const uint32_t e = act[(r << 4) | s];
+        put_bits(&w, e & 0xFFFF, (int)(e >> 16));
+        put_bits(&w, (uint32_t)(l < 0 ? l - 1 : l), s);
+      }
+      if (q < 63)
+        put_bits(&w, act[0x00] & 0xFFFF, (int)(act[0x00] >> 16)); /* EOB */
+    }
+    if (w.n)
+      put_bits(&w, 0xFF, 8 - w.n); /* pad with 1-bits */
+    seg_bytes[by] = (uint32_t)w.bytes;
+  }
+  return 0;
+}

@@ -98,6 +98,14 @@ int orc_zigzag_rle_q32(const uint8_t *q32, size_t sizeX, size_t sizeY, size_t by
                        int16_t *levels, uint8_t *runs, uint8_t *counts);
 int orc_zigzag_rle_u8(const uint8_t *coef, int layout /* 0 q32, 1 stereo, 2 block */, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
                       int16_t *levels, uint8_t *runs, uint8_t *counts);
+/* Baseline Huffman coding (T.81 Annex C, F.1.2, tables K.3-K.6) of the records above: one unstuffed, 1-padded
+ * segment per block row at out + by*seg_stride (seg_stride >= 208*sizeX/8 + 8), its length in seg_bytes[by];
+ * the DC predictor restarts in every row.  orc_huffman_spec: BITS/HUFFVAL as a DHT segment carries them
+ * (which: 0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma); orc_huffman_tables: size << 16 | code per symbol. */
+int orc_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals);
+void orc_huffman_tables(int chroma, uint32_t *dc256, uint32_t *ac256);
+int orc_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *counts, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                     int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes);
 int orc_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr,
                     size_t pitch_y, size_t pitch_c);
 

@@ -239,6 +239,29 @@ def zigzag_rle_u8(coef, layout, sizeX, sizeY, levels, runs=None, counts=None, by
     return rc
 
 
+def huffman_spec(which):
+    """(BITS[16], HUFFVAL[...]) of the library's Huffman table `which` (0 DC luma, 1 AC luma, 2 DC chroma, 3 AC chroma)"""
+    bits = np.zeros(16, dtype=np.uint8)
+    vals = np.zeros(256, dtype=np.uint8)
+    n = ctypes.c_int()
+    _check(_lib.load().mdct_huffman_spec(which, bits.ctypes.data, vals.ctypes.data, ctypes.byref(n)))
+    return bits.tolist(), vals[:n.value].tolist()
+
+
+def huffman_seg_stride(sizeX):
+    """smallest legal segment stride for mdct_huffman_rows on a plane of this width"""
+    return (sizeX // 8) * 208 + 8
+
+
+def huffman_rows(levels, runs, counts, sizeX, sizeY, out, seg_bytes, seg_stride=None, chroma=False, by0=0, by1=None, stream=None, check=True):
+    """baseline Huffman coding of the run/level records: one unstuffed segment per block row (mdct_huffman_rows)"""
+    rc = _lib.load().mdct_huffman_rows(_ptr(levels), _ptr(runs), _ptr(counts), sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, int(bool(chroma)),
+                                       _ptr(out), huffman_seg_stride(sizeX) if seg_stride is None else seg_stride, _ptr(seg_bytes), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
 def split420_u8(ycc, sizeX, sizeY, y, cb, cr, pitch=None, pitch_y=None, pitch_c=None, stream=None, check=True):
     """interleaved 8-bit Y Cb Cr -> level-shifted int16 Y (full) and Cb / Cr (2x2 box average) planes"""
     rc = _lib.load().mdct_split420_u8(_ptr(ycc), 3 * sizeX if pitch is None else pitch, sizeX, sizeY, _ptr(y), _ptr(cb), _ptr(cr),

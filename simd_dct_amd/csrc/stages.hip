@@ -249,10 +249,297 @@ __global__ __launch_bounds__(kWG) void k_split420(SplitArgs a)
   __builtin_nontemporal_store(cr, reinterpret_cast<u32x2 *>(a.cr + (size_t)rp * a.pitch_c + (size_t)s * 4));
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_huffman_rows: baseline Huffman coding (ITU-T T.81 Annex C, F.1.2) of the run/level records.
+// One workgroup of 4 waves per block row; the row is one restart interval: DC predictor 0 at its
+// start, byte-aligned, 1-padded segment at out + row * seg_stride, unstuffed (the container writer
+// stuffs, simd_dct_amd/jfif.py).  The row is walked in chunks of 256 blocks, one block per lane, 64
+// consecutive blocks per wave:
+//   0. the head of the wave's records (the first kHuffStage pairs: 48 B of levels, 32 B of runs per
+//      block) comes in with 16 B per lane loads -- the NEXT chunk's are issued before this one is
+//      coded -- and is parked in LDS with a per-block skew of one dword, so that "entry i of every
+//      lane" hits 64 banks; a block with more pairs reads the rest from HBM;
+//   1. DC value per lane, predecessor's by a wave shuffle (lane 0: prefetched with the records);
+//   2. walk the pairs, count bits;   3. exclusive scan: shuffles in the wave, 4 totals through LDS;
+//   4. walk again, emitting each code (Huffman code and amplitude bits as one token) into a 64-bit
+//      accumulator that is OR-ed, 32 bits at a time, into an LDS ring of the row's bit stream
+//      (ds_or: the first and last word of a block are shared with its neighbours);
+//   5. the chunk's complete words leave, byte-swapped (the stream is MSB first), 4 B per lane, and
+//      their ring slots are cleared; the trailing partial word simply stays in the ring.
+// The ring holds kHuffRing words (8 bit/px over a chunk); a chunk with more bits than that is emitted
+// in several windows (walk 4 repeated, each time keeping only the words of one window).
+// ---------------------------------------------------------------------------------------
+struct HuffArgs
+{
+  const int16_t *levels;
+  const uint8_t *runs, *counts;
+  uint8_t *out;
+  uint32_t *seg_bytes;
+  size_t seg_stride;
+  uint32_t bpr, by0;
+  uint32_t dc[12];  // size << 16 | code per DC category
+  uint32_t ac[256]; // size << 16 | code per RRRRSSSS
+};
+
+constexpr int kHuffWaves = 4;
+constexpr int kHuffChunk = 64 * kHuffWaves;       // blocks per chunk = lanes of the workgroup
+constexpr uint32_t kHuffRing = 4096;              // words of bit stream held in LDS (power of two)
+constexpr int kHuffStage = 24;                    // pairs per block parked in LDS
+constexpr int kLvSkew = 2 * kHuffStage + 4;       // bytes per block in LDS: 48 + 4 (13 dwords: odd)
+constexpr int kRnSkew = 32 + 4;                   // 32 runs (two 16 B pieces) + 4 (9 dwords: odd)
+
+struct BlockWalk
+{ // one lane's block: calls f(table entry, amplitude bits, amplitude size) for every code in coding order
+  template <class LV, class RN, class F>
+  __device__ __forceinline__ static void run(LV &&lv, RN &&rn, int n, int pred, const uint32_t *dc, const uint32_t *ac, F &&f)
+  {
+    int i = 0, dcv = 0, p = -1;
+    if (n > 0 && rn(0) == 0)
+    { // the first pair sits at scan position 0: it is the DC coefficient
+      dcv = lv(0);
+      i = 1;
+      p = 0;
+    }
+    int diff = dcv - pred;
+    diff = diff > 2047 ? 2047 : (diff < -2047 ? -2047 : diff); // 8-bit baseline: categories 0..11 (F.1.2.1.1)
+    int s = diff ? 32 - __builtin_clz((uint32_t)(diff < 0 ? -diff : diff)) : 0; // SSSS: bits of |DIFF|
+    f(dc[s], (uint32_t)(diff < 0 ? diff - 1 : diff), s);
+    int q = 0;
+    for (; i < n; i++)
+    {
+      p += rn(i) + 1;
+      int r = p - q - 1, l = lv(i);
+      q = p;
+      l = l > 1023 ? 1023 : (l < -1023 ? -1023 : l); // categories 1..10 (F.1.2.2.1)
+      for (; r > 15; r -= 16)
+        f(ac[0xF0], 0u, 0); // ZRL
+      s = 32 - __builtin_clz((uint32_t)(l < 0 ? -l : l));
+      f(ac[(r << 4) | s], (uint32_t)(l < 0 ? l - 1 : l), s);
+    }
+    if (q < 63)
+      f(ac[0x00], 0u, 0); // EOB
+  }
+};
+
+__global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
+{
+  __shared__ uint32_t ac[256], dc[12];
+  __shared__ __attribute__((aligned(16))) uint8_t lv_all[kHuffWaves][64 * kLvSkew];
+  __shared__ __attribute__((aligned(16))) uint8_t rn_all[kHuffWaves][64 * kRnSkew];
+  __shared__ uint32_t ring[kHuffRing];
+  __shared__ uint32_t tot[2][kHuffWaves];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t row = a.by0 + blockIdx.x;
+  ac[tid] = a.ac[tid];
+  if (tid < 12)
+    dc[tid] = a.dc[tid];
+  for (uint32_t w = tid; w < kHuffRing; w += kHuffChunk)
+    ring[w] = 0;
+  uint32_t *out_w = reinterpret_cast<uint32_t *>(a.out + (size_t)row * a.seg_stride);
+  const size_t row_blk0 = (size_t)row * a.bpr;
+  const uint8_t *g_lv = reinterpret_cast<const uint8_t *>(a.levels) + row_blk0 * 128;
+  const uint8_t *g_rn = a.runs + row_blk0 * 64;
+  const uint8_t *g_ct = a.counts + row_blk0;
+  uint8_t *lv_lds = lv_all[wave], *rn_lds = rn_all[wave];
+
+  // the head of the wave's 64 records as 16-byte pieces: levels 3 per block, runs 2 per block
+  u32x4 plv[3], prn[2];
+  int pn = 0;                          // this lane's pair count
+  int pp_ct = 0, pp_rn = 1, pp_lv = 0; // head of the block before the wave's first one (its DC is lane 0's predictor)
+  auto fetch = [&](uint32_t c0w) { // c0w: the wave's first block in the row
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+    {
+      const uint32_t q = k * 64 + lane, b = q / 3, part = q - 3 * b;
+      if (c0w + b < a.bpr)
+        plv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(g_lv + (size_t)(c0w + b) * 128 + part * 16));
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+    {
+      const uint32_t q = k * 64 + lane, b = q >> 1, part = q & 1;
+      if (c0w + b < a.bpr)
+        prn[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(g_rn + (size_t)(c0w + b) * 64 + part * 16));
+    }
+    pn = c0w + lane < a.bpr ? (int)g_ct[c0w + lane] : 0;
+    pp_ct = 0;
+    if (c0w > 0 && c0w < a.bpr)
+    { // three independent loads: nothing here waits for them
+      pp_ct = g_ct[c0w - 1];
+      pp_rn = g_rn[(size_t)(c0w - 1) * 64];
+      pp_lv = a.levels[(row_blk0 + c0w - 1) * 64];
+    }
+  };
+  auto park = [&]() { // registers -> LDS
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+    {
+      const uint32_t q = k * 64 + lane, b = q / 3, part = q - 3 * b;
+      uint32_t *d = reinterpret_cast<uint32_t *>(lv_lds + b * kLvSkew + part * 16);
+      d[0] = plv[k].x; d[1] = plv[k].y; d[2] = plv[k].z; d[3] = plv[k].w;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+    {
+      const uint32_t q = k * 64 + lane, b = q >> 1, part = q & 1;
+      uint32_t *d = reinterpret_cast<uint32_t *>(rn_lds + b * kRnSkew + part * 16);
+      d[0] = prn[k].x; d[1] = prn[k].y; d[2] = prn[k].z; d[3] = prn[k].w;
+    }
+  };
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  uint32_t base_bits = 0; // bits of the row produced by earlier chunks
+  uint32_t par = 0;
+  fetch(wave * 64);
+  __syncthreads(); // tables and the cleared ring
+  for (uint32_t c0 = 0; c0 < a.bpr; c0 += kHuffChunk, par ^= 1)
+  {
+    const uint32_t c0w = c0 + wave * 64, bx = c0w + lane;
+    const bool live = bx < a.bpr;
+    wave_sync(); // the previous chunk's walks are done with the wave's LDS records
+    park();
+    const int n = pn, prev_dc = (pp_ct > 0 && pp_rn == 0) ? pp_lv : 0;
+    if (c0 + kHuffChunk < a.bpr)
+      fetch(c0w + kHuffChunk); // in flight while this chunk is coded
+    wave_sync();
+    const int16_t *lv_l = reinterpret_cast<const int16_t *>(lv_lds + lane * kLvSkew);
+    const uint8_t *rn_l = rn_lds + lane * kRnSkew;
+    const int16_t *lv_g = a.levels + (row_blk0 + (live ? bx : 0)) * 64;
+    const uint8_t *rn_g = g_rn + (size_t)(live ? bx : 0) * 64;
+    auto lv = [&](int i) -> int { return i < kHuffStage ? (int)lv_l[i] : (int)lv_g[i]; };
+    auto rn = [&](int i) -> int { return i < kHuffStage ? (int)rn_l[i] : (int)rn_g[i]; };
+    // 1. DC of this block and of its predecessor
+    const int my_dc = (n > 0 && rn_l[0] == 0) ? (int)lv_l[0] : 0;
+    const int up = __shfl_up(my_dc, 1, 64);
+    const int pred = lane == 0 ? prev_dc : up;
+    // 2. bits of this block
+    uint32_t bits = 0;
+    if (live)
+      BlockWalk::run(lv, rn, n, pred, dc, ac, [&](uint32_t e, uint32_t, int s) { bits += (e >> 16) + (uint32_t)s; });
+    // 3. exclusive scan: inside the wave, then over the 4 waves
+    uint32_t incl = bits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint32_t v = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d)
+        incl += v;
+    }
+    if (lane == 63)
+      tot[par][wave] = incl;
+    __syncthreads(); // also: every wave has flushed (and cleared) the previous chunk's words
+    uint32_t wave_start = 0, chunk_bits = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kHuffWaves; w++)
+    {
+      const uint32_t t = tot[par][w];
+      wave_start += w < wave ? t : 0;
+      chunk_bits += t;
+    }
+    const uint32_t end_bits = base_bits + chunk_bits;
+    const uint32_t w_first = base_bits >> 5, w_end = end_bits >> 5; // complete words of the row after this chunk: [.., w_end)
+    // 4. + 5. emit and flush, one window of the ring at a time (one window unless the chunk exceeds 8 bit/px)
+    for (uint32_t win = w_first; win <= w_end; win += kHuffRing)
+    {
+      if (win != w_first)
+        __syncthreads(); // the previous window's slots are cleared
+      if (live)
+      {
+        const uint32_t cur = base_bits + wave_start + (incl - bits); // bit position in the row
+        uint32_t widx = cur >> 5;
+        uint64_t acc = 0;         // bits not yet written
+        uint32_t nacc = cur & 31; // pretend that many zero bits precede: OR leaves the neighbour's bits alone
+        BlockWalk::run(lv, rn, n, pred, dc, ac, [&](uint32_t e, uint32_t amp, int s) {
+          const uint32_t tok = ((e & 0xFFFFu) << s) | (amp & ((1u << s) - 1u)), len = (e >> 16) + (uint32_t)s; // <= 16 + 11 bits
+          acc = (acc << len) | (uint64_t)tok;
+          nacc += len;
+          if (nacc >= 32)
+          {
+            nacc -= 32;
+            if (widx - win < kHuffRing)
+              atomicOr(&ring[widx & (kHuffRing - 1)], (uint32_t)(acc >> nacc));
+            widx++;
+          }
+        });
+        if (nacc && widx - win < kHuffRing)
+          atomicOr(&ring[widx & (kHuffRing - 1)], (uint32_t)(acc << (32 - nacc)));
+      }
+      __syncthreads();
+      const uint32_t stop = min(w_end, win + kHuffRing);
+      for (uint32_t w = win + tid; w < stop; w += kHuffChunk)
+      {
+        out_w[w] = __builtin_bswap32(ring[w & (kHuffRing - 1)]);
+        ring[w & (kHuffRing - 1)] = 0;
+      }
+    }
+    base_bits = end_bits;
+  }
+  __syncthreads();
+  if (tid == 0)
+  { // F.1.2.3: pad the last byte with 1-bits; the segment's length in bytes
+    const uint32_t rem = base_bits & 31;
+    if (rem)
+    {
+      const uint32_t pad = (8 - (rem & 7)) & 7;
+      uint32_t w = ring[(base_bits >> 5) & (kHuffRing - 1)];
+      if (pad)
+        w |= ((1u << pad) - 1u) << (32 - rem - pad);
+      out_w[base_bits >> 5] = __builtin_bswap32(w);
+    }
+    a.seg_bytes[row] = (base_bits + 7) / 8;
+  }
+}
+
 } // namespace mdct
 
 namespace
 {
+
+// ITU-T T.81 Annex K.3.3, Tables K.3-K.6: BITS and HUFFVAL of the typical Huffman tables
+static const uint8_t kDcLumaBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+static const uint8_t kDcChromaBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+static const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t kAcLumaBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+static const uint8_t kAcLumaVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1,
+    0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a,
+    0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3,
+    0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+static const uint8_t kAcChromaBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+static const uint8_t kAcChromaVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1,
+    0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+    0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca,
+    0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+const uint8_t *huff_bits(int which) { return which == 0 ? kDcLumaBits : (which == 1 ? kAcLumaBits : (which == 2 ? kDcChromaBits : kAcChromaBits)); }
+const uint8_t *huff_vals(int which) { return which == 1 ? kAcLumaVals : (which == 3 ? kAcChromaVals : kDcVals); }
+
+// Annex C: codes in order of increasing length; entry = size << 16 | code
+void huff_build(int which, uint32_t *tab, int ntab)
+{
+  const uint8_t *bits = huff_bits(which), *vals = huff_vals(which);
+  for (int i = 0; i < ntab; i++)
+    tab[i] = 0;
+  uint32_t code = 0;
+  int k = 0;
+  for (int len = 1; len <= 16; len++)
+  {
+    for (int i = 0; i < bits[len - 1]; i++, k++)
+      if (vals[k] < ntab)
+        tab[vals[k]] = ((uint32_t)len << 16) | code++;
+    code <<= 1;
+  }
+}
 
 int scan_launch(int src, const void *coef, size_t pitch, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream)
 {
@@ -330,6 +617,52 @@ int mdct_zigzag_rle_u8(const uint8_t *coef, int layout, size_t sizeX, size_t siz
 int mdct_zigzag_rle_q32(const uint8_t *q32, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream)
 {
   return mdct_zigzag_rle_u8(q32, MDCT_LAYOUT_Q32, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
+}
+
+int mdct_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals)
+{
+  if (which < 0 || which > 3 || !bits16 || !vals || !nvals)
+    return mdct_set_error(MDCT_INVALID_PARAMETER, "table 0..3 (DC luma, AC luma, DC chroma, AC chroma) and non-null outputs");
+  int n = 0;
+  for (int i = 0; i < 16; i++)
+  {
+    bits16[i] = huff_bits(which)[i];
+    n += bits16[i];
+  }
+  for (int i = 0; i < n; i++)
+    vals[i] = huff_vals(which)[i];
+  *nvals = n;
+  return MDCT_SUCCESS;
+}
+
+int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *counts, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride,
+                      uint32_t *seg_bytes, void *stream)
+{
+  if (!levels || !runs || !counts || !out || !seg_bytes)
+    return mdct_set_error(MDCT_INVALID_PARAMETER, "null pointer");
+  if (sizeX == 0 || sizeX % 8 != 0 || sizeY % 8 != 0)
+    return mdct_set_error(MDCT_NOT_SUPPORTED, "plane %zux%zu is not a multiple of 8x8", sizeX, sizeY);
+  const size_t bpr = sizeX / 8;
+  if (by0 > by1 || by1 > sizeY / 8 || bpr > 0xFFFF)
+    return mdct_set_error(MDCT_INVALID_PARAMETER, "bad block-row range [%zu,%zu) for %zu rows, or more than 65535 blocks per row (a restart interval)", by0, by1, sizeY / 8);
+  if (seg_stride < bpr * 208 + 8 || seg_stride % 4 != 0 || ((uintptr_t)out & 3))
+    return mdct_set_error(MDCT_INVALID_PARAMETER, "seg_stride must be a multiple of 4 and >= 208 * blocks per row + 8 = %zu (worst case of F.1.2); out 4-byte aligned", bpr * 208 + 8);
+  if (by0 == by1)
+    return MDCT_SUCCESS;
+  mdct::HuffArgs a;
+  a.levels = levels;
+  a.runs = runs;
+  a.counts = counts;
+  a.out = out;
+  a.seg_bytes = seg_bytes;
+  a.seg_stride = seg_stride;
+  a.bpr = (uint32_t)bpr;
+  a.by0 = (uint32_t)by0;
+  huff_build(chroma ? 2 : 0, a.dc, 12);
+  huff_build(chroma ? 3 : 1, a.ac, 256);
+  hipLaunchKernelGGL(mdct::k_huffman_rows, dim3((uint32_t)(by1 - by0)), dim3(mdct::kHuffChunk), 0, (hipStream_t)stream, a);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MDCT_SUCCESS : mdct_set_error(MDCT_NOT_SUPPORTED, "huffman kernel launch: %s", hipGetErrorString(e));
 }
 
 int mdct_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr, size_t pitch_y, size_t pitch_c, void *stream)

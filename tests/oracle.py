@@ -44,6 +44,8 @@ def oracle():
         lib.orc_zigzag_rle_i16.argtypes = [vp, sz, sz, sz, sz, sz, vp, vp, vp]
         lib.orc_zigzag_rle_q32.argtypes = [vp, sz, sz, sz, sz, vp, vp, vp]
         lib.orc_zigzag_rle_u8.argtypes = [vp, ctypes.c_int, sz, sz, sz, sz, vp, vp, vp]
+        lib.orc_huffman_rows.argtypes = [vp, vp, vp, sz, sz, sz, sz, ctypes.c_int, vp, sz, vp]
+        lib.orc_huffman_spec.argtypes = [ctypes.c_int, vp, vp, vp]
         lib.orc_split420_u8.argtypes = [vp, sz, sz, sz, vp, vp, vp, sz, sz]
         lib.orc_dct8.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_int]
         lib.orc_idct8_own.argtypes = [vp, ctypes.c_ssize_t]
@@ -279,3 +281,22 @@ def split420(ycc, W, H):
     rc = oracle().orc_split420_u8(ycc.ctypes.data, 3 * W, W, H, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, W, W // 2)
     assert rc == 0, rc
     return y, cb, cr
+
+
+def huffman_spec(which):
+    bits = np.zeros(16, dtype=np.uint8)
+    vals = np.zeros(256, dtype=np.uint8)
+    n = ctypes.c_int()
+    assert oracle().orc_huffman_spec(which, bits.ctypes.data, vals.ctypes.data, ctypes.byref(n)) == 0
+    return bits.tolist(), vals[:n.value].tolist()
+
+
+def huffman_rows(levels, runs, counts, W, H, chroma=False, by0=0, by1=None, fill=0):
+    """-> (segments uint8 [(H/8) * stride], seg_bytes uint32 [H/8], stride)"""
+    stride = (W // 8) * 208 + 8
+    seg = np.full((H // 8) * stride, fill, dtype=np.uint8)
+    nb = np.full(H // 8, fill * 0x01010101, dtype=np.uint32)
+    rc = oracle().orc_huffman_rows(levels.ctypes.data, runs.ctypes.data, counts.ctypes.data, W, H, by0, H // 8 if by1 is None else by1, int(chroma),
+                                   seg.ctypes.data, stride, nb.ctypes.data)
+    assert rc == 0, rc
+    return seg, nb, stride

@@ -1,0 +1,198 @@
+"""The entropy stage ("zig-zag + run-length / entropy stage consuming the reordered streams"):
+baseline Huffman coding of the run/level records, and the JFIF container around it.  No reference counterpart --
+but an INDEPENDENT one: libjpeg (through PIL) must decode the files, reproduce our own inverse transform within the
++-1 of two different IDCTs, and write the same Huffman tables itself.  That pins scan order, run/level semantics,
+code construction, DC prediction / restart semantics and the tables.  GPU: the kernel's bytes equal the checker's."""
+import io
+
+import numpy as np
+import pytest
+
+import oracle as O
+from simd_dct_amd import api, jfif, synth
+
+Image = pytest.importorskip("PIL.Image")
+
+# ITU-T T.81 Annex K.1 / K.2 example quantisation tables (natural order)
+K1_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                    18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+K2_CHROMA = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.float32)
+
+
+def _libjpeg_tables(colour):
+    """the DHT specifications libjpeg itself writes (optimize=False = its copy of Annex K.3.3)"""
+    img = Image.fromarray(np.zeros((16, 16, 3) if colour else (16, 16), dtype=np.uint8))
+    buf = io.BytesIO()
+    img.save(buf, "JPEG", quality=50, optimize=False)
+    b = buf.getvalue()
+    i, got = 2, {}
+    while i < len(b):
+        m, L = b[i + 1], (b[i + 2] << 8) | b[i + 3]
+        if m == 0xC4:
+            p = i + 4
+            while p < i + 2 + L:
+                bits = list(b[p + 1:p + 17])
+                n = sum(bits)
+                got[b[p]] = (bits, list(b[p + 17:p + 17 + n]))
+                p += 17 + n
+        if m == 0xDA:
+            break
+        i += 2 + L
+    return got
+
+
+def test_huffman_tables_are_the_ones_libjpeg_writes():
+    got = _libjpeg_tables(colour=True)
+    for which, key in ((0, 0x00), (1, 0x10), (2, 0x01), (3, 0x11)):
+        assert O.huffman_spec(which) == got[key], which  # the checker's literals
+        assert api.huffman_spec(which) == got[key], which  # the product's literals
+
+
+def _encode_cpu(img, qtable, chroma=False):
+    H, W = img.shape
+    coef = O.u8_i16("fwd", img, W, H, lut=qtable)
+    lv, rn, ct = O.zigzag_rle("i16", coef, W, H)
+    seg, nb, stride = O.huffman_rows(lv, rn, ct, W, H, chroma=chroma)
+    return coef, dict(segments=seg, seg_bytes=nb, seg_stride=stride, blocks_per_row=W // 8, qtable=qtable)
+
+
+def test_libjpeg_decodes_the_checkers_stream():
+    for (W, H), kind in (((256, 128), "photo"), ((64, 8), "noise"), ((1024, 64), "photo")):
+        img = synth.plane_u8_np(W, H, kind)
+        coef, comp = _encode_cpu(img, K1_LUMA)
+        data = jfif.write_jpeg([comp], W, H)
+        dec = np.asarray(Image.open(io.BytesIO(data)).convert("L"))
+        own = O.u8_i16("inv", coef, W, H, lut=K1_LUMA)
+        assert dec.shape == (H, W)
+        assert np.abs(dec.astype(int) - own.astype(int)).max() <= 1, (W, H)  # libjpeg's integer IDCT vs our float one
+    # extremes: flat blocks (EOB only), full-scale checkerboards (long codes, 0xFF bytes -> stuffing), runs > 15 (ZRL)
+    W, H = 128, 32
+    img = np.zeros((H, W), dtype=np.uint8)
+    img[:, 32:64] = 255
+    img[8:16, 64:96] = (np.indices((8, 32)).sum(0) % 2) * 255
+    img[16:24, :] = synth.plane_u8_np(W, 8, "noise")
+    k = np.cos((2 * np.arange(8) + 1) * 7 * np.pi / 16)
+    img[24:32, 0:8] = np.rint(128 + 100 * np.outer(k, k)).astype(np.uint8)  # only the (7,7) coefficient: scan position 63
+    q1 = np.ones(64, dtype=np.float32)
+    coef, comp = _encode_cpu(img, q1)
+    assert (comp["seg_bytes"] > 0).all()
+    lv, rn, ct = O.zigzag_rle("i16", coef, W, H)
+    assert rn.max() > 15  # the ZRL path is exercised
+    data = jfif.write_jpeg([comp], W, H)
+    assert b"\xff\x00" in data  # and so is byte stuffing
+    dec = np.asarray(Image.open(io.BytesIO(data)).convert("L"))
+    assert np.abs(dec.astype(int) - O.u8_i16("inv", coef, W, H, lut=q1).astype(int)).max() <= 1
+
+
+def test_huffman_argument_checks_without_device():
+    lv = np.zeros((16, 64), dtype=np.int16)
+    rn = np.zeros((16, 64), dtype=np.uint8)
+    ct = np.zeros(16, dtype=np.uint8)
+    out = np.zeros(2 * api.huffman_seg_stride(64), dtype=np.uint8)
+    nb = np.zeros(2, dtype=np.uint32)
+    assert api.huffman_rows(None, rn, ct, 64, 16, out, nb, check=False) == 1
+    assert api.huffman_rows(lv, rn, ct, 60, 16, out, nb, check=False) == 2
+    assert api.huffman_rows(lv, rn, ct, 64, 16, out, nb, seg_stride=64, check=False) == 1
+    assert "208" in api.last_error()
+    assert api.huffman_rows(lv, rn, ct, 64, 16, out, nb, by1=3, check=False) == 1
+
+
+# ------------------------------------------------------------------------------------------ GPU
+torch = pytest.importorskip("torch")
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _encode_gpu(d_img, W, H, qtable, chroma=False, from_i16=None):
+    """u8 plane (or ready int16 plane) on the device -> coefficients, records, row segments; all on the device"""
+    coef = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    if from_i16 is None:
+        api.fwd_u8_i16(d_img, coef, W, H, lut=qtable)
+    else:
+        api.fwd_i16(from_i16, coef, W, H, lut=qtable)
+    nblk = (W // 8) * (H // 8)
+    lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
+    rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
+    ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
+    api.zigzag_rle_i16(coef, W, H, lv, rn, ct)
+    stride = api.huffman_seg_stride(W)
+    seg = torch.full(((H // 8) * stride,), 0x5A, dtype=torch.uint8, device="cuda")
+    nb = torch.zeros((H // 8,), dtype=torch.int32, device="cuda")
+    api.huffman_rows(lv, rn, ct, W, H, seg, nb, chroma=chroma)
+    torch.cuda.synchronize()
+    return coef, (lv, rn, ct), dict(segments=seg.cpu().numpy(), seg_bytes=nb.cpu().numpy().astype(np.uint32), seg_stride=stride, blocks_per_row=W // 8, qtable=qtable)
+
+
+@pytest.mark.gpu
+def test_huffman_kernel_equals_the_checker():
+    api.init(0)
+    rng = np.random.default_rng(3)
+    for (W, H) in ((8, 8), (64, 16), (264, 24), (2048, 64), (4104, 16)):  # one lane ... several 256-block chunks with a ragged tail
+        for kind, q in (("photo", K1_LUMA), ("noise", np.ones(64, dtype=np.float32)), ("photo", K2_CHROMA)):
+            img = synth.plane_u8_np(W, H, kind, seed=W + H)
+            chroma = q is K2_CHROMA
+            coef, (lv, rn, ct), comp = _encode_gpu(_dev(img), W, H, q, chroma=chroma)
+            seg, nb, stride = O.huffman_rows(lv.cpu().numpy(), rn.cpu().numpy(), ct.cpu().numpy(), W, H, chroma=chroma)
+            assert np.array_equal(comp["seg_bytes"], nb), (W, H, kind)
+            for r in range(H // 8):
+                assert np.array_equal(comp["segments"][r * stride:r * stride + nb[r]], seg[r * stride:r * stride + nb[r]]), (W, H, kind, r)
+    # arbitrary (not DCT-shaped) records: dense blocks, saturating levels, empty blocks; a sub-range leaves the other rows alone
+    W, H = 512, 32
+    coef = (rng.integers(-1500, 1500, (H, W)) * (rng.random((H, W)) < 0.5)).astype(np.int16)
+    coef[:8, :64] = 0
+    lvh, rnh, cth = O.zigzag_rle("i16", coef, W, H)
+    stride = api.huffman_seg_stride(W)
+    seg = torch.full(((H // 8) * stride,), 0x5A, dtype=torch.uint8, device="cuda")
+    nb = torch.full((H // 8,), -1, dtype=torch.int32, device="cuda")
+    api.huffman_rows(_dev(lvh), _dev(rnh), _dev(cth), W, H, seg, nb, by0=1, by1=3)
+    want_seg, want_nb, _ = O.huffman_rows(lvh, rnh, cth, W, H, by0=1, by1=3, fill=0x5A)
+    got_nb = nb.cpu().numpy()
+    assert got_nb[0] == -1 and got_nb[3] == -1 and np.array_equal(got_nb[1:3].astype(np.uint32), want_nb[1:3])
+    g = seg.cpu().numpy()
+    for r in (1, 2):
+        assert np.array_equal(g[r * stride:r * stride + want_nb[r]], want_seg[r * stride:r * stride + want_nb[r]])
+    assert (g[:stride] == 0x5A).all() and (g[3 * stride:] == 0x5A).all()
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_writes_jpegs_libjpeg_opens():
+    """pixels -> mdct_fwd_u8_i16 (Annex K tables) -> mdct_zigzag_rle_i16 -> mdct_huffman_rows -> JFIF: decoded by libjpeg, the
+    picture equals our own inverse transform within 1 grey level; grey at 4096x2160 and 4:2:0 colour through mdct_split420_u8"""
+    api.init(0)
+    W, H = 4096, 2160 - 2160 % 16
+    img = synth.plane_u8_torch(W, H, "photo")
+    coef, _, comp = _encode_gpu(img, W, H, K1_LUMA)
+    data = jfif.write_jpeg([comp], W, H)
+    dec = np.asarray(Image.open(io.BytesIO(data)).convert("L"))
+    own = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+    api.inv_i16_u8(coef, own, W, H, lut=K1_LUMA)
+    assert np.abs(dec.astype(int) - own.cpu().numpy().astype(int)).max() <= 1
+    assert len(data) < W * H // 4  # and it is compressed
+    # colour: interleaved YCbCr -> split420 -> three planes -> three non-interleaved scans
+    W, H = 640, 480
+    ycc = torch.stack([synth.plane_u8_torch(W, H, "photo", seed=s) for s in (5, 6, 7)], dim=-1).contiguous()
+    y = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    cb = torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda")
+    cr = torch.empty_like(cb)
+    api.split420_u8(ycc, W, H, y, cb, cr)
+    comps, coefs = [], []
+    for plane, (w, h), q, chroma in ((y, (W, H), K1_LUMA, False), (cb, (W // 2, H // 2), K2_CHROMA, True), (cr, (W // 2, H // 2), K2_CHROMA, True)):
+        c, _, comp = _encode_gpu(None, w, h, q, chroma=chroma, from_i16=plane)
+        comps.append(comp)
+        coefs.append(c)
+    data = jfif.write_jpeg(comps, W, H)
+    im = Image.open(io.BytesIO(data))
+    im.draft("YCbCr", im.size)  # libjpeg's native output: no YCbCr -> RGB -> YCbCr round trip (and its gamut clipping) in between
+    assert im.mode == "YCbCr"
+    dec = np.asarray(im)
+    assert dec.shape == (H, W, 3)
+    own_y = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+    api.inv_i16_u8(coefs[0], own_y, W, H, lut=K1_LUMA)
+    assert np.abs(dec[:, :, 0].astype(int) - own_y.cpu().numpy().astype(int)).max() <= 1
+    # chroma comes back upsampled by libjpeg (its own interpolation): compare at the sample centres, loosely
+    own_cb = torch.empty((H // 2, W // 2), dtype=torch.uint8, device="cuda")
+    api.inv_i16_u8(coefs[1], own_cb, W // 2, H // 2, lut=K2_CHROMA)
+    box = dec[:, :, 1].astype(float).reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))
+    assert np.abs(box - own_cb.cpu().numpy().astype(float)).mean() < 2.0

@@ -60,7 +60,13 @@ ycc = [torch.stack([u8[(i + k) % NS].reshape(H, W) for k in range(3)], dim=-1).c
 sy = [torch.empty((H, W), dtype=torch.int16, device="cuda") for _ in range(2)]
 scb = [torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda") for _ in range(2)]
 scr = [torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda") for _ in range(2)]
+for i in range(2):
+    M.zigzag_rle_i16(qcoef[i], W, H, lv[i], rn[i], ct[i])
+hstride = M.huffman_seg_stride(W)
+hseg = [torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda") for _ in range(2)]
+hnb = [torch.empty((H // 8,), dtype=torch.int32, device="cuda") for _ in range(2)]
 cases += [
+    ("Huffman rows from records (3 B/px in)", 3.016, W * H, [lambda i=i: M.huffman_rows(lv[i % 2], rn[i % 2], ct[i % 2], W, H, hseg[i % 2], hnb[i % 2]) for i in range(2)]),
     ("zig-zag scan, i16 (2+2 B/px)", 4, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2]) for i in range(NS)]),
     ("zig-zag + run/level, i16 (2+3)", 5.016, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
     ("zig-zag + run/level, q32 (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_q32(q32b[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
