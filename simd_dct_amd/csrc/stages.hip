@@ -256,18 +256,20 @@ __global__ __launch_bounds__(kWG) void k_split420(SplitArgs a)
 // start, byte-aligned, 1-padded segment at out + row * seg_stride, unstuffed (the container writer
 // stuffs, simd_dct_amd/jfif.py).  The row is walked in chunks of 256 blocks, one block per lane, 64
 // consecutive blocks per wave:
-//   0. the head of the wave's records (the first kHuffStage pairs: 48 B of levels, 32 B of runs per
-//      block) comes in with 16 B per lane loads -- the NEXT chunk's are issued before this one is
-//      coded -- and is parked in LDS with a per-block skew of one dword, so that "entry i of every
-//      lane" hits 64 banks; a block with more pairs reads the rest from HBM;
+//   0. the head of the wave's records (the first kHuffStage pairs of each block) comes in with
+//      8 + 4 B per lane loads -- the NEXT chunk's are issued before this one is coded -- and is parked
+//      in LDS as one dword per pair, kRecSkew dwords per block, so that "entry i of every lane" hits
+//      64 banks; a block with more pairs reads the rest from HBM;
 //   1. DC value per lane, predecessor's by a wave shuffle (lane 0: prefetched with the records);
-//   2. walk the pairs, count bits;   3. exclusive scan: shuffles in the wave, 4 totals through LDS;
-//   4. walk again, emitting each code (Huffman code and amplitude bits as one token) into a 64-bit
-//      accumulator that is OR-ed, 32 bits at a time, into an LDS ring of the row's bit stream
-//      (ds_or: the first and last word of a block are shared with its neighbours);
+//   2. walk the pairs: each becomes its token (Huffman code and amplitude bits, <= 26 bits, and the
+//      length) in place in LDS, the lengths are summed;   3. exclusive scan of the sums: shuffles in
+//      the wave, 4 totals through LDS;
+//   4. walk the tokens, shifting each into a 64-bit accumulator that is OR-ed, 32 bits at a time,
+//      into an LDS ring of the row's bit stream (ds_or: the first and last word of a block are
+//      shared with its neighbours);
 //   5. the chunk's complete words leave, byte-swapped (the stream is MSB first), 4 B per lane, and
 //      their ring slots are cleared; the trailing partial word simply stays in the ring.
-// The ring holds kHuffRing words (8 bit/px over a chunk); a chunk with more bits than that is emitted
+// The ring holds kHuffRing words (4 bit/px over a chunk); a chunk with more bits than that is emitted
 // in several windows (walk 4 repeated, each time keeping only the words of one window).
 // ---------------------------------------------------------------------------------------
 struct HuffArgs
@@ -283,50 +285,43 @@ struct HuffArgs
 };
 
 constexpr int kHuffWaves = 4;
-constexpr int kHuffChunk = 64 * kHuffWaves;       // blocks per chunk = lanes of the workgroup
-constexpr uint32_t kHuffRing = 4096;              // words of bit stream held in LDS (power of two)
-constexpr int kHuffStage = 24;                    // pairs per block parked in LDS
-constexpr int kLvSkew = 2 * kHuffStage + 4;       // bytes per block in LDS: 48 + 4 (13 dwords: odd)
-constexpr int kRnSkew = 32 + 4;                   // 32 runs (two 16 B pieces) + 4 (9 dwords: odd)
+constexpr int kHuffChunk = 64 * kHuffWaves; // blocks per chunk = lanes of the workgroup
+constexpr uint32_t kHuffRing = 2048;        // words of bit stream held in LDS (power of two)
+constexpr int kHuffStage = 28;              // pairs per block parked in LDS, one dword each (a multiple of 4)
+constexpr int kRecSkew = kHuffStage + 1;    // dwords per block in LDS (odd: entry i of 64 blocks = 64 banks)
+constexpr int kHuffPieces = kHuffStage / 4; // a block's parked head in pieces of 4 pairs (8 B of levels + 4 B of runs)
 
-struct BlockWalk
-{ // one lane's block: calls f(table entry, amplitude bits, amplitude size) for every code in coding order
-  template <class LV, class RN, class F>
-  __device__ __forceinline__ static void run(LV &&lv, RN &&rn, int n, int pred, const uint32_t *dc, const uint32_t *ac, F &&f)
-  {
-    int i = 0, dcv = 0, p = -1;
-    if (n > 0 && rn(0) == 0)
-    { // the first pair sits at scan position 0: it is the DC coefficient
-      dcv = lv(0);
-      i = 1;
-      p = 0;
-    }
-    int diff = dcv - pred;
-    diff = diff > 2047 ? 2047 : (diff < -2047 ? -2047 : diff); // 8-bit baseline: categories 0..11 (F.1.2.1.1)
-    int s = diff ? 32 - __builtin_clz((uint32_t)(diff < 0 ? -diff : diff)) : 0; // SSSS: bits of |DIFF|
-    f(dc[s], (uint32_t)(diff < 0 ? diff - 1 : diff), s);
-    int q = 0;
-    for (; i < n; i++)
-    {
-      p += rn(i) + 1;
-      int r = p - q - 1, l = lv(i);
-      q = p;
-      l = l > 1023 ? 1023 : (l < -1023 ? -1023 : l); // categories 1..10 (F.1.2.2.1)
-      for (; r > 15; r -= 16)
-        f(ac[0xF0], 0u, 0); // ZRL
-      s = 32 - __builtin_clz((uint32_t)(l < 0 ? -l : l));
-      f(ac[(r << 4) | s], (uint32_t)(l < 0 ? l - 1 : l), s);
-    }
-    if (q < 63)
-      f(ac[0x00], 0u, 0); // EOB
-  }
+// A parked pair is  run << 16 | (uint16_t)level  (top 10 bits zero).  The counting walk replaces it by
+// its token  length << 27 | Huffman code and amplitude bits  (length >= 2: top 5 bits non-zero); pairs
+// that need ZRL codes first (rare) stay as they are and are coded again by the emitting walk.
+struct HuffTok
+{
+  uint32_t bits, len;
 };
+
+__device__ __forceinline__ HuffTok huff_dc_token(int diff, const uint32_t *dc)
+{
+  diff = diff > 2047 ? 2047 : (diff < -2047 ? -2047 : diff);                        // 8-bit baseline: categories 0..11 (F.1.2.1.1)
+  const int s = diff ? 32 - __builtin_clz((uint32_t)(diff < 0 ? -diff : diff)) : 0; // SSSS: bits of |DIFF|
+  const uint32_t e = dc[s];
+  return {((e & 0xFFFFu) << s) | ((uint32_t)(diff < 0 ? diff - 1 : diff) & ((1u << s) - 1u)), (e >> 16) + (uint32_t)s};
+}
+
+__device__ __forceinline__ HuffTok huff_ac_token(int r, int l, const uint32_t *ac)
+{                                                 // r: 0..15 zeros before the coefficient
+  l = l > 1023 ? 1023 : (l < -1023 ? -1023 : l); // categories 1..10 (F.1.2.2.1)
+  const int amp = l + (l >> 31);                 // F.1.2.2.1: a negative value is coded as value - 1, low SSSS bits
+  int lead; // leading bits equal to the sign bit
+  asm("v_ffbh_i32 %0, %1" : "=v"(lead) : "v"(amp));
+  const int s = 32 - lead; // SSSS = bits of |l| = significant bits of amp (l != 0)
+  const uint32_t e = ac[(r << 4) | s];
+  return {((e & 0xFFFFu) << s) | ((uint32_t)amp & ((1u << s) - 1u)), (e >> 16) + (uint32_t)s}; // <= 16 + 10 bits
+}
 
 __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
 {
   __shared__ uint32_t ac[256], dc[12];
-  __shared__ __attribute__((aligned(16))) uint8_t lv_all[kHuffWaves][64 * kLvSkew];
-  __shared__ __attribute__((aligned(16))) uint8_t rn_all[kHuffWaves][64 * kRnSkew];
+  __shared__ uint32_t rec_all[kHuffWaves][64 * kRecSkew];
   __shared__ uint32_t ring[kHuffRing];
   __shared__ uint32_t tot[2][kHuffWaves];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -341,50 +336,40 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
   const uint8_t *g_lv = reinterpret_cast<const uint8_t *>(a.levels) + row_blk0 * 128;
   const uint8_t *g_rn = a.runs + row_blk0 * 64;
   const uint8_t *g_ct = a.counts + row_blk0;
-  uint8_t *lv_lds = lv_all[wave], *rn_lds = rn_all[wave];
+  uint32_t *rec_lds = rec_all[wave];
 
-  // the head of the wave's 64 records as 16-byte pieces: levels 3 per block, runs 2 per block
-  u32x4 plv[3], prn[2];
+  // the head of the wave's 64 records: kHuffPieces pieces per block, kHuffPieces per lane
+  u32x2 plv[kHuffPieces];
+  uint32_t prn[kHuffPieces];
   int pn = 0;                          // this lane's pair count
   int pp_ct = 0, pp_rn = 1, pp_lv = 0; // head of the block before the wave's first one (its DC is lane 0's predictor)
+  // Straight-line loads with clamped addresses: under a branch the compiler's wait-count bookkeeping serialises them
+  // (one round trip per piece) and waits for the whole prefetch before the first walk.
+  const uint32_t last_blk = a.bpr - 1;
   auto fetch = [&](uint32_t c0w) { // c0w: the wave's first block in the row
 #pragma unroll
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < kHuffPieces; k++)
     {
-      const uint32_t q = k * 64 + lane, b = q / 3, part = q - 3 * b;
-      if (c0w + b < a.bpr)
-        plv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(g_lv + (size_t)(c0w + b) * 128 + part * 16));
+      const uint32_t q = k * 64 + lane, b = q / kHuffPieces, part = q - kHuffPieces * b, blk = min(c0w + b, last_blk);
+      plv[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(g_lv + (blk * 128u + part * 8u))); // 32-bit offsets from a uniform base
+      prn[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(g_rn + (blk * 64u + part * 4u)));
     }
-#pragma unroll
-    for (int k = 0; k < 2; k++)
-    {
-      const uint32_t q = k * 64 + lane, b = q >> 1, part = q & 1;
-      if (c0w + b < a.bpr)
-        prn[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(g_rn + (size_t)(c0w + b) * 64 + part * 16));
-    }
-    pn = c0w + lane < a.bpr ? (int)g_ct[c0w + lane] : 0;
-    pp_ct = 0;
-    if (c0w > 0 && c0w < a.bpr)
-    { // three independent loads: nothing here waits for them
-      pp_ct = g_ct[c0w - 1];
-      pp_rn = g_rn[(size_t)(c0w - 1) * 64];
-      pp_lv = a.levels[(row_blk0 + c0w - 1) * 64];
-    }
+    pn = g_ct[min(c0w + lane, last_blk)]; // lanes past the row's end are masked by `live`
+    const uint32_t pb = min(max(c0w, 1u) - 1u, last_blk);
+    pp_ct = g_ct[pb];
+    pp_rn = g_rn[pb * 64u];
+    pp_lv = *reinterpret_cast<const int16_t *>(g_lv + pb * 128u);
   };
-  auto park = [&]() { // registers -> LDS
+  auto park = [&]() { // registers -> LDS, level and run of a pair in one dword
 #pragma unroll
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < kHuffPieces; k++)
     {
-      const uint32_t q = k * 64 + lane, b = q / 3, part = q - 3 * b;
-      uint32_t *d = reinterpret_cast<uint32_t *>(lv_lds + b * kLvSkew + part * 16);
-      d[0] = plv[k].x; d[1] = plv[k].y; d[2] = plv[k].z; d[3] = plv[k].w;
-    }
+      const uint32_t q = k * 64 + lane, b = q / kHuffPieces, part = q - kHuffPieces * b;
+      uint32_t *d = rec_lds + b * kRecSkew + part * 4;
+      const uint32_t l[2] = {plv[k].x, plv[k].y};
 #pragma unroll
-    for (int k = 0; k < 2; k++)
-    {
-      const uint32_t q = k * 64 + lane, b = q >> 1, part = q & 1;
-      uint32_t *d = reinterpret_cast<uint32_t *>(rn_lds + b * kRnSkew + part * 16);
-      d[0] = prn[k].x; d[1] = prn[k].y; d[2] = prn[k].z; d[3] = prn[k].w;
+      for (int e = 0; e < 4; e++)
+        d[e] = ((l[e >> 1] >> (16 * (e & 1))) & 0xFFFFu) | (((prn[k] >> (8 * e)) & 0xFFu) << 16);
     }
   };
   auto wave_sync = [] {
@@ -392,6 +377,7 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
+  const uint32_t zrl = a.ac[0xF0], eob = a.ac[0x00]; // size << 16 | code (kernel arguments: scalar registers)
 
   uint32_t base_bits = 0; // bits of the row produced by earlier chunks
   uint32_t par = 0;
@@ -401,26 +387,55 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
   {
     const uint32_t c0w = c0 + wave * 64, bx = c0w + lane;
     const bool live = bx < a.bpr;
-    wave_sync(); // the previous chunk's walks are done with the wave's LDS records
     park();
-    const int n = pn, prev_dc = (pp_ct > 0 && pp_rn == 0) ? pp_lv : 0;
+    const int n = live ? pn : 0, prev_dc = (c0w > 0 && pp_ct > 0 && pp_rn == 0) ? pp_lv : 0;
     if (c0 + kHuffChunk < a.bpr)
       fetch(c0w + kHuffChunk); // in flight while this chunk is coded
     wave_sync();
-    const int16_t *lv_l = reinterpret_cast<const int16_t *>(lv_lds + lane * kLvSkew);
-    const uint8_t *rn_l = rn_lds + lane * kRnSkew;
-    const int16_t *lv_g = a.levels + (row_blk0 + (live ? bx : 0)) * 64;
-    const uint8_t *rn_g = g_rn + (size_t)(live ? bx : 0) * 64;
-    auto lv = [&](int i) -> int { return i < kHuffStage ? (int)lv_l[i] : (int)lv_g[i]; };
-    auto rn = [&](int i) -> int { return i < kHuffStage ? (int)rn_l[i] : (int)rn_g[i]; };
+    uint32_t *rec = rec_lds + lane * kRecSkew;
+    const int16_t *lv_g = reinterpret_cast<const int16_t *>(g_lv + (live ? bx : 0u) * 128u);
+    const uint8_t *rn_g = g_rn + (live ? bx : 0u) * 64u;
+    const int nl = n < kHuffStage ? n : kHuffStage; // pairs of this block that sit in LDS
     // 1. DC of this block and of its predecessor
-    const int my_dc = (n > 0 && rn_l[0] == 0) ? (int)lv_l[0] : 0;
+    const uint32_t e0 = rec[0];
+    const bool has_dc = n > 0 && (e0 >> 16) == 0; // the first pair sits at scan position 0: it is the DC coefficient
+    const int my_dc = has_dc ? (int)(int16_t)e0 : 0;
     const int up = __shfl_up(my_dc, 1, 64);
-    const int pred = lane == 0 ? prev_dc : up;
-    // 2. bits of this block
+    const HuffTok dct = huff_dc_token(my_dc - (lane == 0 ? prev_dc : up), dc);
+    // 2. bits of this block; the parked pairs become tokens
     uint32_t bits = 0;
+    bool need_eob = false;
     if (live)
-      BlockWalk::run(lv, rn, n, pred, dc, ac, [&](uint32_t e, uint32_t, int s) { bits += (e >> 16) + (uint32_t)s; });
+    {
+      bits = dct.len;
+      int pos = has_dc ? 0 : -1; // scan position of the last coded coefficient
+      auto count = [&](uint32_t e, int run, int l) -> uint32_t { // the pair's token, or e itself if ZRL codes precede it
+        const int r = run + (pos >> 31); // zeros before it among the AC positions (position 0 is the DC's)
+        pos += run + 1;
+        const HuffTok t = huff_ac_token(r & 15, l, ac);
+        bits += t.len + (uint32_t)(r >> 4) * (zrl >> 16);
+        return r > 15 ? e : t.len << 27 | t.bits;
+      };
+      int i = has_dc ? 1 : 0;
+      for (; i + 1 < nl; i += 2)
+      { // two pairs per trip: their LDS reads and table lookups overlap
+        const uint32_t ea = rec[i], eb = rec[i + 1];
+        const uint32_t ta = count(ea, (int)(ea >> 16), (int)(int16_t)ea), tb = count(eb, (int)(eb >> 16), (int)(int16_t)eb);
+        rec[i] = ta;
+        rec[i + 1] = tb;
+      }
+      if (i < nl)
+      {
+        const uint32_t e = rec[i];
+        rec[i] = count(e, (int)(e >> 16), (int)(int16_t)e);
+        i++;
+      }
+      for (; i < n; i++)
+        count(0u, (int)rn_g[i], (int)lv_g[i]);
+      need_eob = pos < 63;
+      if (need_eob)
+        bits += eob >> 16;
+    }
     // 3. exclusive scan: inside the wave, then over the 4 waves
     uint32_t incl = bits;
 #pragma unroll
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
     }
     const uint32_t end_bits = base_bits + chunk_bits;
     const uint32_t w_first = base_bits >> 5, w_end = end_bits >> 5; // complete words of the row after this chunk: [.., w_end)
-    // 4. + 5. emit and flush, one window of the ring at a time (one window unless the chunk exceeds 8 bit/px)
+    // 4. + 5. emit and flush, one window of the ring at a time (one window unless the chunk exceeds 4 bit/px)
     for (uint32_t win = w_first; win <= w_end; win += kHuffRing)
     {
       if (win != w_first)
@@ -452,22 +467,49 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
       {
         const uint32_t cur = base_bits + wave_start + (incl - bits); // bit position in the row
         uint32_t widx = cur >> 5;
-        uint64_t acc = 0;         // bits not yet written
+        uint32_t acc = 0;         // the bits not yet written: acc < 2^nacc
         uint32_t nacc = cur & 31; // pretend that many zero bits precede: OR leaves the neighbour's bits alone
-        BlockWalk::run(lv, rn, n, pred, dc, ac, [&](uint32_t e, uint32_t amp, int s) {
-          const uint32_t tok = ((e & 0xFFFFu) << s) | (amp & ((1u << s) - 1u)), len = (e >> 16) + (uint32_t)s; // <= 16 + 11 bits
-          acc = (acc << len) | (uint64_t)tok;
-          nacc += len;
-          if (nacc >= 32)
+        auto put = [&](uint32_t tok, uint32_t len) { // 1 <= len <= 27, tok < 2^len
+          const uint32_t total = nacc + len;
+          if (total < 32)
           {
-            nacc -= 32;
-            if (widx - win < kHuffRing)
-              atomicOr(&ring[widx & (kHuffRing - 1)], (uint32_t)(acc >> nacc));
-            widx++;
+            acc = (acc << len) | tok;
+            nacc = total;
           }
-        });
+          else
+          { // the word is complete: the pending bits and the head of the token
+            const uint32_t over = total - 32;
+            if (widx - win < kHuffRing)
+              atomicOr(&ring[widx & (kHuffRing - 1)], (acc << ((32 - nacc) & 31)) | (tok >> over));
+            widx++;
+            acc = tok & ((1u << over) - 1u);
+            nacc = over;
+          }
+        };
+        auto put_pair = [&](int r, int l) {
+          for (; r > 15; r -= 16)
+            put(zrl & 0xFFFFu, zrl >> 16);
+          const HuffTok t = huff_ac_token(r, l, ac);
+          put(t.bits, t.len);
+        };
+        put(dct.bits, dct.len);
+        int i = has_dc ? 1 : 0;
+        uint32_t e_next = rec[i]; // one token ahead (the row's skew dword makes rec[nl] readable)
+        for (; i < nl; i++)
+        {
+          const uint32_t e = e_next;
+          e_next = rec[i + 1];
+          if (e >> 27)
+            put(e & 0x7FFFFFFu, e >> 27);
+          else
+            put_pair((int)(e >> 16) - (i == 0 ? 1 : 0), (int)(int16_t)e);
+        }
+        for (; i < n; i++)
+          put_pair((int)rn_g[i] - (i == 0 ? 1 : 0), (int)lv_g[i]);
+        if (need_eob)
+          put(eob & 0xFFFFu, eob >> 16);
         if (nacc && widx - win < kHuffRing)
-          atomicOr(&ring[widx & (kHuffRing - 1)], (uint32_t)(acc << (32 - nacc)));
+          atomicOr(&ring[widx & (kHuffRing - 1)], acc << (32 - nacc));
       }
       __syncthreads();
       const uint32_t stop = min(w_end, win + kHuffRing);

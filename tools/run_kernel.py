@@ -1,5 +1,5 @@
 """Launch ONE engine kernel repeatedly on the bench workload (for rocprofv3 --pmc passes):
-    python3 tools/run_kernel.py {roundtrip|fwd|inv|q32|copy} [launches]"""
+    python3 tools/run_kernel.py {roundtrip|fwd|inv|q32|copy|huffman|huffman_k1} [launches]"""
 import os
 import sys
 
@@ -19,6 +19,25 @@ dsts = [torch.empty_like(s) for s in srcs]
 lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
 u8s = [synth.plane_u8_torch(W, H, "photo", seed=synth.SEED + i) for i in range(4)]
 u8d = [torch.empty(W * H, dtype=torch.uint8, device="cuda") for _ in range(4)]
+if which.startswith("huffman"):
+    # records of quantised coefficients: "huffman" = the dense time_all.py case (22 pairs per block), "huffman_k1" = Annex K.1 table (5 pairs)
+    q = (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32) if which == "huffman" else np.array(
+        [16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+         18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+    nblk = (W // 8) * (H // 8)
+    recs = []
+    for s_ in range(2):
+        M.fwd_i16(srcs[s_], dsts[s_], W, H, lut=q)
+        lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
+        rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
+        ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
+        M.zigzag_rle_i16(dsts[s_], W, H, lv, rn, ct)
+        recs.append((lv, rn, ct))
+    hstride = M.huffman_seg_stride(W)
+    hseg = torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda")
+    hnb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    print("pairs per block", float(recs[0][2].float().mean()))
 torch.cuda.synchronize()
 for i in range(n):
     s = i % 4
@@ -30,6 +49,8 @@ for i in range(n):
         M.inv_i16(srcs[s], dsts[s], W, H)
     elif which == "q32":
         M.fwd_quant_u8(u8s[s], u8d[s], lut, W, H, 0, H // 8)
+    elif which.startswith("huffman"):
+        M.huffman_rows(*recs[i % 2], W, H, hseg, hnb)
     elif which == "copy":
         M.stream_copy(srcs[s], dsts[s], W * H * 2)
 torch.cuda.synchronize()

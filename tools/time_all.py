@@ -62,11 +62,23 @@ scb = [torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda") for _ in 
 scr = [torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda") for _ in range(2)]
 for i in range(2):
     M.zigzag_rle_i16(qcoef[i], W, H, lv[i], rn[i], ct[i])
+# the same planes under the Annex K.1 luminance table: the sparser records of an ordinary-quality JPEG
+K1 = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+               18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+lvk = [torch.empty_like(lv[0]) for _ in range(2)]
+rnk = [torch.empty_like(rn[0]) for _ in range(2)]
+ctk = [torch.empty_like(ct[0]) for _ in range(2)]
+for i in range(2):
+    M.fwd_i16(i16[i], o16[i], W, H, lut=K1)
+    M.zigzag_rle_i16(o16[i], W, H, lvk[i], rnk[i], ctk[i])
+torch.cuda.synchronize()
+print(f"records: {float(ct[0].float().mean()):.1f} pairs per block (quality-60 table), {float(ctk[0].float().mean()):.1f} (Annex K.1 table)")
 hstride = M.huffman_seg_stride(W)
 hseg = [torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda") for _ in range(2)]
 hnb = [torch.empty((H // 8,), dtype=torch.int32, device="cuda") for _ in range(2)]
 cases += [
     ("Huffman rows from records (3 B/px in)", 3.016, W * H, [lambda i=i: M.huffman_rows(lv[i % 2], rn[i % 2], ct[i % 2], W, H, hseg[i % 2], hnb[i % 2]) for i in range(2)]),
+    ("Huffman rows, Annex K.1 records", 3.016, W * H, [lambda i=i: M.huffman_rows(lvk[i % 2], rnk[i % 2], ctk[i % 2], W, H, hseg[i % 2], hnb[i % 2]) for i in range(2)]),
     ("zig-zag scan, i16 (2+2 B/px)", 4, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2]) for i in range(NS)]),
     ("zig-zag + run/level, i16 (2+3)", 5.016, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
     ("zig-zag + run/level, q32 (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_q32(q32b[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
