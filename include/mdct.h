@@ -183,6 +183,8 @@ int mdct_zigzag_rle_u8(const uint8_t *coef, int layout, size_t sizeX, size_t siz
  * >= 208 * (sizeX/8) + 8 (the worst case of F.1.2); sizeX/8 <= 65535. */
 int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *counts, size_t sizeX, size_t sizeY,
                       size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, void *stream);
+/* smallest legal seg_stride for a plane sizeX wide: 208 * (sizeX/8) + 8 (host function) */
+size_t mdct_huffman_seg_stride(size_t sizeX);
 /* BITS (16 counts) and HUFFVAL of the table as a DHT marker segment carries them (host function).
  * which: 0 DC luminance (K.3), 1 AC luminance (K.5), 2 DC chrominance (K.4), 3 AC chrominance (K.6). */
 int mdct_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals);

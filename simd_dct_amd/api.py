@@ -250,7 +250,7 @@ def huffman_spec(which):
 
 def huffman_seg_stride(sizeX):
     """smallest legal segment stride for mdct_huffman_rows on a plane of this width"""
-    return (sizeX // 8) * 208 + 8
+    return int(_lib.load().mdct_huffman_seg_stride(sizeX))
 
 
 def huffman_rows(levels, runs, counts, sizeX, sizeY, out, seg_bytes, seg_stride=None, chroma=False, by0=0, by1=None, stream=None, check=True):

@@ -677,6 +677,8 @@ int mdct_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals)
   return MDCT_SUCCESS;
 }
 
+size_t mdct_huffman_seg_stride(size_t sizeX) { return (sizeX / 8) * 208 + 8; }
+
 int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *counts, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride,
                       uint32_t *seg_bytes, void *stream)
 {
