@@ -41,18 +41,22 @@ struct ScanArgs
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWG = 256;
+// k_scan: every wave works alone (wave-private LDS records), so the workgroup size only sets the LDS granule and the
+// dispatch rate; measured per source (profiles/r02_scan_workgroup_size.log)
+constexpr int scan_wg(int src) { return src == 1 || src == 2 ? 128 : 64; } // SRC_Q32, SRC_STEREO : SRC_I16, SRC_BLOCK
 constexpr int kLvRow = 144; // 64 int16 + 16 B: slot 64 (inside the pad) takes the writes of zero coefficients
 constexpr int kRnRow = 80;  // 64 u8 + 16 B, same trick
 constexpr int kQ32Grp = 520; // staged q32 group: 512 B + 8: a byte read of coefficient c touches banks 2g + 2c + {0,1}, distinct for the 8 groups
 
 template <int SRC, bool RLE>
-__global__ __launch_bounds__(kWG) void k_scan(ScanArgs a)
+__global__ __launch_bounds__(scan_wg(SRC)) void k_scan(ScanArgs a)
 {
-  __shared__ __attribute__((aligned(16))) uint8_t lv_all[kWG / 64][64 * kLvRow];
-  __shared__ __attribute__((aligned(16))) uint8_t rn_all[kWG / 64][RLE ? 64 * kRnRow : 16];
+  constexpr int kScanWG = scan_wg(SRC);
+  __shared__ __attribute__((aligned(16))) uint8_t lv_all[kScanWG / 64][64 * kLvRow];
+  __shared__ __attribute__((aligned(16))) uint8_t rn_all[kScanWG / 64][RLE ? 64 * kRnRow : 16];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t wave_t0 = blockIdx.x * kWG + wave * 64; // first block of the wave within the launch
+  const uint32_t wave_t0 = blockIdx.x * kScanWG + wave * 64; // first block of the wave within the launch
   if (wave_t0 >= a.nblocks)
     return;
   const uint32_t nvalid = min(64u, a.nblocks - wave_t0);
@@ -611,11 +615,11 @@ int scan_launch(int src, const void *coef, size_t pitch, size_t sizeX, size_t si
   a.bpr = (uint32_t)bpr;
   a.by0 = (uint32_t)by0;
   a.nblocks = (uint32_t)n;
-  const dim3 g((uint32_t)((n + mdct::kWG - 1) / mdct::kWG)), b(mdct::kWG);
   hipStream_t s = (hipStream_t)stream;
 #define MDCT_SCAN(SRC) \
   do \
   { \
+    const dim3 g((uint32_t)((n + mdct::scan_wg(SRC) - 1) / mdct::scan_wg(SRC))), b(mdct::scan_wg(SRC)); \
     if (runs) \
       hipLaunchKernelGGL((mdct::k_scan<SRC, true>), g, b, 0, s, a); \
     else \

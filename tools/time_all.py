@@ -52,6 +52,12 @@ for i in range(NS):
     M.fwd_i16(i16[i], qcoef[i], W, H, lut=lut60)  # sparse, photo-like quantised coefficients
     M.fwd_quant_u8(u8[i], o8[i], lut2000, W, H, 0, H // 8)
 q32b = [o.clone() for o in o8]
+st8, bl8 = [], []
+for i in range(2):  # the same pictures in the reference's other two intact layouts
+    M.fwd_quant_u8(u8[i], o8[i], lut8, W, H, 0, H // 16, layout=M.LAYOUT_STEREO, profile=M.PROFILE_REF_SSE)
+    st8.append(o8[i].clone())
+    M.fwd_quant_u8(u8[i], o8[i], lut8, W, H, 0, H // 8, layout=M.LAYOUT_BLOCK, profile=M.PROFILE_REF_SCALAR)
+    bl8.append(o8[i].clone())
 nblk = (W // 8) * (H // 8)
 lv = [torch.empty((nblk, 64), dtype=torch.int16, device="cuda") for _ in range(2)]
 rn = [torch.empty((nblk, 64), dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -82,6 +88,8 @@ cases += [
     ("zig-zag scan, i16 (2+2 B/px)", 4, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2]) for i in range(NS)]),
     ("zig-zag + run/level, i16 (2+3)", 5.016, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
     ("zig-zag + run/level, q32 (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_q32(q32b[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
+    ("zig-zag + run/level, stereo planes (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_u8(st8[i % 2], M.LAYOUT_STEREO, W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(2)]),
+    ("zig-zag + run/level, encq blocks (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_u8(bl8[i % 2], M.LAYOUT_BLOCK, W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(2)]),
     ("4:2:0 split (3+3 B/px)", 6, W * H, [lambda i=i: M.split420_u8(ycc[i], W, H, sy[i], scb[i], scr[i]) for i in range(2)]),
 ]
 # config 4 on one GPU: 256 independent 4096x4096 int16 planes, forward only.  Blocks are
