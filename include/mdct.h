@@ -179,7 +179,9 @@ int mdct_zigzag_rle_u8(const uint8_t *coef, int layout, size_t sizeX, size_t siz
  * 1-bits (F.1.2.3), written at out + by * seg_stride with its length in seg_bytes[by].  The bytes are NOT
  * stuffed (B.1.1.5) and carry no markers: the container writer does both (simd_dct_amd/jfif.py writes a JFIF
  * file any decoder opens; the tests decode it with libjpeg).  Levels are those of 8-bit baseline JPEG (DC
- * differences within +-2047, AC within +-1023; larger values saturate).  seg_stride: multiple of 4,
+ * differences within +-2047, AC within +-1023; larger values saturate).  A count above 64 is read as 64; a
+ * record that then is not a block (a zero AC level, scan positions beyond 63) is coded as its DC coefficient
+ * alone, so the worst case below holds for any input.  seg_stride: multiple of 4,
  * >= 208 * (sizeX/8) + 8 (the worst case of F.1.2); sizeX/8 <= 65535. */
 int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *counts, size_t sizeX, size_t sizeY,
                       size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, void *stream);

@@ -994,10 +994,21 @@ int orc_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *
       const size_t blk = by * bpr + bx;
       const int16_t *lv = levels + blk * 64;
       const uint8_t *rn = runs + blk * 64;
-      const int n = counts[blk];
+      int n = counts[blk] > 64 ? 64 : counts[blk];
       int i = 0, dc = 0;
       if (n > 0 && rn[0] == 0)
         dc = lv[i++]; /* the first pair sits at scan position 0 */
+      { /* not a block (a zero AC level, or positions past 63): coded as its DC coefficient alone, so that the
+           worst case of F.1.2 (which sizes seg_stride) holds for any input */
+        int pp = i ? 0 : -1, bad = 0;
+        for (int k = i; k < n; k++)
+        {
+          pp += rn[k] + 1;
+          bad |= lv[k] == 0;
+        }
+        if (bad || pp > 63)
+          n = i;
+      }
       int diff = dc - pred;
       pred = dc;
       diff = diff > 2047 ? 2047 : (diff < -2047 ? -2047 : diff); /* 8-bit baseline: categories 0..11 (F.1.2.1.1) */

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
     const uint32_t c0w = c0 + wave * 64, bx = c0w + lane;
     const bool live = bx < a.bpr;
     park();
-    const int n = live ? pn : 0, prev_dc = (c0w > 0 && pp_ct > 0 && pp_rn == 0) ? pp_lv : 0;
+    const int n = live ? min(pn, 64) : 0, prev_dc = (c0w > 0 && pp_ct > 0 && pp_rn == 0) ? pp_lv : 0;
     if (c0 + kHuffChunk < a.bpr)
       fetch(c0w + kHuffChunk); // in flight while this chunk is coded
     wave_sync();
@@ -409,18 +409,22 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
     // 2. bits of this block; the parked pairs become tokens
     uint32_t bits = 0;
     bool need_eob = false;
+    const int first_ac = has_dc ? 1 : 0;
+    int ac_end = n; // pairs [first_ac, ac_end) are coded
     if (live)
     {
       bits = dct.len;
       int pos = has_dc ? 0 : -1; // scan position of the last coded coefficient
+      uint32_t lmin = 0xFFFFu;   // smallest AC level seen, as a 16-bit pattern: 0 only for a zero level
       auto count = [&](uint32_t e, int run, int l) -> uint32_t { // the pair's token, or e itself if ZRL codes precede it
         const int r = run + (pos >> 31); // zeros before it among the AC positions (position 0 is the DC's)
         pos += run + 1;
+        lmin = min(lmin, (uint32_t)l & 0xFFFFu);
         const HuffTok t = huff_ac_token(r & 15, l, ac);
         bits += t.len + (uint32_t)(r >> 4) * (zrl >> 16);
         return r > 15 ? e : t.len << 27 | t.bits;
       };
-      int i = has_dc ? 1 : 0;
+      int i = first_ac;
       for (; i + 1 < nl; i += 2)
       { // two pairs per trip: their LDS reads and table lookups overlap
         const uint32_t ea = rec[i], eb = rec[i + 1];
@@ -436,6 +440,12 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
       }
       for (; i < n; i++)
         count(0u, (int)rn_g[i], (int)lv_g[i]);
+      if (pos > 63 || lmin == 0)
+      { // not a block (positions past 63, or a zero level): coded as its DC coefficient alone -- keeps the worst case of F.1.2
+        ac_end = first_ac;
+        bits = dct.len;
+        pos = 0;
+      }
       need_eob = pos < 63;
       if (need_eob)
         bits += eob >> 16;
@@ -497,9 +507,10 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
           put(t.bits, t.len);
         };
         put(dct.bits, dct.len);
-        int i = has_dc ? 1 : 0;
+        int i = first_ac;
+        const int nl2 = ac_end < nl ? ac_end : nl;
         uint32_t e_next = rec[i]; // one token ahead (the row's skew dword makes rec[nl] readable)
-        for (; i < nl; i++)
+        for (; i < nl2; i++)
         {
           const uint32_t e = e_next;
           e_next = rec[i + 1];
@@ -508,7 +519,7 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
           else
             put_pair((int)(e >> 16) - (i == 0 ? 1 : 0), (int)(int16_t)e);
         }
-        for (; i < n; i++)
+        for (; i < ac_end; i++)
           put_pair((int)rn_g[i] - (i == 0 ? 1 : 0), (int)lv_g[i]);
         if (need_eob)
           put(eob & 0xFFFFu, eob >> 16);

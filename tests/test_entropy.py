@@ -154,6 +154,26 @@ def test_huffman_kernel_equals_the_checker():
     for r in (1, 2):
         assert np.array_equal(g[r * stride:r * stride + want_nb[r]], want_seg[r * stride:r * stride + want_nb[r]])
     assert (g[:stride] == 0x5A).all() and (g[3 * stride:] == 0x5A).all()
+    # garbage in: random bytes as records (zero levels, runs up to 255, counts up to 255).  Such a record is coded as its DC
+    # alone, so no row outgrows its segment, and the checker agrees byte for byte
+    W, H = 2304, 24
+    nblk = (W // 8) * (H // 8)
+    lvh = rng.integers(-32768, 32768, (nblk, 64)).astype(np.int16)
+    lvh[rng.random((nblk, 64)) < 0.05] = 0
+    rnh = rng.integers(0, 256, (nblk, 64)).astype(np.uint8)
+    rnh[rng.random((nblk, 64)) < 0.9] = 0  # mostly dense, so that a good share of the records stays valid
+    cth = rng.integers(0, 256, nblk).astype(np.uint8)
+    cth[rng.random(nblk) < 0.7] //= 8
+    stride = api.huffman_seg_stride(W)
+    seg = torch.full(((H // 8) * stride + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    nb = torch.zeros((H // 8,), dtype=torch.int32, device="cuda")
+    api.huffman_rows(_dev(lvh), _dev(rnh), _dev(cth), W, H, seg, nb)
+    want_seg, want_nb, _ = O.huffman_rows(lvh, rnh, cth, W, H, fill=0x5A)
+    g, got_nb = seg.cpu().numpy(), nb.cpu().numpy().astype(np.uint32)
+    assert np.array_equal(got_nb, want_nb) and (got_nb <= stride - 8).all()
+    for r in range(H // 8):
+        assert np.array_equal(g[r * stride:r * stride + want_nb[r]], want_seg[r * stride:r * stride + want_nb[r]]), r
+    assert (g[(H // 8) * stride:] == 0x5A).all()
 
 
 @pytest.mark.gpu
