@@ -344,6 +344,25 @@ def main():
         except Exception as e:
             extras["roundtrip_8_planes_one_launch"] = {"error": str(e)[:120]}
 
+        # the stages after the transform: quantised coefficients -> zig-zag + run/level records -> baseline Huffman rows
+        try:
+            q60 = (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32)
+            M.fwd_i16(srcs[0], dsts[0], W, H, lut=q60)
+            nblk = (W // 8) * (H // 8)
+            lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
+            rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
+            ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
+            hstride = M.huffman_seg_stride(W)
+            hseg = torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda")
+            hnb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
+            extras["zigzag_rle_i16"] = rate(lambda i: M.zigzag_rle_i16(dsts[0], W, H, lv, rn, ct), 5 * W * H + nblk, n=100, warm=200)
+            extras["huffman_rows"] = rate(lambda i: M.huffman_rows(lv, rn, ct, W, H, hseg, hnb), 3 * W * H + nblk, n=100, warm=200)
+            extras["huffman_rows"]["pairs_per_block"] = round(float(ct.float().mean()), 1)
+            extras["huffman_rows"]["bits_per_px"] = round(float(hnb.sum()) * 8 / (W * H), 3)
+            del lv, rn, ct, hseg, hnb
+        except Exception as e:
+            extras["huffman_rows"] = {"error": str(e)[:120]}
+
     log("extras done")
     if dist is not None and not args.no_extras and args.backend == "nccl":
         # north_star's whole-node run at configs[3]'s own shape: a batch of 256 independent 4096x4096 int16 planes,
