@@ -216,3 +216,45 @@ def test_gpu_pipeline_writes_jpegs_libjpeg_opens():
     api.inv_i16_u8(coefs[1], own_cb, W // 2, H // 2, lut=K2_CHROMA)
     box = dec[:, :, 1].astype(float).reshape(H // 2, 2, W // 2, 2).mean(axis=(1, 3))
     assert np.abs(box - own_cb.cpu().numpy().astype(float)).mean() < 2.0
+
+
+@pytest.mark.gpu
+def test_encoder_stages_replay_from_one_hip_graph():
+    """a small frame is launch-bound: pixels -> coefficients -> records -> Huffman rows captured once as a hipGraph
+    (the entry points neither allocate nor synchronise) and replayed on new pictures; every replay decodes with libjpeg"""
+    api.init(0)
+    W, H = 1920, 1080 - 1080 % 8
+    img = torch.zeros((H, W), dtype=torch.uint8, device="cuda")
+    coef = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    nblk = (W // 8) * (H // 8)
+    lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
+    rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
+    ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
+    stride = api.huffman_seg_stride(W)
+    seg = torch.zeros(((H // 8) * stride,), dtype=torch.uint8, device="cuda")
+    nb = torch.zeros((H // 8,), dtype=torch.int32, device="cuda")
+
+    def stages():
+        api.fwd_u8_i16(img, coef, W, H, lut=K1_LUMA)
+        api.zigzag_rle_i16(coef, W, H, lv, rn, ct)
+        api.huffman_rows(lv, rn, ct, W, H, seg, nb)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm up outside capture (lazy device probe)
+        stages()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        stages()
+    for seed in (21, 22):
+        pic = synth.plane_u8_np(W, H, "photo", seed=seed)
+        img.copy_(_dev(pic))
+        g.replay()
+        torch.cuda.synchronize()
+        comp = dict(segments=seg.cpu().numpy(), seg_bytes=nb.cpu().numpy().astype(np.uint32), seg_stride=stride, blocks_per_row=W // 8, qtable=K1_LUMA)
+        dec = np.asarray(Image.open(io.BytesIO(jfif.write_jpeg([comp], W, H))).convert("L"))
+        own = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+        api.inv_i16_u8(coef, own, W, H, lut=K1_LUMA)
+        assert np.abs(dec.astype(int) - own.cpu().numpy().astype(int)).max() <= 1, seed
+        assert np.abs(dec.astype(int) - pic.astype(int)).mean() < 16  # and it is this picture (whose +-24 noise K.1 quantises away)
