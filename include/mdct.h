@@ -172,6 +172,11 @@ int mdct_zigzag_rle_q32(const uint8_t *q32, size_t sizeX, size_t sizeY, size_t b
  * MDCT_LAYOUT_BLOCK_SSE stores only half of every block (simd_dct.cpp:1662-1676) and is refused. */
 int mdct_zigzag_rle_u8(const uint8_t *coef, int layout, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
                        int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
+/* The encoder's front half fused: 8-bit pixels -> the records of mdct_fwd_u8_i16 followed by mdct_zigzag_rle_i16
+ * (bit for bit), without the int16 plane in between: 1 byte in + 3 bytes out per pixel instead of 3 + 5.
+ * pitch in bytes; no alignment requirement on the pixel plane; levels and runs 16-byte aligned; lut may be NULL. */
+int mdct_fwd_u8_records(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY,
+                        size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
 /* Entropy stage: baseline Huffman coding of those records (ITU-T T.81 Annex C code construction, F.1.2.1 DC
  * difference categories, F.1.2.2 RRRRSSSS with ZRL / EOB, the typical tables of Annex K.3.3 -- `chroma` selects
  * Tables K.4 / K.6 instead of K.3 / K.5).  One independently decodable segment per block row: the row is a

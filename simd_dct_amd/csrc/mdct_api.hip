@@ -243,6 +243,38 @@ int run_u8_i16(int mode, const void *from, void *to, uint8_t *px, int16_t *coef,
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "u8<->i16 kernel launch");
 }
 
+int run_u8_records(const uint8_t *px, size_t pitch_px, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts,
+                   void *stream)
+{
+  if (px == nullptr || levels == nullptr || runs == nullptr || counts == nullptr)
+    return fail(MDCT_INVALID_PARAMETER, "null pointer");
+  if (sizeX % 8 != 0 || sizeY % 8 != 0)
+    return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu is not a multiple of 8x8", sizeX, sizeY);
+  if (pitch_px < sizeX || by0 > by1 || by1 > sizeY / 8)
+    return fail(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows", by0, by1, sizeY / 8);
+  if (((uintptr_t)levels | (uintptr_t)runs) & 15)
+    return fail(MDCT_INVALID_PARAMETER, "levels and runs must be 16-byte aligned");
+  const mdct_device_info *di;
+  int r = current(&di);
+  if (r)
+    return r;
+  mdct::U8RecArgs a;
+  a.px = px;
+  a.levels = levels;
+  a.runs = runs;
+  a.counts = counts;
+  a.pitch_px = pitch_px;
+  a.bpr = (uint32_t)(sizeX / 8);
+  a.by0 = (uint32_t)by0;
+  if ((r = count_blocks(sizeX / 8, by1 - by0, &a.nblocks)))
+    return r;
+  if ((r = make_own_tables(lut, a.tb, /*pair_order=*/true)))
+    return r;
+  a.dc_shift = level_shift ? 64.0f * 128.0f : 0.0f;
+  const hipError_t e = mdct::launch_u8_records(a, (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "u8 -> records kernel launch");
+}
+
 int run_f32(int mode, const float *from, float *to, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
 {
   int r = own_plane_args(from, to, sizeof(float), pitch_in, pitch_out, sizeX, sizeY, by0, by1);
@@ -399,6 +431,11 @@ int mdct_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch
 int mdct_roundtrip_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
 {
   return run_i16(mdct::MODE_ROUNDTRIP, from, to, pitch_in, pitch_out, lut, sizeX, sizeY, by0, by1, stream);
+}
+
+int mdct_fwd_u8_records(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream)
+{
+  return run_u8_records(px, pitch, lut, level_shift, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
 }
 
 int mdct_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)

@@ -108,6 +108,19 @@ struct U8I16Args
   float px_lo, px_hi, px_magic; // inverse: clamp bounds and rounding constant (shift folded in)
 };
 
+struct U8RecArgs
+{ // pixels -> quantised coefficients -> zig-zag + run/level records in one pass (k_u8_records)
+  const uint8_t *px;
+  int16_t *levels; // [block][64]
+  uint8_t *runs;   // [block][64]
+  uint8_t *counts; // [block]
+  OwnTables tb;
+  DctConsts consts;
+  size_t pitch_px; // bytes
+  uint32_t bpr, by0, nblocks;
+  float dc_shift;  // 64*128 when level-shifting, else 0
+};
+
 struct F32Args
 {
   const float *from;
@@ -136,6 +149,7 @@ hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool sa
 hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s);
 hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s);
 hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s);
+hipError_t launch_u8_records(const U8RecArgs &a, hipStream_t s);
 hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s);
 hipError_t launch_stream_copy(const void *from, void *to, size_t bytes, int cus, hipStream_t s);
 

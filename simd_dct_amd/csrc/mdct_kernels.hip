@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "mdct_kernels.h"
+#include "scan_records.h"
 
 #pragma clang fp contract(off)
 
@@ -1071,6 +1072,58 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_
   (void)HAS_LUT;
 }
 
+// Pixels -> records in one pass (the encoder's front half): the forward transform and quantiser of
+// k_u8_i16<MODE_FWD>, then -- instead of storing the int16 plane and reading it back -- the zig-zag scan and
+// run/level compaction of k_scan (scan_records.h) on the values still in registers.  1 B/px in, 3 B/px out
+// (k_u8_i16 + k_scan move 3 + 5).  Bit for bit the records mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 produce.
+// One wave per workgroup: every wave works alone on 64 consecutive blocks (lane = block).
+__global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lv[64 * kLvRow];
+  __shared__ __attribute__((aligned(16))) uint8_t rn[64 * kRnRow];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t wave_t0 = blockIdx.x * 64; // first block of the wave within the launch
+  const uint32_t nvalid = min(64u, a.nblocks - wave_t0);
+  const bool valid = lane < nvalid;
+  const uint32_t t = wave_t0 + (valid ? lane : 0);
+  const uint32_t row = t / a.bpr, bx = t - row * a.bpr;
+  const DctConsts &C = a.consts;
+  const uint8_t *src = a.px + (size_t)(a.by0 + row) * 8 * a.pitch_px + (size_t)bx * 8;
+  uint2 rows[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    rows[r] = load8(src + (size_t)r * a.pitch_px);
+  // the forward transform on packed fp32 (aan_fwd_h / aan_fwd_v: the same individually rounded operations as raw_fwd);
+  // a.tb.qf is in the pair order of the column pass, (v*4 + j)*2 + {0,1} = coefficient (v, A[j]) / (v, B[j])
+  const AanPk &K = reinterpret_cast<const AanPk &>(C);
+  f32x2 P[4][8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    const f32x2 a01 = {ubyte_to_float<0>(rows[r].x), ubyte_to_float<1>(rows[r].x)}, a23 = {ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
+    const f32x2 a45 = {ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)}, a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
+    aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
+  }
+  int val[64];
+  constexpr int kA[4] = {0, 2, 5, 1}, kB[4] = {4, 6, 3, 7};
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    aan_fwd_v(K, P[j]);
+    if (j == 0)
+      P[0][0].x = P[0][0].x - a.dc_shift; // the level shift is exactly "raw DC minus 64 * 128"
+#pragma unroll
+    for (int v = 0; v < 8; v++)
+    { // the int16 the plane would have held (store_i16x8<0>), sign-extended
+      f32x2 m;
+      MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[v * 4 + j], MDCT_K_LH);
+      val[v * 8 + kA[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.x) & 0xFFFFu);
+      val[v * 8 + kB[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.y) & 0xFFFFu);
+    }
+  }
+  scan_emit<true>(val, lv, rn, lane, nvalid, valid, (size_t)a.by0 * a.bpr + wave_t0, a.levels, a.runs, a.counts);
+}
+
 // Several planes (each with its own table) in one launch: linear block index over the
 // concatenation of the planes; prefix[] is the exclusive scan of per-plane block counts.
 // LUTMODE: 0 no plane has a table, 1 every plane has one, 2 mixed (branch per wave)
@@ -1341,6 +1394,14 @@ hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s)
     hipLaunchKernelGGL((k_u8_i16<MODE_FWD, true>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
   else
     hipLaunchKernelGGL((k_u8_i16<MODE_INV, true>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_u8_records(const U8RecArgs &a, hipStream_t s)
+{
+  if (a.nblocks == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(k_u8_records, dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 

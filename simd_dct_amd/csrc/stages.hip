@@ -16,15 +16,12 @@
 #include <stdint.h>
 
 #include "mdct.h"
+#include "scan_records.h"
 
 extern "C" __attribute__((visibility("hidden"))) int mdct_set_error(int code, const char *fmt, ...); // mdct_api.hip
 
 namespace mdct
 {
-
-// ITU-T T.81 Figure A.6: natural index (v*8+u) of the k-th coefficient of the zig-zag scan
-constexpr int kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
-                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 enum { SRC_I16 = 0, SRC_Q32 = 1, SRC_STEREO = 2, SRC_BLOCK = 3 };
 
@@ -44,8 +41,6 @@ constexpr int kWG = 256;
 // k_scan: every wave works alone (wave-private LDS records), so the workgroup size only sets the LDS granule and the
 // dispatch rate; measured per source (profiles/r02_scan_workgroup_size.log)
 constexpr int scan_wg(int src) { return src == 1 || src == 2 ? 128 : 64; } // SRC_Q32, SRC_STEREO : SRC_I16, SRC_BLOCK
-constexpr int kLvRow = 144; // 64 int16 + 16 B: slot 64 (inside the pad) takes the writes of zero coefficients
-constexpr int kRnRow = 80;  // 64 u8 + 16 B, same trick
 constexpr int kQ32Grp = 520; // staged q32 group: 512 B + 8: a byte read of coefficient c touches banks 2g + 2c + {0,1}, distinct for the 8 groups
 
 template <int SRC, bool RLE>
@@ -135,70 +130,7 @@ __global__ __launch_bounds__(scan_wg(SRC)) void k_scan(ScanArgs a)
     }
   }
 
-  // ---- scan order; RLE: compact the non-zero levels to the front of the lane's record
-  uint8_t *my_lv = lv + lane * kLvRow;
-  uint32_t pos = 0;
-  if constexpr (RLE)
-  {
-    uint8_t *my_rn = rn + lane * kRnRow;
-    const u32x4 z = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < kLvRow / 16; i++)
-      *reinterpret_cast<u32x4 *>(my_lv + i * 16) = z;
-#pragma unroll
-    for (int i = 0; i < kRnRow / 16; i++)
-      *reinterpret_cast<u32x4 *>(my_rn + i * 16) = z;
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 0; k < 64; k++)
-    {
-      const int c = val[kZigZag[k]];
-      const bool nz = c != 0;
-      const uint32_t slot = nz ? pos : 64u; // zeros write into the pad
-      *reinterpret_cast<int16_t *>(my_lv + slot * 2) = (int16_t)c;
-      my_rn[slot] = (uint8_t)run;
-      pos += nz ? 1u : 0u;
-      run = nz ? 0u : run + 1u;
-    }
-  }
-  else
-  {
-#pragma unroll
-    for (int k = 0; k < 64; k += 2)
-      *reinterpret_cast<uint32_t *>(my_lv + k * 2) = ((uint32_t)val[kZigZag[k]] & 0xFFFFu) | ((uint32_t)val[kZigZag[k + 1]] << 16);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // ---- records out: the wave's 64 x 128 B of levels (and 64 x 64 B of runs) are contiguous; 16 B per lane per store
-  uint8_t *out_lv = reinterpret_cast<uint8_t *>(a.levels) + blk0 * 128;
-#pragma unroll
-  for (int j = 0; j < 8; j++)
-  {
-    const uint32_t b = j * 8 + (lane >> 3);
-    if (b < nvalid)
-    {
-      const u32x4 w = *reinterpret_cast<const u32x4 *>(lv + b * kLvRow + (lane & 7) * 16);
-      __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(out_lv + (j * 64 + lane) * 16));
-    }
-  }
-  if constexpr (RLE)
-  {
-    uint8_t *out_rn = a.runs + blk0 * 64;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-    {
-      const uint32_t b = j * 16 + (lane >> 2);
-      if (b < nvalid)
-      {
-        const u32x4 w = *reinterpret_cast<const u32x4 *>(rn + b * kRnRow + (lane & 3) * 16);
-        __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(out_rn + (j * 64 + lane) * 16));
-      }
-    }
-    if (valid)
-      a.counts[blk0 + lane] = (uint8_t)pos;
-  }
+  scan_emit<RLE>(val, lv, rn, lane, nvalid, valid, blk0, a.levels, a.runs, a.counts);
 }
 
 struct SplitArgs

@@ -273,6 +273,11 @@ def zigzag_rle(kind, src, W, H, rle=True, by0=0, by1=None, pitch=None, fill=0):
     return levels, runs, counts
 
 
+def u8_records(img, W, H, lut=None, level_shift=True):
+    """the checker's composition mdct_fwd_u8_records must equal: pixels -> int16 coefficients -> run/level records"""
+    return zigzag_rle("i16", u8_i16("fwd", img, W, H, lut=lut, level_shift=level_shift), W, H)
+
+
 def split420(ycc, W, H):
     ycc = np.ascontiguousarray(ycc, dtype=np.uint8)
     y = np.zeros((H, W), dtype=np.int16)

@@ -115,6 +115,11 @@ def test_stage_argument_checks_without_device():
     assert api.zigzag_rle_i16(a, 64, 16, lv, rn, None, check=False) == 1      # runs without counts
     assert api.zigzag_rle_i16(a, 64, 16, lv, rn, ct, by1=3, check=False) == 1  # range beyond the plane
     assert api.zigzag_rle_q32(a.view(np.uint8), 56, 16, lv, check=False) == 2  # q32 needs sizeX % 64
+    px = np.zeros((16, 64), dtype=np.uint8)
+    assert api.fwd_u8_records(px, 64, 16, lv, rn, None, check=False) == 1
+    assert api.fwd_u8_records(px, 60, 16, lv, rn, ct, check=False) == 2
+    assert api.fwd_u8_records(px, 64, 16, lv, rn, ct, pitch=32, check=False) == 1
+    assert api.fwd_u8_records(px, 64, 16, lv, rn, ct, by1=3, check=False) == 1
     ycc = np.zeros((16, 16, 3), dtype=np.uint8)
     y = np.zeros((16, 16), dtype=np.int16)
     c = np.zeros((8, 8), dtype=np.int16)
@@ -167,6 +172,61 @@ def test_scan_and_rle_match_the_checker():
                 assert np.array_equal(lv.cpu().numpy(), want[0]), (W, H, rle)
                 if rle:
                     assert np.array_equal(rn.cpu().numpy(), want[1]) and np.array_equal(ct.cpu().numpy(), want[2])
+
+
+@pytest.mark.gpu
+def test_fused_pixels_to_records_equals_the_two_stage_path():
+    """mdct_fwd_u8_records == mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 == the checker's composition, bit for bit: one lane,
+    partial waves, pitched and unaligned pixel planes, no table / no level shift, sub-ranges leaving the rest alone, 8192^2"""
+    api.init(0)
+    K1 = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                   18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+    for (W, H, pitch) in ((8, 8, 8), (64, 24, 64), (200, 40, 203), (1000, 16, 1024), (2048, 64, 2048)):
+        nblk = (W // 8) * (H // 8)
+        for kind, lut, shift in (("photo", K1, True), ("noise", None, True), ("photo", (K1 / 8).astype(np.float32), False)):
+            wide = synth.plane_u8_np(pitch, H + 1, kind, seed=W + H)
+            img = np.ascontiguousarray(wide[:H, :W])
+            d_wide = _dev(wide.reshape(-1)[1:])  # an odd base address: no alignment requirement on the pixel plane
+            want = O.u8_records(wide.reshape(-1)[1:1 + pitch * H].reshape(H, pitch)[:, :W], W, H, lut=lut, level_shift=shift)
+            lv = torch.full((nblk, 64), 0x5A5A, dtype=torch.int16, device="cuda")
+            rn = torch.full((nblk, 64), 0x5A, dtype=torch.uint8, device="cuda")
+            ct = torch.full((nblk,), 0x5A, dtype=torch.uint8, device="cuda")
+            api.fwd_u8_records(d_wide, W, H, lv, rn, ct, lut=lut, level_shift=shift, pitch=pitch)
+            for got, w in zip((lv, rn, ct), want):
+                assert np.array_equal(got.cpu().numpy(), w), (W, H, kind)
+            # the two-stage path on the device gives the same records
+            src = _dev(wide.reshape(-1)[1:1 + pitch * H].reshape(H, pitch)[:, :W])
+            coef = torch.empty((H, W), dtype=torch.int16, device="cuda")
+            lv2, rn2, ct2 = torch.empty_like(lv), torch.empty_like(rn), torch.empty_like(ct)
+            api.fwd_u8_i16(src, coef, W, H, lut=lut, level_shift=shift)
+            api.zigzag_rle_i16(coef, W, H, lv2, rn2, ct2)
+            assert torch.equal(lv, lv2) and torch.equal(rn, rn2) and torch.equal(ct, ct2)
+            del img
+    assert api.fwd_u8_records(_dev(np.zeros((16, 64), dtype=np.uint8)), 64, 16, lv, rn, ct, lut=np.zeros(64, dtype=np.float32), check=False) == 1  # a zero table entry
+    # a sub-range writes its own records only
+    W, H = 512, 64
+    bpr = W // 8
+    img = synth.plane_u8_np(W, H, "photo", seed=5)
+    want = O.u8_records(img, W, H, lut=K1)
+    lv = torch.full(((W // 8) * (H // 8), 64), 0x5A5A, dtype=torch.int16, device="cuda")
+    rn = torch.full(((W // 8) * (H // 8), 64), 0x5A, dtype=torch.uint8, device="cuda")
+    ct = torch.full(((W // 8) * (H // 8),), 0x5A, dtype=torch.uint8, device="cuda")
+    api.fwd_u8_records(_dev(img), W, H, lv, rn, ct, lut=K1, by0=2, by1=5)
+    g = [t.cpu().numpy() for t in (lv, rn, ct)]
+    for got, w, canary in zip(g, want, (0x5A5A, 0x5A, 0x5A)):
+        assert np.array_equal(got[2 * bpr:5 * bpr], w[2 * bpr:5 * bpr])
+        assert (got[:2 * bpr] == canary).all() and (got[5 * bpr:] == canary).all()
+    # full size: against the two-stage device path (itself checked against the oracle at this size elsewhere)
+    W = H = 8192
+    img = synth.plane_u8_torch(W, H, "photo")
+    nblk = (W // 8) * (H // 8)
+    coef = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    rec = [(torch.empty((nblk, 64), dtype=torch.int16, device="cuda"), torch.empty((nblk, 64), dtype=torch.uint8, device="cuda"), torch.empty((nblk,), dtype=torch.uint8, device="cuda")) for _ in range(2)]
+    api.fwd_u8_records(img, W, H, *rec[0], lut=K1)
+    api.fwd_u8_i16(img, coef, W, H, lut=K1)
+    api.zigzag_rle_i16(coef, W, H, *rec[1])
+    for a, b in zip(*rec):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.gpu

@@ -1,6 +1,7 @@
 """Example: a baseline JPEG written by the engine's stages (tools/ = not part of the product path).
     python3 tools/gpu_jpeg.py out.jpg [raw_grey_file X Y | synthetic X Y]
-pixels -> mdct_fwd_u8_i16 (Annex K.1 table) -> mdct_zigzag_rle_i16 -> mdct_huffman_rows -> simd_dct_amd.jfif.write_jpeg"""
+pixels -> mdct_fwd_u8_records (Annex K.1 table; = mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 in one pass) -> mdct_huffman_rows
+-> simd_dct_amd.jfif.write_jpeg"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,7 +16,6 @@ W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (4096, 216
 M.init(0)
 img = synth.plane_u8_torch(W, H, "photo") if src == "synthetic" else torch.from_numpy(np.fromfile(src, dtype=np.uint8)[: W * H].reshape(H, W)).cuda()
 nblk = (W // 8) * (H // 8)
-coef = torch.empty((H, W), dtype=torch.int16, device="cuda")
 lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
 rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
 ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
@@ -24,10 +24,9 @@ seg = torch.empty(((H // 8) * stride,), dtype=torch.uint8, device="cuda")
 nb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    M.fwd_u8_i16(img, coef, W, H, lut=K1)
-    M.zigzag_rle_i16(coef, W, H, lv, rn, ct)
+    M.fwd_u8_records(img, W, H, lv, rn, ct, lut=K1)
     M.huffman_rows(lv, rn, ct, W, H, seg, nb)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 data = jfif.write_jpeg([dict(segments=seg.cpu().numpy(), seg_bytes=nb.cpu().numpy(), seg_stride=stride, blocks_per_row=W // 8, qtable=K1)], W, H)
 open(out, "wb").write(data)
-print(f"{W}x{H}: three device stages {dt * 1e6:.0f} us ({W * H / dt / 1e6:.0f} Mpx/s), file {len(data)} bytes ({8 * len(data) / (W * H):.2f} bit/px) -> {out}")
+print(f"{W}x{H}: two device stages {dt * 1e6:.0f} us ({W * H / dt / 1e6:.0f} Mpx/s), file {len(data)} bytes ({8 * len(data) / (W * H):.2f} bit/px) -> {out}")
