@@ -799,6 +799,26 @@ def test_soak_random_differential():
         assert np.array_equal(fo.cpu().numpy(), O.f32("fwd", f, W2, H2))
         M.inv_f32(dev(f), fo, W2, H2)
         assert np.array_equal(fo.cpu().numpy(), O.f32("inv", f, W2, H2))
+        # the stages after the transform: fused pixels -> records, records of an arbitrary coefficient plane, Huffman rows of both
+        nblk = (W2 // 8) * (H2 // 8)
+        sparse = (src * (rng.random((H2, W2)) < rng.choice([0.02, 0.2, 0.9]))).astype(np.int16)
+        for recs_want, make in ((O.u8_records(px, W2, H2, lut=table, level_shift=bool(it & 1)), lambda l, r, c: M.fwd_u8_records(dev(px), W2, H2, l, r, c, lut=table, level_shift=bool(it & 1))),
+                                (O.zigzag_rle("i16", sparse, W2, H2), lambda l, r, c: M.zigzag_rle_i16(dev(sparse), W2, H2, l, r, c))):
+            lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
+            rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
+            ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
+            make(lv, rn, ct)
+            for got, want in zip((lv, rn, ct), recs_want):
+                assert np.array_equal(got.cpu().numpy(), want), (it, W2, H2)
+            stride = M.huffman_seg_stride(W2)
+            seg = torch.zeros(((H2 // 8) * stride,), dtype=torch.uint8, device="cuda")
+            nb = torch.zeros((H2 // 8,), dtype=torch.int32, device="cuda")
+            M.huffman_rows(lv, rn, ct, W2, H2, seg, nb, chroma=bool(it & 2))
+            ws, wn, _ = O.huffman_rows(*recs_want, W2, H2, chroma=bool(it & 2))
+            gs = seg.cpu().numpy()
+            assert np.array_equal(nb.cpu().numpy().astype(np.uint32), wn), (it, W2, H2)
+            for r in range(H2 // 8):
+                assert np.array_equal(gs[r * stride:r * stride + wn[r]], ws[r * stride:r * stride + wn[r]]), (it, W2, H2, r)
 
 
 RELINKED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "simd_dct_relinked")
