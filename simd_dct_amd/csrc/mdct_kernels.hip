@@ -476,6 +476,23 @@ __device__ __forceinline__ uint32_t pack4_lo8(uint32_t a, uint32_t b, uint32_t c
 }
 
 constexpr int kWG = 256;           // 4 waves
+#ifndef MDCT_XCD_SWIZZLE
+#define MDCT_XCD_SWIZZLE 0
+#endif
+// Workgroup index of the launch.  Hardware hands consecutive workgroups to the 8 XCDs round-robin, so with the plain
+// linear order the 8 XCDs stream through neighbouring tiles (the same DRAM pages) at any moment; MDCT_XCD_SWIZZLE=1
+// gives every XCD one contiguous eighth of the plane instead.  Measured (profiles/r02_xcd_mapping.log): the linear order
+// is faster for every single plane (8192^2: copy 42.9 vs 51.5 us, round trip 46.8 vs 50.7, q32 31.0 vs 31.7); only the
+// 17 GB batch of config 4 gains 2 % from the swizzle.  These kernels have no reuse for an XCD's L2 to keep: linear it is.
+__device__ __forceinline__ uint32_t wg_index()
+{
+#if MDCT_XCD_SWIZZLE
+  const uint32_t w = blockIdx.x, per = gridDim.x >> 3;
+  return w < per * 8 ? (w & 7) * per + (w >> 3) : w;
+#else
+  return blockIdx.x;
+#endif
+}
 constexpr int kQ32RowStride = 72;  // 64 lanes + 8 pad: keeps rows 8-byte aligned for ds_read_b64
 constexpr int kStereoRowStride = kWG + 16; // 256 blocks + pad, rows stay 16-byte aligned for ds_read_b128
 
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(kWG, (SAFE || GENERAL) ? 1 : MDCT_Q32_MINW) void k_
   __shared__ __attribute__((aligned(16))) uint8_t lds[kWG / 64][64 * kQ32RowStride];
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t wave_t0 = blockIdx.x * kWG + wave * 64; // first block of this wave within the launch
+  const uint32_t wave_t0 = wg_index() * kWG + wave * 64; // first block of this wave within the launch
   if (wave_t0 >= a.nblocks) // whole waves past the end of the launch (the grid is in workgroups of 4 waves)
     return;
   uint32_t wave_blocks = 64, t = wave_t0 + lane;
@@ -579,7 +596,7 @@ constexpr int u8_waves_hi(int profile, int layout) { return layout == MDCT_LAYOU
 template <int PROFILE, int LAYOUT, bool SAFE>
 __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
 {
-  const uint32_t t = blockIdx.x * kWG + threadIdx.x; // linear block index within the launch
+  const uint32_t t = wg_index() * kWG + threadIdx.x; // linear block index within the launch
   const bool valid = t < a.nblocks;
 
   // block coordinates.  STEREO enumerates (block row, eye, block x): simd_dct.cpp:1089-1099.
@@ -625,7 +642,7 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
     // (:1061-1099), so a full workgroup owns 256 consecutive bytes per plane.  Stage them in LDS
     // as [coef][block] and store 16 B per lane (4 wide stores instead of 64 byte stores per lane).
     __shared__ __attribute__((aligned(16))) uint8_t slds[64 * kStereoRowStride];
-    const uint32_t wg_t0 = blockIdx.x * kWG;
+    const uint32_t wg_t0 = wg_index() * kWG;
     const bool full_wg = wg_t0 + kWG <= a.nblocks; // workgroup-uniform
     if (full_wg)
     {
@@ -988,7 +1005,7 @@ constexpr int i16_waves(int mode) { return mode == MODE_ROUNDTRIP ? 3 : (mode ==
 template <int MODE, bool HAS_LUT>
 __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(MODE), i16_waves(MODE)))) void k_i16(I16Args a)
 {
-  const uint32_t t = blockIdx.x * kWG + threadIdx.x;
+  const uint32_t t = wg_index() * kWG + threadIdx.x;
   if (t >= a.nblocks)
     return;
   const uint32_t row = t / a.bpr;
@@ -1013,7 +1030,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
 template <int MODE, bool HAS_LUT>
 __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_WAVES, MDCT_U8I16_WAVES))) void k_u8_i16(U8I16Args a)
 {
-  const uint32_t t = blockIdx.x * kWG + threadIdx.x;
+  const uint32_t t = wg_index() * kWG + threadIdx.x;
   if (t >= a.nblocks)
     return;
   const uint32_t row = t / a.bpr;
@@ -1133,7 +1150,7 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
 template <int LUTMODE>
 __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_PLANES_WAVES, MDCT_PLANES_WAVES))) void k_i16_planes(PlaneBatchArgs a)
 {
-  const uint32_t t = blockIdx.x * kWG + threadIdx.x;
+  const uint32_t t = wg_index() * kWG + threadIdx.x;
   // plane index from the wave's first block: wave-uniform, so the table reads stay scalar
   const uint32_t tw = __builtin_amdgcn_readfirstlane(t - (threadIdx.x & 63));
   if (tw >= a.prefix[a.n])
@@ -1188,7 +1205,7 @@ __device__ __forceinline__ float swap_pair(float v)
 template <int MODE, bool WIDE>
 __global__ __launch_bounds__(kWG) MDCT_F32_ATTR void k_f32(F32Args a)
 {
-  const uint32_t t = blockIdx.x * kWG + threadIdx.x;
+  const uint32_t t = wg_index() * kWG + threadIdx.x;
   if (t >= a.nblocks)
     return;
   const DctConsts &C = a.consts;
@@ -1283,7 +1300,7 @@ __global__ __launch_bounds__(kWG) MDCT_F32_ATTR void k_f32(F32Args a)
 constexpr int kCopyUnroll = 8;
 __global__ __launch_bounds__(kWG) void k_stream_copy(const u32x4 *__restrict__ from, u32x4 *__restrict__ to, size_t n16)
 {
-  const size_t base = (size_t)blockIdx.x * kWG * kCopyUnroll + threadIdx.x;
+  const size_t base = (size_t)wg_index() * kWG * kCopyUnroll + threadIdx.x;
   u32x4 v[kCopyUnroll];
   if (base + (size_t)(kCopyUnroll - 1) * kWG < n16)
   {

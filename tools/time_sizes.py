@@ -7,7 +7,7 @@ from simd_dct_amd import synth
 M.init(0)
 lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
 t = M.Timer()
-for W in (2048, 4096, 8192, 16384):
+for W in (2048, 4096, 8192, 16384, 32768):
     H = W
     n = 4 if W <= 8192 else 2
     i16 = [synth.plane_i16_torch(W, H, "photo", seed=i) for i in range(n)]
