@@ -192,6 +192,14 @@ int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t 
                       size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, void *stream);
 /* smallest legal seg_stride for a plane sizeX wide: 208 * (sizeX/8) + 8 (host function) */
 size_t mdct_huffman_seg_stride(size_t sizeX);
+/* The row segments -> one contiguous scan, ready to follow an SOS header: every row byte-stuffed (B.1.1.5: a zero
+ * byte after each 0xFF) and, between consecutive rows, the restart marker FF D0+m with m = (first_rst + row) mod 8
+ * (E.1.4; first_rst = 0 for a scan that starts at the image's first row).  row_offsets: n_rows + 1 device uint64;
+ * on completion row_offsets[r] is where row r starts in `out` and row_offsets[n_rows] the total length.  A row
+ * that would end beyond out_capacity is not written: compare row_offsets[n_rows] with the capacity.
+ * (n_rows * seg_stride * 2 always suffices; in practice the total is ~0.2 bytes per pixel.) */
+int mdct_jpeg_pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, size_t seg_stride, size_t n_rows, int first_rst,
+                        uint8_t *out, size_t out_capacity, uint64_t *row_offsets, void *stream);
 /* BITS (16 counts) and HUFFVAL of the table as a DHT marker segment carries them (host function).
  * which: 0 DC luminance (K.3), 1 AC luminance (K.5), 2 DC chrominance (K.4), 3 AC chrominance (K.6). */
 int mdct_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals);

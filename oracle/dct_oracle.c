@@ -1039,3 +1039,40 @@ int orc_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *
   }
   return 0;
 }
+
+/* the row segments -> one stuffed scan with RSTm between the rows (ITU-T T.81 B.1.1.5, E.1.4); checker of
+ * mdct_jpeg_pack_rows.  A row that would end beyond `capacity` is not written. */
+int orc_jpeg_pack_rows(const uint8_t *seg, const uint32_t *seg_bytes, size_t seg_stride, size_t n_rows, int first_rst, uint8_t *out, size_t capacity, uint64_t *row_off)
+{
+  if (!seg || !seg_bytes || !out || !row_off)
+    return 1;
+  uint64_t pos = 0;
+  for (size_t r = 0; r < n_rows; r++)
+  {
+    const uint8_t *p = seg + r * seg_stride;
+    uint64_t len = seg_bytes[r];
+    for (uint32_t i = 0; i < seg_bytes[r]; i++)
+      len += p[i] == 0xFF;
+    if (r + 1 < n_rows)
+      len += 2;
+    row_off[r] = pos;
+    if (pos + len <= capacity)
+    {
+      uint8_t *o = out + pos;
+      for (uint32_t i = 0; i < seg_bytes[r]; i++)
+      {
+        *o++ = p[i];
+        if (p[i] == 0xFF)
+          *o++ = 0;
+      }
+      if (r + 1 < n_rows)
+      {
+        *o++ = 0xFF;
+        *o++ = (uint8_t)(0xD0 + ((first_rst + r) & 7));
+      }
+    }
+    pos += len;
+  }
+  row_off[n_rows] = pos;
+  return 0;
+}

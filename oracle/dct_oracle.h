@@ -106,6 +106,7 @@ int orc_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals);
 void orc_huffman_tables(int chroma, uint32_t *dc256, uint32_t *ac256);
 int orc_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *counts, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
                      int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes);
+int orc_jpeg_pack_rows(const uint8_t *seg, const uint32_t *seg_bytes, size_t seg_stride, size_t n_rows, int first_rst, uint8_t *out, size_t capacity, uint64_t *row_off);
 int orc_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr,
                     size_t pitch_y, size_t pitch_c);
 

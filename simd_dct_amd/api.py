@@ -272,6 +272,15 @@ def huffman_rows(levels, runs, counts, sizeX, sizeY, out, seg_bytes, seg_stride=
     return rc
 
 
+def jpeg_pack_rows(segments, seg_bytes, seg_stride, n_rows, out, row_offsets, first_rst=0, out_capacity=None, stream=None, check=True):
+    """row segments of huffman_rows -> one stuffed scan with RSTm between the rows (mdct_jpeg_pack_rows); row_offsets: n_rows + 1 int64"""
+    cap = out.numel() * out.element_size() if out_capacity is None and hasattr(out, "numel") else (out.nbytes if out_capacity is None else out_capacity)
+    rc = _lib.load().mdct_jpeg_pack_rows(_ptr(segments), _ptr(seg_bytes), seg_stride, n_rows, first_rst, _ptr(out), cap, _ptr(row_offsets), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
 def split420_u8(ycc, sizeX, sizeY, y, cb, cr, pitch=None, pitch_y=None, pitch_c=None, stream=None, check=True):
     """interleaved 8-bit Y Cb Cr -> level-shifted int16 Y (full) and Cb / Cr (2x2 box average) planes"""
     rc = _lib.load().mdct_split420_u8(_ptr(ycc), 3 * sizeX if pitch is None else pitch, sizeX, sizeY, _ptr(y), _ptr(cb), _ptr(cr),

@@ -484,6 +484,154 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// k_pack_*: the row segments of k_huffman_rows -> one contiguous, decodable scan (ITU-T T.81 B.1.1.5: a zero byte
+// after every 0xFF of entropy-coded data; E.1.4 / B.2.1: RSTm, m = 0..7 cyclic, between the restart intervals).
+// Three small launches: stuffed length of every row, exclusive scan over the rows, the copy.  The data is ~0.15 B/px.
+// ---------------------------------------------------------------------------------------
+struct PackArgs
+{
+  const uint8_t *seg;
+  const uint32_t *seg_bytes;
+  size_t seg_stride;
+  uint8_t *out;
+  unsigned long long capacity;
+  unsigned long long *row_off; // [n_rows + 1]: k_pack_count leaves the lengths here, k_pack_scan turns them into offsets
+  uint32_t n_rows, first_rst;
+};
+
+// 0x80 in every byte of w that equals 0xFF (exact: no carries between bytes)
+__device__ __forceinline__ uint32_t ff_bytes(uint32_t w)
+{
+  const uint32_t t = ~w; // a zero byte of t is an 0xFF byte of w
+  return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+}
+
+// sum over the 256 threads of the workgroup (returned to all) and the exclusive prefix of this thread
+__device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t *wave_tot /* LDS [4] */, uint32_t &total)
+{
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    const uint32_t u = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d)
+      incl += u;
+  }
+  __syncthreads(); // the previous use of wave_tot is over
+  if (lane == 63)
+    wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 4; w++)
+  {
+    const uint32_t t = wave_tot[w];
+    before += w < wave ? t : 0;
+    total += t;
+  }
+  return before + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_pack_count(PackArgs a)
+{
+  __shared__ uint32_t wave_tot[4];
+  const uint32_t r = blockIdx.x, nb = a.seg_bytes[r];
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(a.seg + (size_t)r * a.seg_stride);
+  uint32_t ff = 0;
+  for (uint32_t i = threadIdx.x * 4; i < nb; i += 1024)
+  {
+    uint32_t m = ff_bytes(p[i >> 2]);
+    if (nb - i < 4)
+      m &= (1u << (8 * (nb - i))) - 1u; // the bytes past the row's end are not data
+    ff += (uint32_t)__builtin_popcount(m);
+  }
+  uint32_t total;
+  (void)wg_scan256(ff, wave_tot, total);
+  if (threadIdx.x == 0)
+    a.row_off[r] = (unsigned long long)nb + total + (r + 1 < a.n_rows ? 2u : 0u);
+}
+
+__global__ __launch_bounds__(256) void k_pack_scan(PackArgs a)
+{ // one workgroup: lengths -> exclusive offsets, row_off[n_rows] = total
+  __shared__ unsigned long long wave_tot[4];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long carry = 0;
+  for (uint32_t c0 = 0; c0 < a.n_rows; c0 += 256)
+  {
+    const uint32_t i = c0 + threadIdx.x;
+    const unsigned long long v = i < a.n_rows ? a.row_off[i] : 0ull;
+    unsigned long long incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const unsigned long long u = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d)
+        incl += u;
+    }
+    __syncthreads();
+    if (lane == 63)
+      wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned long long before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++)
+    {
+      const unsigned long long t = wave_tot[w];
+      before += w < wave ? t : 0ull;
+      total += t;
+    }
+    if (i < a.n_rows)
+      a.row_off[i] = carry + before + incl - v;
+    carry += total;
+  }
+  if (threadIdx.x == 0)
+    a.row_off[a.n_rows] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_pack_write(PackArgs a)
+{
+  __shared__ uint32_t wave_tot[4];
+  const uint32_t r = blockIdx.x, nb = a.seg_bytes[r];
+  const unsigned long long base = a.row_off[r], end = a.row_off[r + 1];
+  if (end > a.capacity)
+    return; // does not fit: the caller sees row_off[n_rows] > capacity
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(a.seg + (size_t)r * a.seg_stride);
+  uint8_t *out = a.out + base;
+  uint32_t done = 0; // bytes of this row already written
+  for (uint32_t c0 = 0; c0 < nb; c0 += 1024)
+  {
+    const uint32_t i = c0 + threadIdx.x * 4;
+    uint32_t w = 0, nvalid = 0;
+    if (i < nb)
+    {
+      w = p[i >> 2];
+      nvalid = min(4u, nb - i);
+    }
+    uint32_t m = ff_bytes(w);
+    if (nvalid < 4)
+      m &= (1u << (8 * nvalid)) - 1u;
+    const uint32_t mine = nvalid + (uint32_t)__builtin_popcount(m);
+    uint32_t total;
+    uint32_t pos = done + wg_scan256(mine, wave_tot, total);
+    for (uint32_t k = 0; k < nvalid; k++)
+    {
+      const uint32_t b = (w >> (8 * k)) & 0xFFu;
+      out[pos++] = (uint8_t)b;
+      if (b == 0xFFu)
+        out[pos++] = 0;
+    }
+    done += total;
+  }
+  if (threadIdx.x == 0 && r + 1 < a.n_rows)
+  {
+    out[done] = 0xFF;
+    out[done + 1] = (uint8_t)(0xD0 + ((a.first_rst + r) & 7));
+  }
+}
+
 } // namespace mdct
 
 namespace
@@ -654,6 +802,34 @@ int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t 
   hipLaunchKernelGGL(mdct::k_huffman_rows, dim3((uint32_t)(by1 - by0)), dim3(mdct::kHuffChunk), 0, (hipStream_t)stream, a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? MDCT_SUCCESS : mdct_set_error(MDCT_NOT_SUPPORTED, "huffman kernel launch: %s", hipGetErrorString(e));
+}
+
+int mdct_jpeg_pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, size_t seg_stride, size_t n_rows, int first_rst, uint8_t *out, size_t out_capacity, uint64_t *row_offsets,
+                        void *stream)
+{
+  if (!segments || !seg_bytes || !out || !row_offsets)
+    return mdct_set_error(MDCT_INVALID_PARAMETER, "null pointer");
+  if (seg_stride % 4 != 0 || ((uintptr_t)segments & 3) || ((uintptr_t)row_offsets & 7))
+    return mdct_set_error(MDCT_INVALID_PARAMETER, "segments 4-byte aligned with a stride that is a multiple of 4; row_offsets 8-byte aligned");
+  if (n_rows > 0x7FFFFFFFull || first_rst < 0 || first_rst > 7)
+    return mdct_set_error(MDCT_INVALID_PARAMETER, "more than 2^31 rows, or first_rst outside 0..7");
+  mdct::PackArgs a;
+  a.seg = segments;
+  a.seg_bytes = seg_bytes;
+  a.seg_stride = seg_stride;
+  a.out = out;
+  a.capacity = out_capacity;
+  a.row_off = reinterpret_cast<unsigned long long *>(row_offsets);
+  a.n_rows = (uint32_t)n_rows;
+  a.first_rst = (uint32_t)first_rst;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_rows)
+    hipLaunchKernelGGL(mdct::k_pack_count, dim3(a.n_rows), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(mdct::k_pack_scan, dim3(1), dim3(256), 0, s, a);
+  if (n_rows)
+    hipLaunchKernelGGL(mdct::k_pack_write, dim3(a.n_rows), dim3(256), 0, s, a);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MDCT_SUCCESS : mdct_set_error(MDCT_NOT_SUPPORTED, "pack kernel launch: %s", hipGetErrorString(e));
 }
 
 int mdct_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr, size_t pitch_y, size_t pitch_c, void *stream)

@@ -44,8 +44,9 @@ def scan_bytes(segments, seg_bytes, seg_stride):
 
 def write_jpeg(components, width, height, specs=None):
     """components: list of 1 (grey) or 3 (Y, Cb, Cr with Cb/Cr at half resolution) dicts with keys
-         'segments' (uint8 array / bytes), 'seg_bytes' (per block row), 'seg_stride', 'blocks_per_row',
-         'qtable' (64 integers 1..255, natural order v*8+u)
+         'blocks_per_row', 'qtable' (64 integers 1..255, natural order v*8+u) and either
+         'scan' (bytes / uint8 array: the stuffed, RST-delimited scan as mdct_jpeg_pack_rows leaves it) or
+         'segments' (uint8 array / bytes), 'seg_bytes' (per block row), 'seg_stride' (stuffed and joined here)
        specs: {which: (bits16, vals)} Huffman specifications (default: the library's, api.huffman_spec)
        Returns the file as bytes."""
     specs = specs or {w: api.huffman_spec(w) for w in range(4)}
@@ -69,6 +70,6 @@ def write_jpeg(components, width, height, specs=None):
         f.append(_seg(0xDD, struct.pack(">H", c["blocks_per_row"])))
         th = 0 if ci == 0 else 1
         f.append(_seg(0xDA, bytes([1, ci + 1, (th << 4) | th, 0, 63, 0])))
-        f.append(scan_bytes(c["segments"], c["seg_bytes"], c["seg_stride"]))
+        f.append(bytes(memoryview(np.ascontiguousarray(c["scan"]))) if "scan" in c else scan_bytes(c["segments"], c["seg_bytes"], c["seg_stride"]))
     f.append(b"\xff\xd9")
     return b"".join(f)

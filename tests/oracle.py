@@ -45,6 +45,7 @@ def oracle():
         lib.orc_zigzag_rle_q32.argtypes = [vp, sz, sz, sz, sz, vp, vp, vp]
         lib.orc_zigzag_rle_u8.argtypes = [vp, ctypes.c_int, sz, sz, sz, sz, vp, vp, vp]
         lib.orc_huffman_rows.argtypes = [vp, vp, vp, sz, sz, sz, sz, ctypes.c_int, vp, sz, vp]
+        lib.orc_jpeg_pack_rows.argtypes = [vp, vp, sz, sz, ctypes.c_int, vp, sz, vp]
         lib.orc_huffman_spec.argtypes = [ctypes.c_int, vp, vp, vp]
         lib.orc_split420_u8.argtypes = [vp, sz, sz, sz, vp, vp, vp, sz, sz]
         lib.orc_dct8.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_int]
@@ -305,3 +306,16 @@ def huffman_rows(levels, runs, counts, W, H, chroma=False, by0=0, by1=None, fill
                                    seg.ctypes.data, stride, nb.ctypes.data)
     assert rc == 0, rc
     return seg, nb, stride
+
+
+def jpeg_pack_rows(seg, seg_bytes, stride, first_rst=0, capacity=None, fill=0):
+    """-> (out uint8 [capacity], row_off uint64 [n_rows + 1])"""
+    seg = np.ascontiguousarray(seg, dtype=np.uint8)
+    nb = np.ascontiguousarray(seg_bytes, dtype=np.uint32)
+    n = len(nb)
+    capacity = 2 * int(nb.sum()) + 2 * n if capacity is None else capacity
+    out = np.full(capacity, fill, dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    rc = oracle().orc_jpeg_pack_rows(seg.ctypes.data, nb.ctypes.data, stride, n, first_rst, out.ctypes.data, capacity, off.ctypes.data)
+    assert rc == 0, rc
+    return out, off

@@ -258,3 +258,65 @@ def test_encoder_stages_replay_from_one_hip_graph():
         api.inv_i16_u8(coef, own, W, H, lut=K1_LUMA)
         assert np.abs(dec.astype(int) - own.cpu().numpy().astype(int)).max() <= 1, seed
         assert np.abs(dec.astype(int) - pic.astype(int)).mean() < 16  # and it is this picture (whose +-24 noise K.1 quantises away)
+
+
+def test_pack_checker_equals_the_host_writer():
+    """orc_jpeg_pack_rows == jfif.scan_bytes (numpy) on segments full of 0xFF bytes, empty rows, a capacity that cuts the scan short"""
+    rng = np.random.default_rng(9)
+    stride, n = 408, 13
+    nb = rng.integers(0, stride - 8, n).astype(np.uint32)
+    nb[3] = 0
+    seg = rng.integers(0, 256, n * stride).astype(np.uint8)
+    seg[rng.random(n * stride) < 0.3] = 0xFF
+    out, off = O.jpeg_pack_rows(seg, nb, stride)
+    want = jfif.scan_bytes(seg, nb, stride)
+    assert int(off[n]) == len(want) and out[: len(want)].tobytes() == want
+    assert np.array_equal(np.diff(off.astype(np.int64))[:-1], [len(jfif.stuff(seg[r * stride:r * stride + nb[r]])) + 2 for r in range(n - 1)])
+    cut = int(off[7]) + 5  # rows 0..6 fit, row 7 does not
+    out2, off2 = O.jpeg_pack_rows(seg, nb, stride, capacity=cut, fill=0x77)
+    assert np.array_equal(off2, off) and out2[: int(off[7])].tobytes() == want[: int(off[7])] and (out2[int(off[7]):] == 0x77).all()
+    out3, off3 = O.jpeg_pack_rows(seg, nb, stride, first_rst=5)
+    assert out3[int(off[1]) - 2: int(off[1])].tolist() == [0xFF, 0xD5] and out3[int(off[4]) - 2: int(off[4])].tolist() == [0xFF, 0xD0]
+
+
+@pytest.mark.gpu
+def test_device_packed_scan_is_the_file_libjpeg_opens():
+    """mdct_jpeg_pack_rows: byte-equal to the checker (random segments incl. all-0xFF and empty rows, capacity cut, first_rst), and a grey
+    JPEG whose scan was stuffed and joined on the device decodes like the one stuffed on the host"""
+    api.init(0)
+    rng = np.random.default_rng(10)
+    for (stride, n) in ((16, 1), (408, 13), (4104, 300), (213000, 40)):
+        nb = rng.integers(0, stride - 8, n).astype(np.uint32)
+        nb[0] = stride - 8
+        if n > 3:
+            nb[3] = 0
+        seg = rng.integers(0, 256, n * stride).astype(np.uint8)
+        seg[rng.random(n * stride) < 0.2] = 0xFF
+        if n > 5:
+            seg[5 * stride:6 * stride] = 0xFF
+        want, woff = O.jpeg_pack_rows(seg, nb, stride, first_rst=n % 8, fill=0x77)
+        out = torch.full((len(want) + 16,), 0x77, dtype=torch.uint8, device="cuda")
+        off = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
+        api.jpeg_pack_rows(_dev(seg), _dev(nb.view(np.int32)), stride, n, out, off, first_rst=n % 8, out_capacity=len(want))
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), woff), (stride, n)
+        g = out.cpu().numpy()
+        assert np.array_equal(g[: len(want)], want) and (g[len(want):] == 0x77).all(), (stride, n)
+        if n > 8:  # a capacity that ends inside row 7: rows 0..6 arrive, nothing else is touched
+            cut = int(woff[7]) + 3
+            out.fill_(0x77)
+            api.jpeg_pack_rows(_dev(seg), _dev(nb.view(np.int32)), stride, n, out, off, first_rst=n % 8, out_capacity=cut)
+            g = out.cpu().numpy()
+            assert int(off[n].item()) == int(woff[n]) and np.array_equal(g[: int(woff[7])], want[: int(woff[7])]) and (g[int(woff[7]):] == 0x77).all()
+    W, H = 4096, 2160 - 2160 % 16
+    img = synth.plane_u8_torch(W, H, "photo")
+    coef, _, comp = _encode_gpu(img, W, H, K1_LUMA)
+    d_seg, d_nb = _dev(comp["segments"]), _dev(comp["seg_bytes"].view(np.int32))
+    scan = torch.empty((W * H // 2,), dtype=torch.uint8, device="cuda")
+    off = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
+    api.jpeg_pack_rows(d_seg, d_nb, comp["seg_stride"], H // 8, scan, off)
+    total = int(off[-1].item())
+    assert total <= scan.numel()
+    packed = dict(scan=scan[:total].cpu().numpy(), blocks_per_row=W // 8, qtable=K1_LUMA)
+    a, b = jfif.write_jpeg([packed], W, H), jfif.write_jpeg([comp], W, H)
+    assert a == b
+    assert np.asarray(Image.open(io.BytesIO(a)).convert("L")).shape == (H, W)

@@ -1,7 +1,7 @@
 """Example: a baseline JPEG written by the engine's stages (tools/ = not part of the product path).
     python3 tools/gpu_jpeg.py out.jpg [raw_grey_file X Y | synthetic X Y]
 pixels -> mdct_fwd_u8_records (Annex K.1 table; = mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 in one pass) -> mdct_huffman_rows
--> simd_dct_amd.jfif.write_jpeg"""
+-> mdct_jpeg_pack_rows (stuffing + RSTm, one contiguous scan) -> simd_dct_amd.jfif.write_jpeg (the marker segments)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,11 +22,18 @@ ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
 stride = M.huffman_seg_stride(W)
 seg = torch.empty(((H // 8) * stride,), dtype=torch.uint8, device="cuda")
 nb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
+scan = torch.empty((W * H // 2,), dtype=torch.uint8, device="cuda")
+off = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     M.fwd_u8_records(img, W, H, lv, rn, ct, lut=K1)
     M.huffman_rows(lv, rn, ct, W, H, seg, nb)
+    M.jpeg_pack_rows(seg, nb, stride, H // 8, scan, off)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-data = jfif.write_jpeg([dict(segments=seg.cpu().numpy(), seg_bytes=nb.cpu().numpy(), seg_stride=stride, blocks_per_row=W // 8, qtable=K1)], W, H)
+t0 = time.perf_counter()
+total = int(off[-1].item())
+assert total <= scan.numel()
+data = jfif.write_jpeg([dict(scan=scan[:total].cpu().numpy(), blocks_per_row=W // 8, qtable=K1)], W, H)
+host_ms = (time.perf_counter() - t0) * 1e3
 open(out, "wb").write(data)
-print(f"{W}x{H}: two device stages {dt * 1e6:.0f} us ({W * H / dt / 1e6:.0f} Mpx/s), file {len(data)} bytes ({8 * len(data) / (W * H):.2f} bit/px) -> {out}")
+print(f"{W}x{H}: three device stages {dt * 1e6:.0f} us ({W * H / dt / 1e6:.0f} Mpx/s), file {len(data)} bytes ({8 * len(data) / (W * H):.2f} bit/px) -> {out}; copy back + header {host_ms:.1f} ms")

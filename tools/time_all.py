@@ -82,9 +82,14 @@ print(f"records: {float(ct[0].float().mean()):.1f} pairs per block (quality-60 t
 hstride = M.huffman_seg_stride(W)
 hseg = [torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda") for _ in range(2)]
 hnb = [torch.empty((H // 8,), dtype=torch.int32, device="cuda") for _ in range(2)]
+pscan = torch.empty((W * H // 2,), dtype=torch.uint8, device="cuda")
+poff = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
+for i in range(2):
+    M.huffman_rows(lv[i], rn[i], ct[i], W, H, hseg[i], hnb[i])
 cases += [
     ("Huffman rows from records (3 B/px in)", 3.016, W * H, [lambda i=i: M.huffman_rows(lv[i % 2], rn[i % 2], ct[i % 2], W, H, hseg[i % 2], hnb[i % 2]) for i in range(2)]),
     ("Huffman rows, Annex K.1 records", 3.016, W * H, [lambda i=i: M.huffman_rows(lvk[i % 2], rnk[i % 2], ctk[i % 2], W, H, hseg[i % 2], hnb[i % 2]) for i in range(2)]),
+    ("JPEG scan pack (stuffing + RSTm) of those rows", 0.45, W * H, [lambda i=i: M.jpeg_pack_rows(hseg[i % 2], hnb[i % 2], hstride, H // 8, pscan, poff) for i in range(2)]),
     ("zig-zag scan, i16 (2+2 B/px)", 4, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2]) for i in range(NS)]),
     ("zig-zag + run/level, i16 (2+3)", 5.016, W * H, [lambda i=i: M.zigzag_rle_i16(qcoef[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
     ("zig-zag + run/level, q32 (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_q32(q32b[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(NS)]),
