@@ -177,6 +177,10 @@ int mdct_zigzag_rle_u8(const uint8_t *coef, int layout, size_t sizeX, size_t siz
  * pitch in bytes; no alignment requirement on the pixel plane; levels and runs 16-byte aligned; lut may be NULL. */
 int mdct_fwd_u8_records(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY,
                         size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
+/* the same from an int16 plane (e.g. the planes of mdct_split420_u8): mdct_fwd_i16 followed by mdct_zigzag_rle_i16;
+ * pitch in elements, rows 16-byte aligned */
+int mdct_fwd_i16_records(const int16_t *from, size_t pitch, const float *lut, size_t sizeX, size_t sizeY,
+                         size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream);
 /* Entropy stage: baseline Huffman coding of those records (ITU-T T.81 Annex C code construction, F.1.2.1 DC
  * difference categories, F.1.2.2 RRRRSSSS with ZRL / EOB, the typical tables of Annex K.3.3 -- `chroma` selects
  * Tables K.4 / K.6 instead of K.3 / K.5).  One independently decodable segment per block row: the row is a

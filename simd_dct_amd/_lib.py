@@ -58,6 +58,7 @@ SIGNATURES = {
     "mdct_inv_i16": (c_int, _PLANE),
     "mdct_roundtrip_i16": (c_int, _PLANE),
     "mdct_fwd_u8_records": (c_int, [c_void_p, c_size_t, f32p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdct_fwd_i16_records": (c_int, [c_void_p, c_size_t, f32p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdct_fwd_u8_i16": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, f32p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mdct_inv_i16_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, f32p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mdct_fwd_f32": (c_int, _PLANE_F32),

@@ -174,6 +174,16 @@ def fwd_u8_records(src, sizeX, sizeY, levels, runs, counts, lut=None, level_shif
     return rc
 
 
+def fwd_i16_records(src, sizeX, sizeY, levels, runs, counts, lut=None, by0=0, by1=None, pitch=None, stream=None, check=True):
+    """int16 plane -> zig-zag run/level records of its quantised coefficients in one pass (mdct_fwd_i16_records)"""
+    keep, lp = _lut_ptr(lut)
+    rc = _lib.load().mdct_fwd_i16_records(_ptr(src), sizeX if pitch is None else pitch, lp, sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, _ptr(levels), _ptr(runs), _ptr(counts),
+                                          _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
 def inv_i16_u8(src, dst, sizeX, sizeY, lut=None, level_shift=True, by0=0, by1=None, pitch_in=None, pitch_out=None, stream=None, check=True):
     """int16 coefficients -> 8-bit pixels (mdct_inv_i16_u8)"""
     keep, lp = _lut_ptr(lut)

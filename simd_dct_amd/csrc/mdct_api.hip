@@ -243,9 +243,10 @@ int run_u8_i16(int mode, const void *from, void *to, uint8_t *px, int16_t *coef,
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "u8<->i16 kernel launch");
 }
 
-int run_u8_records(const uint8_t *px, size_t pitch_px, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts,
+int run_u8_records(const void *px_, bool i16_in, size_t pitch_px, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts,
                    void *stream)
 {
+  const uint8_t *px = static_cast<const uint8_t *>(px_);
   if (px == nullptr || levels == nullptr || runs == nullptr || counts == nullptr)
     return fail(MDCT_INVALID_PARAMETER, "null pointer");
   if (sizeX % 8 != 0 || sizeY % 8 != 0)
@@ -254,6 +255,8 @@ int run_u8_records(const uint8_t *px, size_t pitch_px, const float *lut, int lev
     return fail(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows", by0, by1, sizeY / 8);
   if (((uintptr_t)levels | (uintptr_t)runs) & 15)
     return fail(MDCT_INVALID_PARAMETER, "levels and runs must be 16-byte aligned");
+  if (i16_in && (((uintptr_t)px | (pitch_px * sizeof(int16_t))) & 15))
+    return fail(MDCT_INVALID_PARAMETER, "rows of the int16 plane must be 16-byte aligned");
   const mdct_device_info *di;
   int r = current(&di);
   if (r)
@@ -271,7 +274,7 @@ int run_u8_records(const uint8_t *px, size_t pitch_px, const float *lut, int lev
   if ((r = make_own_tables(lut, a.tb, /*pair_order=*/true)))
     return r;
   a.dc_shift = level_shift ? 64.0f * 128.0f : 0.0f;
-  const hipError_t e = mdct::launch_u8_records(a, (hipStream_t)stream);
+  const hipError_t e = mdct::launch_u8_records(a, i16_in, (hipStream_t)stream);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "u8 -> records kernel launch");
 }
 
@@ -435,7 +438,12 @@ int mdct_roundtrip_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t
 
 int mdct_fwd_u8_records(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream)
 {
-  return run_u8_records(px, pitch, lut, level_shift, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
+  return run_u8_records(px, false, pitch, lut, level_shift, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
+}
+
+int mdct_fwd_i16_records(const int16_t *from, size_t pitch, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream)
+{
+  return run_u8_records(from, true, pitch, lut, 0, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
 }
 
 int mdct_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)

@@ -110,13 +110,13 @@ struct U8I16Args
 
 struct U8RecArgs
 { // pixels -> quantised coefficients -> zig-zag + run/level records in one pass (k_u8_records)
-  const uint8_t *px;
+  const uint8_t *px; // 8-bit pixels, or an int16 plane (k_u8_records<true>)
   int16_t *levels; // [block][64]
   uint8_t *runs;   // [block][64]
   uint8_t *counts; // [block]
   OwnTables tb;
   DctConsts consts;
-  size_t pitch_px; // bytes
+  size_t pitch_px; // bytes (int16 plane: elements)
   uint32_t bpr, by0, nblocks;
   float dc_shift;  // 64*128 when level-shifting, else 0
 };
@@ -149,7 +149,7 @@ hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool sa
 hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s);
 hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s);
 hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s);
-hipError_t launch_u8_records(const U8RecArgs &a, hipStream_t s);
+hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s);
 hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s);
 hipError_t launch_stream_copy(const void *from, void *to, size_t bytes, int cus, hipStream_t s);
 

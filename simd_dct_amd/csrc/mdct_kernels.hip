@@ -1089,11 +1089,12 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_
   (void)HAS_LUT;
 }
 
-// Pixels -> records in one pass (the encoder's front half): the forward transform and quantiser of
-// k_u8_i16<MODE_FWD>, then -- instead of storing the int16 plane and reading it back -- the zig-zag scan and
+// Pixels (or an int16 plane, I16_IN) -> records in one pass (the encoder's front half): the forward
+// transform and quantiser of k_u8_i16<MODE_FWD> (k_i16<MODE_FWD>), then -- instead of storing the int16 plane and reading it back -- the zig-zag scan and
 // run/level compaction of k_scan (scan_records.h) on the values still in registers.  1 B/px in, 3 B/px out
 // (k_u8_i16 + k_scan move 3 + 5).  Bit for bit the records mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 produce.
 // One wave per workgroup: every wave works alone on 64 consecutive blocks (lane = block).
+template <bool I16_IN>
 __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lv[64 * kLvRow];
@@ -1105,21 +1106,40 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
   const uint32_t t = wave_t0 + (valid ? lane : 0);
   const uint32_t row = t / a.bpr, bx = t - row * a.bpr;
   const DctConsts &C = a.consts;
-  const uint8_t *src = a.px + (size_t)(a.by0 + row) * 8 * a.pitch_px + (size_t)bx * 8;
-  uint2 rows[8];
-#pragma unroll
-  for (int r = 0; r < 8; r++)
-    rows[r] = load8(src + (size_t)r * a.pitch_px);
   // the forward transform on packed fp32 (aan_fwd_h / aan_fwd_v: the same individually rounded operations as raw_fwd);
-  // a.tb.qf is in the pair order of the column pass, (v*4 + j)*2 + {0,1} = coefficient (v, A[j]) / (v, B[j])
+  // a.tb.qf is in the pair order of the column pass, (v*4 + j)*2 + {0,1} = coefficient (v, A[j]) / (v, B[j]).
+  // Rows are converted as they are consumed: the raw rows (16 / 32 registers) stay live, not 64 floats.
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
   f32x2 P[4][8];
+  if constexpr (I16_IN)
+  { // an int16 plane (pitch in elements): the input of mdct_fwd_i16
+    const int16_t *src = reinterpret_cast<const int16_t *>(a.px) + (size_t)(a.by0 + row) * 8 * a.pitch_px + (size_t)bx * 8;
+    uint4 rows[8];
 #pragma unroll
-  for (int r = 0; r < 8; r++)
+    for (int r = 0; r < 8; r++)
+      rows[r] = ld_stream16(src + (size_t)r * a.pitch_px);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      const f32x2 a01 = {(float)(int16_t)(rows[r].x & 0xFFFF), (float)(int16_t)(rows[r].x >> 16)}, a23 = {(float)(int16_t)(rows[r].y & 0xFFFF), (float)(int16_t)(rows[r].y >> 16)};
+      const f32x2 a45 = {(float)(int16_t)(rows[r].z & 0xFFFF), (float)(int16_t)(rows[r].z >> 16)}, a67 = {(float)(int16_t)(rows[r].w & 0xFFFF), (float)(int16_t)(rows[r].w >> 16)};
+      aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
+    }
+  }
+  else
   {
-    const f32x2 a01 = {ubyte_to_float<0>(rows[r].x), ubyte_to_float<1>(rows[r].x)}, a23 = {ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
-    const f32x2 a45 = {ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)}, a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
-    aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
+    const uint8_t *src = a.px + (size_t)(a.by0 + row) * 8 * a.pitch_px + (size_t)bx * 8;
+    uint2 rows[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      rows[r] = load8(src + (size_t)r * a.pitch_px);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      const f32x2 a01 = {ubyte_to_float<0>(rows[r].x), ubyte_to_float<1>(rows[r].x)}, a23 = {ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
+      const f32x2 a45 = {ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)}, a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
+      aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
+    }
   }
   int val[64];
   constexpr int kA[4] = {0, 2, 5, 1}, kB[4] = {4, 6, 3, 7};
@@ -1414,11 +1434,14 @@ hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s)
   return hipGetLastError();
 }
 
-hipError_t launch_u8_records(const U8RecArgs &a, hipStream_t s)
+hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s)
 {
   if (a.nblocks == 0)
     return hipSuccess;
-  hipLaunchKernelGGL(k_u8_records, dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a);
+  if (i16_in)
+    hipLaunchKernelGGL(k_u8_records<true>, dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_u8_records<false>, dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 

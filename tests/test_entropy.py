@@ -105,8 +105,9 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _encode_gpu(d_img, W, H, qtable, chroma=False, from_i16=None):
-    """u8 plane (or ready int16 plane) on the device -> coefficients, records, row segments; all on the device"""
+def _encode_gpu(d_img, W, H, qtable, chroma=False, from_i16=None, fused=False):
+    """u8 plane (or ready int16 plane) on the device -> coefficients, records, row segments; all on the device.
+    fused: the records come from mdct_fwd_u8_records / mdct_fwd_i16_records instead of the two-stage path"""
     coef = torch.empty((H, W), dtype=torch.int16, device="cuda")
     if from_i16 is None:
         api.fwd_u8_i16(d_img, coef, W, H, lut=qtable)
@@ -116,7 +117,12 @@ def _encode_gpu(d_img, W, H, qtable, chroma=False, from_i16=None):
     lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
     rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
     ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
-    api.zigzag_rle_i16(coef, W, H, lv, rn, ct)
+    if not fused:
+        api.zigzag_rle_i16(coef, W, H, lv, rn, ct)
+    elif from_i16 is None:
+        api.fwd_u8_records(d_img, W, H, lv, rn, ct, lut=qtable)
+    else:
+        api.fwd_i16_records(from_i16, W, H, lv, rn, ct, lut=qtable)
     stride = api.huffman_seg_stride(W)
     seg = torch.full(((H // 8) * stride,), 0x5A, dtype=torch.uint8, device="cuda")
     nb = torch.zeros((H // 8,), dtype=torch.int32, device="cuda")
@@ -199,7 +205,7 @@ def test_gpu_pipeline_writes_jpegs_libjpeg_opens():
     api.split420_u8(ycc, W, H, y, cb, cr)
     comps, coefs = [], []
     for plane, (w, h), q, chroma in ((y, (W, H), K1_LUMA, False), (cb, (W // 2, H // 2), K2_CHROMA, True), (cr, (W // 2, H // 2), K2_CHROMA, True)):
-        c, _, comp = _encode_gpu(None, w, h, q, chroma=chroma, from_i16=plane)
+        c, _, comp = _encode_gpu(None, w, h, q, chroma=chroma, from_i16=plane, fused=True)
         comps.append(comp)
         coefs.append(c)
     data = jfif.write_jpeg(comps, W, H)

@@ -203,6 +203,20 @@ def test_fused_pixels_to_records_equals_the_two_stage_path():
             assert torch.equal(lv, lv2) and torch.equal(rn, rn2) and torch.equal(ct, ct2)
             del img
     assert api.fwd_u8_records(_dev(np.zeros((16, 64), dtype=np.uint8)), 64, 16, lv, rn, ct, lut=np.zeros(64, dtype=np.float32), check=False) == 1  # a zero table entry
+    # the int16-plane variant: mdct_fwd_i16_records == mdct_fwd_i16 + mdct_zigzag_rle_i16 == the checker's composition
+    for (W, H, pitch) in ((8, 8, 8), (200, 40, 208), (1024, 72, 1024)):
+        nblk = (W // 8) * (H // 8)
+        for bits, lut in ((8, K1), (12, None), (12, (K1 * 4).astype(np.float32))):
+            wide = synth.plane_i16_np(pitch, H, "photo", seed=W, bits=bits)
+            src = np.ascontiguousarray(wide[:, :W])
+            want = O.zigzag_rle("i16", O.i16("fwd", src, W, H, lut=lut), W, H)
+            lv = torch.full((nblk, 64), 0x5A5A, dtype=torch.int16, device="cuda")
+            rn = torch.full((nblk, 64), 0x5A, dtype=torch.uint8, device="cuda")
+            ct = torch.full((nblk,), 0x5A, dtype=torch.uint8, device="cuda")
+            api.fwd_i16_records(_dev(wide), W, H, lv, rn, ct, lut=lut, pitch=pitch)
+            for got, w in zip((lv, rn, ct), want):
+                assert np.array_equal(got.cpu().numpy(), w), (W, H, bits)
+    assert api.fwd_i16_records(_dev(np.zeros((16, 72), dtype=np.int16)), 64, 16, lv, rn, ct, pitch=68, check=False) == 1  # rows not 16-byte aligned
     # a sub-range writes its own records only
     W, H = 512, 64
     bpr = W // 8

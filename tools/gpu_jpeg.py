@@ -1,7 +1,9 @@
 """Example: a baseline JPEG written by the engine's stages (tools/ = not part of the product path).
-    python3 tools/gpu_jpeg.py out.jpg [raw_grey_file X Y | synthetic X Y]
-pixels -> mdct_fwd_u8_records (Annex K.1 table; = mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 in one pass) -> mdct_huffman_rows
--> mdct_jpeg_pack_rows (stuffing + RSTm, one contiguous scan) -> simd_dct_amd.jfif.write_jpeg (the marker segments)"""
+    python3 tools/gpu_jpeg.py out.jpg [synthetic | synthetic-color | raw_grey_file] [X Y]
+grey:   pixels -> mdct_fwd_u8_records (Annex K.1 table; = mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 in one pass) -> mdct_huffman_rows
+        -> mdct_jpeg_pack_rows (stuffing + RSTm, one contiguous scan) -> simd_dct_amd.jfif.write_jpeg (the marker segments)
+colour: interleaved 8-bit YCbCr -> mdct_split420_u8 -> per plane mdct_fwd_i16_records (K.1 / K.2) -> mdct_huffman_rows -> mdct_jpeg_pack_rows;
+        three non-interleaved scans (Y at full resolution, Cb / Cr at half)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,30 +12,67 @@ from simd_dct_amd import jfif, synth
 
 K1 = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
                18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+K2 = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.float32)
 out = sys.argv[1] if len(sys.argv) > 1 else "out.jpg"
 src = sys.argv[2] if len(sys.argv) > 2 else "synthetic"
-W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (4096, 2160 - 2160 % 8)
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (4096, 2160 - 2160 % 16)
 M.init(0)
-img = synth.plane_u8_torch(W, H, "photo") if src == "synthetic" else torch.from_numpy(np.fromfile(src, dtype=np.uint8)[: W * H].reshape(H, W)).cuda()
-nblk = (W // 8) * (H // 8)
-lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
-rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
-ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
-stride = M.huffman_seg_stride(W)
-seg = torch.empty(((H // 8) * stride,), dtype=torch.uint8, device="cuda")
-nb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
-scan = torch.empty((W * H // 2,), dtype=torch.uint8, device="cuda")
-off = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
+
+
+class Plane:
+    """device buffers of one component: records, row segments, packed scan"""
+
+    def __init__(self, w, h, qtable, chroma):
+        self.w, self.h, self.q, self.chroma = w, h, qtable, chroma
+        nblk = (w // 8) * (h // 8)
+        self.lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
+        self.rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
+        self.ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
+        self.stride = M.huffman_seg_stride(w)
+        self.seg = torch.empty(((h // 8) * self.stride,), dtype=torch.uint8, device="cuda")
+        self.nb = torch.empty((h // 8,), dtype=torch.int32, device="cuda")
+        self.scan = torch.empty((w * h // 2,), dtype=torch.uint8, device="cuda")
+        self.off = torch.zeros((h // 8 + 1,), dtype=torch.int64, device="cuda")
+
+    def entropy(self):
+        M.huffman_rows(self.lv, self.rn, self.ct, self.w, self.h, self.seg, self.nb, chroma=self.chroma)
+        M.jpeg_pack_rows(self.seg, self.nb, self.stride, self.h // 8, self.scan, self.off)
+
+    def component(self):
+        total = int(self.off[-1].item())
+        assert total <= self.scan.numel()
+        return dict(scan=self.scan[:total].cpu().numpy(), blocks_per_row=self.w // 8, qtable=self.q)
+
+
+if src == "synthetic-color":
+    ycc = torch.stack([synth.plane_u8_torch(W, H, "photo", seed=s) for s in (5, 6, 7)], dim=-1).contiguous()
+    y = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    cb = torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda")
+    cr = torch.empty_like(cb)
+    planes = [Plane(W, H, K1, False), Plane(W // 2, H // 2, K2, True), Plane(W // 2, H // 2, K2, True)]
+
+    def encode():
+        M.split420_u8(ycc, W, H, y, cb, cr)
+        for p, s in zip(planes, (y, cb, cr)):
+            M.fwd_i16_records(s, p.w, p.h, p.lv, p.rn, p.ct, lut=p.q)
+            p.entropy()
+    what = "4:2:0 colour, 10 launches"
+else:
+    img = synth.plane_u8_torch(W, H, "photo") if src == "synthetic" else torch.from_numpy(np.fromfile(src, dtype=np.uint8)[: W * H].reshape(H, W)).cuda()
+    planes = [Plane(W, H, K1, False)]
+
+    def encode():
+        p = planes[0]
+        M.fwd_u8_records(img, W, H, p.lv, p.rn, p.ct, lut=K1)
+        p.entropy()
+    what = "grey, 3 stages"
+
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    M.fwd_u8_records(img, W, H, lv, rn, ct, lut=K1)
-    M.huffman_rows(lv, rn, ct, W, H, seg, nb)
-    M.jpeg_pack_rows(seg, nb, stride, H // 8, scan, off)
+    encode()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 t0 = time.perf_counter()
-total = int(off[-1].item())
-assert total <= scan.numel()
-data = jfif.write_jpeg([dict(scan=scan[:total].cpu().numpy(), blocks_per_row=W // 8, qtable=K1)], W, H)
+data = jfif.write_jpeg([p.component() for p in planes], W, H)
 host_ms = (time.perf_counter() - t0) * 1e3
 open(out, "wb").write(data)
-print(f"{W}x{H}: three device stages {dt * 1e6:.0f} us ({W * H / dt / 1e6:.0f} Mpx/s), file {len(data)} bytes ({8 * len(data) / (W * H):.2f} bit/px) -> {out}; copy back + header {host_ms:.1f} ms")
+print(f"{W}x{H} {what}: device {dt * 1e6:.0f} us ({W * H / dt / 1e6:.0f} Mpx/s), file {len(data)} bytes ({8 * len(data) / (W * H):.2f} bit/px) -> {out}; copy back + header {host_ms:.1f} ms")

@@ -96,6 +96,7 @@ cases += [
     ("zig-zag + run/level, stereo planes (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_u8(st8[i % 2], M.LAYOUT_STEREO, W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(2)]),
     ("zig-zag + run/level, encq blocks (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_u8(bl8[i % 2], M.LAYOUT_BLOCK, W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(2)]),
     ("u8 px -> records, fused (1+3 B/px)", 4.016, W * H, [lambda i=i: M.fwd_u8_records(u8[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2], lut=K1) for i in range(NS)]),
+    ("i16 plane -> records, fused (2+3 B/px)", 5.016, W * H, [lambda i=i: M.fwd_i16_records(i16[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2], lut=K1) for i in range(NS)]),
     ("4:2:0 split (3+3 B/px)", 6, W * H, [lambda i=i: M.split420_u8(ycc[i], W, H, sy[i], scb[i], scr[i]) for i in range(2)]),
 ]
 # config 4 on one GPU: 256 independent 4096x4096 int16 planes, forward only.  Blocks are
