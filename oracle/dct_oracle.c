@@ -1050,8 +1050,9 @@ int orc_jpeg_pack_rows(const uint8_t *seg, const uint32_t *seg_bytes, size_t seg
   for (size_t r = 0; r < n_rows; r++)
   {
     const uint8_t *p = seg + r * seg_stride;
-    uint64_t len = seg_bytes[r];
-    for (uint32_t i = 0; i < seg_bytes[r]; i++)
+    const uint32_t nb = seg_bytes[r] > seg_stride ? (uint32_t)seg_stride : seg_bytes[r]; /* a length beyond the stride is not a row */
+    uint64_t len = nb;
+    for (uint32_t i = 0; i < nb; i++)
       len += p[i] == 0xFF;
     if (r + 1 < n_rows)
       len += 2;
@@ -1059,7 +1060,7 @@ int orc_jpeg_pack_rows(const uint8_t *seg, const uint32_t *seg_bytes, size_t seg
     if (pos + len <= capacity)
     {
       uint8_t *o = out + pos;
-      for (uint32_t i = 0; i < seg_bytes[r]; i++)
+      for (uint32_t i = 0; i < nb; i++)
       {
         *o++ = p[i];
         if (p[i] == 0xFF)

@@ -538,7 +538,7 @@ __device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t *wave_tot /*
 __global__ __launch_bounds__(256) void k_pack_count(PackArgs a)
 {
   __shared__ uint32_t wave_tot[4];
-  const uint32_t r = blockIdx.x, nb = a.seg_bytes[r];
+  const uint32_t r = blockIdx.x, nb = (uint32_t)min((size_t)a.seg_bytes[r], a.seg_stride); // a length beyond the stride is not a row
   const uint32_t *p = reinterpret_cast<const uint32_t *>(a.seg + (size_t)r * a.seg_stride);
   uint32_t ff = 0;
   for (uint32_t i = threadIdx.x * 4; i < nb; i += 1024)
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(256) void k_pack_scan(PackArgs a)
 __global__ __launch_bounds__(256) void k_pack_write(PackArgs a)
 {
   __shared__ uint32_t wave_tot[4];
-  const uint32_t r = blockIdx.x, nb = a.seg_bytes[r];
+  const uint32_t r = blockIdx.x, nb = (uint32_t)min((size_t)a.seg_bytes[r], a.seg_stride); // a length beyond the stride is not a row
   const unsigned long long base = a.row_off[r], end = a.row_off[r + 1];
   if (end > a.capacity)
     return; // does not fit: the caller sees row_off[n_rows] > capacity
