@@ -34,9 +34,9 @@ class Plane:
         self.scan = torch.empty((w * h // 2,), dtype=torch.uint8, device="cuda")
         self.off = torch.zeros((h // 8 + 1,), dtype=torch.int64, device="cuda")
 
-    def entropy(self):
-        M.huffman_rows(self.lv, self.rn, self.ct, self.w, self.h, self.seg, self.nb, chroma=self.chroma)
-        M.jpeg_pack_rows(self.seg, self.nb, self.stride, self.h // 8, self.scan, self.off)
+    def entropy(self, stream=None):
+        M.huffman_rows(self.lv, self.rn, self.ct, self.w, self.h, self.seg, self.nb, chroma=self.chroma, stream=stream)
+        M.jpeg_pack_rows(self.seg, self.nb, self.stride, self.h // 8, self.scan, self.off, stream=stream)
 
     def component(self):
         total = int(self.off[-1].item())
@@ -51,12 +51,21 @@ if src == "synthetic-color":
     cr = torch.empty_like(cb)
     planes = [Plane(W, H, K1, False), Plane(W // 2, H // 2, K2, True), Plane(W // 2, H // 2, K2, True)]
 
+    side_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
     def encode():
+        # the three planes are independent after the split: Y on the current stream, Cb and Cr on two side streams
+        # (fork / join by events, so the same code is capturable as one hipGraph with three parallel branches)
+        cur = torch.cuda.current_stream()
         M.split420_u8(ycc, W, H, y, cb, cr)
-        for p, s in zip(planes, (y, cb, cr)):
-            M.fwd_i16_records(s, p.w, p.h, p.lv, p.rn, p.ct, lut=p.q)
-            p.entropy()
-    what = "4:2:0 colour, 10 launches"
+        for st in side_streams:
+            st.wait_stream(cur)
+        for p, s, st in zip(planes, (y, cb, cr), (cur, side_streams[0], side_streams[1])):
+            M.fwd_i16_records(s, p.w, p.h, p.lv, p.rn, p.ct, lut=p.q, stream=st.cuda_stream)
+            p.entropy(stream=st.cuda_stream)
+        for st in side_streams:
+            cur.wait_stream(st)
+    what = "4:2:0 colour, 10 launches on 3 streams"
 else:
     img = synth.plane_u8_torch(W, H, "photo") if src == "synthetic" else torch.from_numpy(np.fromfile(src, dtype=np.uint8)[: W * H].reshape(H, W)).cuda()
     planes = [Plane(W, H, K1, False)]
