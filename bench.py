@@ -158,6 +158,9 @@ def reference_q32_baseline(threads, runs=10, warmups=2):
     return res
 
 
+GATHER_TIMEOUT_S = float(os.environ.get("MDCT_BENCH_GATHER_TIMEOUT", "300"))  # watchdog of the optional all-gather legs (a healthy 8-rank run needs ~10 s)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,8 +187,19 @@ def main():
     dist = None
     local = local % max(1, torch.cuda.device_count())  # rehearsal: more ranks than GPUs share a device
     torch.cuda.set_device(local)
+    emit = lambda text: print(text, flush=True)
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run, also for one rank (exercises RCCL)
         import torch.distributed as dist
+
+        # stdout carries exactly one line, the JSON: RCCL prints a version banner to file descriptor 1 when its first
+        # communicator comes up, so fd 1 is pointed at stderr for the rest of the run and the line goes to a private copy
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+        def emit(text):
+            json_out.write(text + "\n")
+            json_out.flush()
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -364,6 +378,60 @@ def main():
             extras["huffman_rows"] = {"error": str(e)[:120]}
 
     log("extras done")
+    if rank == 0:
+        line = {
+            "metric": "Mpixels/s 8x8 fwd+inv int16 DCT, 8192x8192 plane",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "io_dtype": "int16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: single 8192x8192 int16 plane per GPU, forward+inverse 8x8 DCT fused in one kernel",
+                       "plane": [W, H], "io": "int16", "planes_per_step_per_gpu": 1, "rotating_plane_sets": NSETS, "untimed_preconditioning_launches": PRECONDITION,
+                       "parallelism": f"independent planes x{world}" if world > 1 else "single GPU", "device": info["name"]},
+            "roofline": {"bound": "hbm", "kernel": "mdct::k_i16<MODE_ROUNDTRIP, no table>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": px_per_step * ALG_BYTES_PER_PX, "avg_launch_ms": round(kernel_ms, 4)},
+            "bit_exact_roundtrip_verified": verified,
+        }
+        traffic = {}
+        tr = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr):
+            try:
+                traffic = json.load(open(tr))
+                line["roofline"]["traffic"] = traffic.get("k_i16_roundtrip_bytes_per_launch")
+                line["roofline"]["traffic_source"] = "profiles/traffic.json (PMC passes of an earlier run of the same kernel, not counters of this run): " + traffic.get("source", "")
+            except Exception:
+                pass
+        if extras:
+            line["extras"] = extras
+            q = extras.get("fwd_quant_u8_q32")
+            if q and "GBps" in q:
+                # the reference's own hot path on the same plane size: 2 algorithmic bytes per pixel (SURVEY.md 8d)
+                copy = extras.get("stream_copy_roofline", {}).get("GBps")
+                line["roofline_u8"] = {"bound": "hbm (co-limited by un-fusable fp32 VALU work, DESIGN.md 4.1)", "kernel": "mdct::k_q32_avx<false, false>",
+                                       "reference": "simdDCT_EncodeQuantize32ReorderBuffer, AVX2 tier, simd_dct.cpp:2064-2262", "achieved": q["GBps"], "peak": HBM_PEAK_GBPS,
+                                       "unit": "GB/s", "frac": round(q["GBps"] / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(q["GBps"] / copy, 3) if copy else None,
+                                       "algorithmic_bytes_per_launch": 2 * W * H, "avg_launch_ms": q["ms"], "Mpx_s": q.get("Mpx_s"),
+                                       "traffic": traffic.get("k_q32_avx_bytes_per_launch"),
+                                       "traffic_source": "profiles/traffic.json: " + traffic.get("source_q32", traffic.get("source", "")) if traffic else None,
+                                       "bit_exact_vs_oracle": q.get("matches_oracle_on_first_stripe")}
+    # The optional whole-node leg runs AFTER the headline line is complete and under a watchdog: a collective that hangs
+    # on some node must not cost the run its JSON line.  If the leg does not finish in time, rank 0 prints the line with
+    # an error note in "allgather" and every rank exits.
+    line_ready = threading.Event()
+
+    def watchdog_fire():
+        if line_ready.is_set():
+            return
+        if rank == 0:
+            line["allgather"] = {"error": f"all-gather leg did not finish within {GATHER_TIMEOUT_S} s; headline unaffected"}
+            emit(json.dumps(line))
+        os._exit(0)
+
+    watchdog = None
+    if dist is not None and not args.no_extras and args.backend == "nccl":
+        watchdog = threading.Timer(GATHER_TIMEOUT_S, watchdog_fire)
+        watchdog.daemon = True
+        watchdog.start()
     if dist is not None and not args.no_extras and args.backend == "nccl":
         # north_star's whole-node run at configs[3]'s own shape: a batch of 256 independent 4096x4096 int16 planes,
         # forward only, sharded over the ranks (whole planes: 256/N per rank -- the same bytes per rank as
@@ -441,49 +509,21 @@ def main():
         except Exception as e:
             allgather = {"error": str(e)[:200]}
 
+    line_ready.set()
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        line = {
-            "metric": "Mpixels/s 8x8 fwd+inv int16 DCT, 8192x8192 plane",
-            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "io_dtype": "int16", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: single 8192x8192 int16 plane per GPU, forward+inverse 8x8 DCT fused in one kernel",
-                       "plane": [W, H], "io": "int16", "planes_per_step_per_gpu": 1, "rotating_plane_sets": NSETS, "untimed_preconditioning_launches": PRECONDITION,
-                       "parallelism": f"independent planes x{world}" if world > 1 else "single GPU", "device": info["name"]},
-            "roofline": {"bound": "hbm", "kernel": "mdct::k_i16<MODE_ROUNDTRIP, no table>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": px_per_step * ALG_BYTES_PER_PX, "avg_launch_ms": round(kernel_ms, 4)},
-            "bit_exact_roundtrip_verified": verified,
-        }
-        traffic = {}
-        tr = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr):
-            try:
-                traffic = json.load(open(tr))
-                line["roofline"]["traffic"] = traffic.get("k_i16_roundtrip_bytes_per_launch")
-                line["roofline"]["traffic_source"] = "profiles/traffic.json (PMC passes of an earlier run of the same kernel, not counters of this run): " + traffic.get("source", "")
-            except Exception:
-                pass
-        if extras:
-            line["extras"] = extras
-            q = extras.get("fwd_quant_u8_q32")
-            if q and "GBps" in q:
-                # the reference's own hot path on the same plane size: 2 algorithmic bytes per pixel (SURVEY.md 8d)
-                copy = extras.get("stream_copy_roofline", {}).get("GBps")
-                line["roofline_u8"] = {"bound": "hbm (co-limited by un-fusable fp32 VALU work, DESIGN.md 4.1)", "kernel": "mdct::k_q32_avx<false, false>",
-                                       "reference": "simdDCT_EncodeQuantize32ReorderBuffer, AVX2 tier, simd_dct.cpp:2064-2262", "achieved": q["GBps"], "peak": HBM_PEAK_GBPS,
-                                       "unit": "GB/s", "frac": round(q["GBps"] / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(q["GBps"] / copy, 3) if copy else None,
-                                       "algorithmic_bytes_per_launch": 2 * W * H, "avg_launch_ms": q["ms"], "Mpx_s": q.get("Mpx_s"),
-                                       "traffic": traffic.get("k_q32_avx_bytes_per_launch"),
-                                       "traffic_source": "profiles/traffic.json: " + traffic.get("source_q32", traffic.get("source", "")) if traffic else None,
-                                       "bit_exact_vs_oracle": q.get("matches_oracle_on_first_stripe")}
         if allgather:
             line["allgather"] = allgather
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle port) ...")
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        emit(json.dumps(line))
     if dist is not None and not args.no_extras and args.backend == "nccl":
+        # (its own watchdog: the line is out, a hang here must only not keep the job alive)
+        tail_dog = threading.Timer(GATHER_TIMEOUT_S, lambda: os._exit(0))
+        tail_dog.daemon = True
+        tail_dog.start()
         # The same gather through the C-ABI's own RCCL leg (mdct_comm_* / mdct_allgather_rows, csrc/comm.hip),
         # i.e. what a C++ host would call.  Runs AFTER the JSON line (stdout stays one line whatever happens
         # here); its result goes to stderr.
@@ -521,6 +561,7 @@ def main():
         except Exception as e:
             if rank == 0:
                 print("[bench cabi-gather] " + json.dumps({"error": str(e)[:200]}), file=sys.stderr, flush=True)
+        tail_dog.cancel()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
