@@ -1,6 +1,6 @@
 # Top-level build for C/C++ users (the Python entry point __graft_entry__.build() does the same).
 #   make            libmdct_hip.so + the C++ CLI + the CPU checker
-#   make lib | cli | oracle | ref | clean
+#   make lib | cli | jpeg_example | oracle | ref | clean
 HIPCC   ?= /opt/rocm/bin/hipcc
 ARCH    ?= gfx950
 CSRC    := simd_dct_amd/csrc
@@ -12,12 +12,17 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -std
 all: lib cli oracle
 
 lib: $(LIB)
-$(LIB): $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/stages.hip $(CSRC)/mdct_kernels.h include/mdct.h include/simd_dct_shim.h
+$(LIB): $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/stages.hip $(CSRC)/mdct_kernels.h $(CSRC)/scan_records.h include/mdct.h include/simd_dct_shim.h
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/stages.hip -ldl -o $@
 
 cli: tools/simd_dct_cli
 tools/simd_dct_cli: tools/simd_dct_cli.cpp $(LIB)
 	$(HIPCC) -O2 -std=c++17 -x hip --offload-arch=$(ARCH) -Iinclude $< -Lsimd_dct_amd -lmdct_hip -Wl,-rpath,'$$ORIGIN/../simd_dct_amd' -o $@
+
+# plain C on the C-ABI: pixels -> baseline JPEG (tools/mdct_jpeg.c)
+jpeg_example: tools/mdct_jpeg
+tools/mdct_jpeg: tools/mdct_jpeg.c $(LIB) include/mdct.h
+	gcc -O2 -std=c99 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude $< -Lsimd_dct_amd -lmdct_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../simd_dct_amd' -Wl,-rpath,/opt/rocm/lib -o $@
 
 oracle:
 	$(MAKE) -C oracle
@@ -25,7 +30,7 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -f $(LIB) tools/simd_dct_cli
+	rm -f $(LIB) tools/simd_dct_cli tools/mdct_jpeg
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib cli oracle ref clean
+.PHONY: all lib cli jpeg_example oracle ref clean

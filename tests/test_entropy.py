@@ -4,6 +4,8 @@ but an INDEPENDENT one: libjpeg (through PIL) must decode the files, reproduce o
 +-1 of two different IDCTs, and write the same Huffman tables itself.  That pins scan order, run/level semantics,
 code construction, DC prediction / restart semantics and the tables.  GPU: the kernel's bytes equal the checker's."""
 import io
+import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -326,3 +328,27 @@ def test_device_packed_scan_is_the_file_libjpeg_opens():
     a, b = jfif.write_jpeg([packed], W, H), jfif.write_jpeg([comp], W, H)
     assert a == b
     assert np.asarray(Image.open(io.BytesIO(a)).convert("L")).shape == (H, W)
+
+
+C_EXAMPLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "mdct_jpeg")
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_writes_the_same_file(tmp_path):
+    """tools/mdct_jpeg.c -- gcc, the C-ABI and the HIP runtime only -- writes byte for byte the JPEG the Python host writes
+    from the same pixels, and libjpeg decodes it (the host side of the stages stays C)"""
+    root = os.path.dirname(C_EXAMPLE[: -len("/mdct_jpeg")])
+    r = subprocess.run(["make", "-s", "-C", root, "jpeg_example"], capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(C_EXAMPLE), r.stderr[-600:]
+    W, H = 1024, 768
+    pic = synth.plane_u8_np(W, H, "photo", seed=31)
+    raw, out = tmp_path / "in.raw", tmp_path / "out.jpg"
+    pic.tofile(raw)
+    r = subprocess.run([C_EXAMPLE, str(out), str(raw), str(W), str(H)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    api.init(0)
+    _, _, comp = _encode_gpu(_dev(pic), W, H, K1_LUMA, fused=True)
+    want = jfif.write_jpeg([comp], W, H)
+    got = out.read_bytes()
+    assert got == want, (len(got), len(want))
+    assert np.asarray(Image.open(io.BytesIO(got)).convert("L")).shape == (H, W)
