@@ -21,8 +21,8 @@ tools/simd_dct_cli: tools/simd_dct_cli.cpp $(LIB)
 
 # plain C on the C-ABI: pixels -> baseline JPEG (tools/mdct_jpeg.c)
 jpeg_example: tools/mdct_jpeg
-# (the library is an order-only prerequisite: a test builds this while the library is loaded, it must never be relinked as a side effect)
-tools/mdct_jpeg: tools/mdct_jpeg.c include/mdct.h | $(LIB)
+# (no dependency on $(LIB): a GPU test builds this while the library is loaded, so it must never relink it as a side effect; run `make lib` first)
+tools/mdct_jpeg: tools/mdct_jpeg.c include/mdct.h
 	gcc -O2 -std=c99 -Wall -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude $< -Lsimd_dct_amd -lmdct_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../simd_dct_amd' -Wl,-rpath,/opt/rocm/lib -o $@
 
 oracle:
