@@ -7,7 +7,11 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 #include "mdct.h"
 #include "simd_dct_shim.h"
@@ -58,6 +62,106 @@ int effective_level()
   return MDCT_SIMD_AVX2;
 }
 
+// The host pipeline's extra hands.  Copying between the caller's pageable memory and the pinned bounce buffers is what
+// bounds a host-pointer call: one core sustains ~15 GB/s of memcpy, PCIe moves ~26 GB/s each way at once.  Three helper
+// threads per calling thread (started on first use, joined when the thread's staging is released) take (a) half of every
+// chunk's input copy and (b) the output copies -- wait for the chunk's stream, then pinned -> caller memory, in two halves
+// -- while the calling thread copies the next chunk's input.  A latch per pipeline slot and direction says when a
+// slot's buffers are free again.
+struct CopyPool
+{
+  struct Job
+  {
+    hipStream_t stream; // not null: wait for it first
+    uint8_t *dst;
+    const uint8_t *src;
+    size_t len;         // 0: nothing to copy (the data was DMA'd straight into pinned caller memory)
+    std::atomic<int> *latch;
+  };
+  enum { kThreads = 3 };
+  std::thread th[kThreads];
+  int started = 0;
+  std::mutex m;
+  std::condition_variable cv_job, cv_done;
+  std::deque<Job> q;
+  bool stop = false;
+  std::atomic<bool> failed{false};
+  int device = 0;
+
+  void run()
+  {
+    (void)hipSetDevice(device);
+    for (;;)
+    {
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_job.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty())
+          return;
+        j = q.front();
+        q.pop_front();
+      }
+      const bool ok = !j.stream || hipStreamSynchronize(j.stream) == hipSuccess;
+      if (ok && j.len)
+        memcpy(j.dst, j.src, j.len);
+      if (!ok)
+        failed = true;
+      {
+        std::lock_guard<std::mutex> lk(m); // the waiter checks the latch under this mutex: no lost wake-up
+        j.latch->fetch_sub(1);
+      }
+      cv_done.notify_all();
+    }
+  }
+  bool start(int dev)
+  {
+    if (started == kThreads)
+      return true;
+    if (started) // a partial start earlier: do without helpers
+      return false;
+    device = dev;
+    stop = false;
+    try
+    {
+      for (; started < kThreads; started++)
+        th[started] = std::thread([this] { run(); });
+    }
+    catch (...)
+    {
+      shutdown();
+      return false;
+    }
+    return true;
+  }
+  void push(const Job &j)
+  {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      q.push_back(j);
+    }
+    cv_job.notify_one();
+  }
+  void wait(std::atomic<int> &latch)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return latch.load() == 0; });
+  }
+  void shutdown()
+  {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_job.notify_all();
+    for (int i = 0; i < started; i++)
+      if (th[i].joinable())
+        th[i].join();
+    started = 0;
+    q.clear();
+  }
+};
+
 struct Staging
 {
   uint8_t *in = nullptr, *out = nullptr; // HBM mirrors of the caller's planes
@@ -67,9 +171,12 @@ struct Staging
   size_t pin_cap = 0;
   hipStream_t stream[2] = {nullptr, nullptr};
   int device = -1;
+  CopyPool pool;
+  std::atomic<int> in_latch[2] = {{0}, {0}}, out_latch[2] = {{0}, {0}}; // outstanding helper jobs per pipeline slot
 
   void release()
   {
+    pool.shutdown(); // before its streams and buffers go
     // errors are ignored on purpose: at process exit the runtime may already be shutting down
     if (in)
       (void)hipFree(in);
@@ -232,8 +339,16 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
     {
       const size_t nchunks = ceil_div(b1 - b0, rows_per_chunk);
       int r = MDCT_SUCCESS;
-      auto drain = [&](size_t c) { // chunk c has finished on its stream: hand its output to the caller
+      const bool helpers = nchunks > 1 && !(pinned_in && pinned_out) && st.pool.start(dev); // see CopyPool
+      if (helpers)
+        st.pool.failed = false;
+      auto drain = [&](size_t c) { // chunk c has left both bounce buffers of its slot; its output is with the caller
         const int sl = (int)(c & 1);
+        if (helpers)
+        {
+          st.pool.wait(st.out_latch[sl]);
+          return !st.pool.failed.load();
+        }
         const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
         if (hipStreamSynchronize(st.stream[sl]) != hipSuccess)
           return false;
@@ -241,33 +356,57 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
           memcpy(pTo + r0 * strip, st.pin_out[sl], (r1 - r0) * strip);
         return true;
       };
+      auto abandon = [&]() { // every job handed to the helpers finishes before the buffers are reused or freed
+        if (helpers)
+          for (int sl = 0; sl < 2; sl++)
+          {
+            st.pool.wait(st.in_latch[sl]);
+            st.pool.wait(st.out_latch[sl]);
+          }
+        return pipeline_failed(st);
+      };
       for (size_t c = 0; c < nchunks && r == MDCT_SUCCESS; c++)
       {
         const int sl = (int)(c & 1);
         if (c >= 2 && !drain(c - 2))
-          return pipeline_failed(st);
+          return abandon();
         const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
         const size_t off = r0 * strip, len = (r1 - r0) * strip;
         const uint8_t *h_in = pFrom + off; // pinned caller memory is DMA'd in place
         if (!pinned_in)
         {
-          memcpy(st.pin_in[sl], pFrom + off, len);
+          const size_t mine = helpers ? (len / 2) & ~(size_t)63 : len; // a helper copies the rest meanwhile
+          if (helpers)
+          {
+            st.in_latch[sl] = 1;
+            st.pool.push({nullptr, st.pin_in[sl] + mine, pFrom + off + mine, len - mine, &st.in_latch[sl]});
+          }
+          memcpy(st.pin_in[sl], pFrom + off, mine);
+          if (helpers)
+            st.pool.wait(st.in_latch[sl]);
           h_in = st.pin_in[sl];
         }
         if (hipMemcpyAsync(st.in + off, h_in, len, hipMemcpyHostToDevice, st.stream[sl]) != hipSuccess)
-          return pipeline_failed(st);
+          return abandon();
         r = mdct_fwd_quant_u8(st.in, st.out, sizeX, lut, sizeX, sizeY, r0, r1, layout, profile, st.stream[sl]);
         if (r == MDCT_SUCCESS && hipMemcpyAsync(pinned_out ? pTo + off : st.pin_out[sl], st.out + off, len, hipMemcpyDeviceToHost, st.stream[sl]) != hipSuccess)
-          return pipeline_failed(st);
+          return abandon();
+        if (helpers)
+        { // queued even when the launch failed: the slot's earlier copies still have to be waited for
+          const size_t out_len = pinned_out || r != MDCT_SUCCESS ? 0 : len, half = (out_len / 2) & ~(size_t)63;
+          st.out_latch[sl] = 2;
+          st.pool.push({st.stream[sl], pTo + off, st.pin_out[sl], half, &st.out_latch[sl]});
+          st.pool.push({st.stream[sl], pTo + off + half, st.pin_out[sl] + half, out_len - half, &st.out_latch[sl]});
+        }
       }
       if (r != MDCT_SUCCESS)
       {
-        (void)pipeline_failed(st);
+        (void)abandon();
         return (simdDctResult)r;
       }
       for (size_t c = nchunks >= 2 ? nchunks - 2 : 0; c < nchunks; c++)
         if (!drain(c))
-          return pipeline_failed(st);
+          return abandon();
       return sdr_Success;
     }
     (void)hipGetLastError(); // could not set the pipeline up: fall through to the plain path
