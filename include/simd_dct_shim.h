@@ -93,10 +93,13 @@ int mdct_shim_get_max_simd(void);
 /* stream (hipStream_t as void*) used for device-pointer calls, and whether they return before
  * completion.  Per HOST THREAD (every thread that calls the three functions has its own setting,
  * default: null stream, synchronous).  Host-pointer calls are synchronous and use the thread's
- * internal copy streams. */
+ * internal copy streams; for pageable q32 / scalar-encq calls larger than one ~4 MiB strip the
+ * calling thread also keeps three helper threads that share the copies between the caller's memory
+ * and the pinned bounce buffers (they sleep between calls and end with the thread or with
+ * mdct_shim_release()). */
 void mdct_shim_set_stream(void *stream);
 void mdct_shim_set_async(int enabled);
-/* frees the calling thread's staging buffers now (they are also freed when the thread exits) */
+/* frees the calling thread's staging buffers and ends its helper threads now (both also happen when the thread exits) */
 void mdct_shim_release(void);
 /* Optional: page-lock a caller-owned host buffer that is reused across calls (hipHostRegister).
  * Host-pointer calls then DMA to/from it in place instead of bouncing through the shim's pinned
