@@ -40,8 +40,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWG = 256;
 // k_scan: every wave works alone (wave-private LDS records), so the workgroup size only sets the LDS granule and the
 // dispatch rate; measured per source (profiles/r02_scan_workgroup_size.log)
-constexpr int scan_wg(int src) { return src == 1 || src == 2 ? 128 : 64; } // SRC_Q32, SRC_STEREO : SRC_I16, SRC_BLOCK
-constexpr int kQ32Grp = 520; // staged q32 group: 512 B + 8: a byte read of coefficient c touches banks 2g + 2c + {0,1}, distinct for the 8 groups
+constexpr int scan_wg(int src) { return src == 2 ? 128 : 64; } // SRC_STEREO : SRC_I16, SRC_Q32, SRC_BLOCK
 
 template <int SRC, bool RLE>
 __global__ __launch_bounds__(scan_wg(SRC)) void k_scan(ScanArgs a)
@@ -80,28 +79,13 @@ __global__ __launch_bounds__(scan_wg(SRC)) void k_scan(ScanArgs a)
     }
   }
   else if constexpr (SRC == SRC_Q32)
-  { // the wave's 64 blocks are 8 consecutive q32 groups = 4096 contiguous bytes [group][coef][8 blocks]
-    const uint8_t *p = static_cast<const uint8_t *>(a.src) + blk0 * 64;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-    {
-      const uint32_t o = (j * 64 + lane) * 16; // byte offset inside the 4 KiB
-      if (o < nvalid * 64)
-      {
-        const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + o));
-        uint32_t *d = reinterpret_cast<uint32_t *>(lv + o + (kQ32Grp - 512) * (o >> 9));
-        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint8_t *g = lv + (lane >> 3) * kQ32Grp + (lane & 7);
+  { // the wave's 64 blocks are 8 consecutive q32 groups [group][coef][8 blocks] = 4 KiB: coefficient c of the lane's block is
+    // one byte load, 8 x 8 contiguous bytes per wave instruction, all 64 instructions inside the same 32 cache lines.
+    // (Staging the 4 KiB through LDS with 16 B per lane loads and reading it back bytewise was 20 us slower.)
+    const uint8_t *p = static_cast<const uint8_t *>(a.src) + blk0 * 64 + (size_t)((valid ? lane : 0) >> 3) * 512 + ((valid ? lane : 0) & 7);
 #pragma unroll
     for (int c = 0; c < 64; c++)
-      val[c] = (int)g[c * 8] - 127; // simd_dct.cpp:2224: the stored byte carries a +127 bias
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // the staging area is reused for the records below
-    __builtin_amdgcn_wave_barrier();
+      val[c] = (int)p[c * 8] - 127;
   }
 
   else if constexpr (SRC == SRC_STEREO)
