@@ -91,10 +91,17 @@ __global__ __launch_bounds__(scan_wg(SRC)) void k_scan(ScanArgs a)
   else if constexpr (SRC == SRC_STEREO)
   { // 64 coefficient planes (simd_dct.cpp:1061-1099): coefficient c of stream position p at c * plane + p, so the
     // wave's 64 blocks are 64 consecutive bytes of every plane; bias +127 as in the q32 tier (:1020)
-    const uint8_t *p = static_cast<const uint8_t *>(a.src) + blk0 + (valid ? lane : 0);
+    // A wave-uniform base per plane (scalar adds) plus the lane's 32-bit offset: no per-lane 64-bit address arithmetic.
+    const uint8_t *p = static_cast<const uint8_t *>(a.src) + blk0;
+    const uint32_t l = valid ? lane : 0;
 #pragma unroll
     for (int c = 0; c < 64; c++)
-      val[c] = (int)p[(size_t)c * a.pitch] - 127;
+    { // readfirstlane pins the plane's base to scalar registers: global_load_ubyte v, v_lane, s[base]
+      const uint64_t b = reinterpret_cast<uint64_t>(p + (size_t)c * a.pitch);
+      typedef const uint8_t __attribute__((address_space(1))) *global_bytes; // keeps the load a global_load (not flat) after the integer round trip
+      const global_bytes pc = reinterpret_cast<global_bytes>((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32 | __builtin_amdgcn_readfirstlane((uint32_t)b));
+      val[c] = (int)pc[l] - 127;
+    }
   }
   else
   { // SRC_BLOCK (simd_dct.cpp:347-362): 64 contiguous bytes per block, coefficient (v,u) stored at u*8+v, bias +127/255*255
