@@ -583,14 +583,14 @@ __global__ __launch_bounds__(kWG, (SAFE || GENERAL) ? 1 : MDCT_Q32_MINW) void k_
 }
 
 // The other tiers / layouts.  Occupancy steering, measured optimum of {default, 3..6} waves/SIMD
-// (profiles/r02_u8_tiers_waves_per_eu.log): the SSE encq tier's half-written 4-byte stores like few
-// waves (38.8 us at 3, 42.7 unsteered), the scalar stereo tier 4 (46.1 vs 49.5); the others are best
-// left to the compiler (stereo/SSE 31.4 us unsteered, 34-36 steered).
+// (profiles/r02_u8_tiers_waves_per_eu.log): the SSE encq tier 4 (30.8 us; 31.2 at 3, 31.0 at 5, 32.9 unsteered, 37.6 at 6 --
+// with the pair-swapped 16-byte stores; its scattered dword stores before that took 38.8 at 3), the scalar stereo tier 4
+// (46.1 vs 49.5); the others are best left to the compiler (stereo/SSE 31.4 us unsteered, 34-36 steered).
 #ifdef MDCT_U8_WAVES
 #define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8_WAVES, MDCT_U8_WAVES)))
 #else
-constexpr int u8_waves_lo(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 3 : ((layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR) ? 4 : 1); }
-constexpr int u8_waves_hi(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 3 : ((layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR) ? 4 : 8); }
+constexpr int u8_waves_lo(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 4 : ((layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR) ? 4 : 1); }
+constexpr int u8_waves_hi(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 4 : ((layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR) ? 4 : 8); }
 #define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(u8_waves_lo(PROFILE, LAYOUT), u8_waves_hi(PROFILE, LAYOUT))))
 #endif
 template <int PROFILE, int LAYOUT, bool SAFE>
@@ -687,22 +687,36 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
     }
   }
   else
-  { // MDCT_LAYOUT_BLOCK_SSE (:1662-1676)
+  { // MDCT_LAYOUT_BLOCK_SSE (:1662-1676): of every 128-byte pair of blocks only the first 64 bytes are written -- for each
+    // coefficient row i8 the columns {0,1,4,5} of the even block, then of the odd block.  The two lanes of a pair swap
+    // halves (DPP) so that each stores 32 contiguous bytes as 2 x 16 B instead of eight scattered dwords.
     if (valid)
     {
-      const uint32_t ab = bx & 1;
-      uint8_t *base = a.to + (size_t)by * 8 * a.sizeX + (size_t)(bx >> 1) * 128 + ab * 4;
-      const bool spill = (by == a.by_last) && ((bx | 1u) == a.bpr - 1) && a.spill_ok;
+      const uint32_t ab = bx & 1; // sizeX % 16 == 0 for this tier: a pair is two neighbouring lanes of one block row
+      uint32_t L[8];
 #pragma unroll
       for (int i8 = 0; i8 < 8; i8++)
+        L[i8] = pack4_lo8(q[i8 * 8 + 0], q[i8 * 8 + 1], q[i8 * 8 + 4], q[i8 * 8 + 5]);
+      uint32_t w[8]; // this lane's 32 bytes: rows 0..3 (even block's lane) or 4..7 (odd block's lane), both blocks' dwords interleaved
+#pragma unroll
+      for (int j = 0; j < 4; j++)
       {
-        const uint32_t lo = pack4_lo8(q[i8 * 8 + 0], q[i8 * 8 + 1], q[i8 * 8 + 4], q[i8 * 8 + 5]);
-        *reinterpret_cast<uint32_t *>(base + i8 * 8) = lo;
-        if (spill)
-        {
-          const uint32_t hi = pack4_lo8(q[i8 * 8 + 2], q[i8 * 8 + 3], q[i8 * 8 + 6], q[i8 * 8 + 7]);
-          *reinterpret_cast<uint32_t *>(base + 128 + i8 * 8) = hi;
-        }
+        const uint32_t keep = ab ? L[4 + j] : L[j], give = ab ? L[j] : L[4 + j];
+        const uint32_t got = (uint32_t)__builtin_amdgcn_mov_dpp((int)give, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+        w[2 * j] = ab ? got : keep;
+        w[2 * j + 1] = ab ? keep : got;
+      }
+      uint8_t *pair = a.to + (size_t)by * 8 * a.sizeX + (size_t)(bx >> 1) * 128;
+      typedef unsigned int u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+      const u32x4_unaligned v0 = {w[0], w[1], w[2], w[3]}, v1 = {w[4], w[5], w[6], w[7]};
+      *reinterpret_cast<u32x4_unaligned *>(pair + ab * 32) = v0;
+      *reinterpret_cast<u32x4_unaligned *>(pair + ab * 32 + 16) = v1;
+      const bool spill = (by == a.by_last) && ((bx | 1u) == a.bpr - 1) && a.spill_ok;
+      if (spill)
+      { // the surviving spill of the plane's last pair (:1676): the other columns, one pair further
+#pragma unroll
+        for (int i8 = 0; i8 < 8; i8++)
+          *reinterpret_cast<uint32_t *>(pair + ab * 4 + 128 + i8 * 8) = pack4_lo8(q[i8 * 8 + 2], q[i8 * 8 + 3], q[i8 * 8 + 6], q[i8 * 8 + 7]);
       }
     }
   }
