@@ -557,6 +557,37 @@ def test_host_pointer_pipeline_multi_chunk():
         M.set_max_simd(M.SIMD_AVX2)
 
 
+def test_host_pipeline_helpers_under_four_concurrent_callers():
+    """four host threads, each on its own quarter of a 8192 x 8192 plane through the reference API with pageable memory:
+    every call runs the multi-chunk pipeline with its own three copy helpers (CopyPool, csrc/shim.hip); repeated, then a
+    thread that exits gives helpers and buffers back and a fresh one starts over"""
+    import threading
+
+    W, H = 8192, 8192
+    img = synth.plane_u8_np(W, H, "photo").reshape(-1)
+    lut = lut_x(2000)
+    out = np.full(W * H, CANARY, dtype=np.uint8)
+    errs = []
+
+    def work(y0, y1, reps):
+        for _ in range(reps):
+            rc = M.simdDCT_EncodeQuantize32ReorderBuffer(img, out, lut, W, 2 * H, y0, y1)  # sizeY = 2H: the whole plane is in range
+            if rc != 0:
+                errs.append(rc)
+
+    quarter = 2 * H // 4
+    for round_ in range(2):  # the second round runs on new threads: the first round's helpers ended with their threads
+        ts = [threading.Thread(target=work, args=(k * quarter, (k + 1) * quarter - 16, 3)) for k in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    assert not errs
+    want = np.zeros(W * H, dtype=np.uint8)
+    O.q32_native_par(img.reshape(H, W), lut, W, H, out=want)
+    assert np.array_equal(out, want)
+
+
 def test_stacked_batch_is_one_tall_plane():
     """config 4 usage: a batch of independent planes stacked in memory is transformed by ONE call on
     the tall plane (blocks are independent), identical to per-plane calls"""
