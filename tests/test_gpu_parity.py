@@ -792,7 +792,11 @@ def test_soak_random_differential():
     rng = np.random.default_rng(int(os.environ.get("MDCT_SOAK_SEED", "1")))
     combos = [("q32_avx", 64), ("stereo_sse", 16), ("stereo_scalar", 16), ("encq_sse", 16), ("encq_scalar", 8)]
     specials = [0.0, -0.7, 1e-6, 1e-30, np.inf, np.nan, 3e38]
+    progress = os.environ.get("MDCT_SOAK_PROGRESS")  # a file that gets one line every 5000 cases (long runs on a watched box)
     for it in range(n):
+        if progress and it % 5000 == 0:
+            with open(progress, "a") as f:
+                f.write(f"case {it} of {n}\n")
         beh, xm = combos[it % len(combos)]
         W = int(rng.integers(1, 24)) * xm
         H = int(rng.integers(1, 24)) * 16
