@@ -110,7 +110,7 @@ __global__ __launch_bounds__(scan_wg(SRC)) void k_scan(ScanArgs a)
 #pragma unroll
     for (int j = 0; j < 4; j++)
     {
-      const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + j * 16));
+      const u32x4 q = *reinterpret_cast<const u32x4 *>(p + j * 16); // plain, not non-temporal: the four pieces of a block share a cache line
       w[4 * j] = q.x; w[4 * j + 1] = q.y; w[4 * j + 2] = q.z; w[4 * j + 3] = q.w;
     }
 #pragma unroll
