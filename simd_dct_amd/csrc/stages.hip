@@ -99,7 +99,9 @@ __global__ __launch_bounds__(scan_wg(SRC)) void k_scan(ScanArgs a)
     { // readfirstlane pins the plane's base to scalar registers: global_load_ubyte v, v_lane, s[base]
       const uint64_t b = reinterpret_cast<uint64_t>(p + (size_t)c * a.pitch);
       typedef const uint8_t __attribute__((address_space(1))) *global_bytes; // keeps the load a global_load (not flat) after the integer round trip
-      const global_bytes pc = reinterpret_cast<global_bytes>((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32)) << 32 | __builtin_amdgcn_readfirstlane((uint32_t)b));
+      // (the builtin returns int: both halves go through uint32_t, or the low half's sign would smear over the high one)
+      const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32)), b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+      const global_bytes pc = reinterpret_cast<global_bytes>((uint64_t)b_hi << 32 | (uint64_t)b_lo);
       val[c] = (int)pc[l] - 127;
     }
   }

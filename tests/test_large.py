@@ -141,3 +141,91 @@ def test_codec_stages_beyond_4GiB():
     assert np.array_equal(got_n, wn)
     for r in range(P // 8):
         assert np.array_equal(got_s[r * stride:r * stride + wn[r]], ws[r * stride:r * stride + wn[r]]), r
+
+
+def test_operands_straddling_a_4GiB_address_boundary():
+    """address arithmetic, not sizes: each operand in turn of the byte-source scans, the fused records kernel, the Huffman
+    rows and the scan packer is placed so that its low 32 address bits cross 0x80000000 or wrap through 0 inside the
+    operand (a kernel that keeps half an address in 32 bits, or lets one sign-extend, faults or reads elsewhere)"""
+    arena = torch.zeros((5 << 30,), dtype=torch.uint8, device="cuda")  # contains one address of every residue mod 2^32
+    a0 = arena.data_ptr()
+
+    def hot(nbytes, into):
+        """a view of `nbytes` of the arena whose middle (rounded to 256 B) sits at an address == `into` (mod 2^32)"""
+        want = (into - (nbytes // 2 // 256) * 256) % (1 << 32)
+        start = a0 + ((want - a0) % (1 << 32))
+        assert start + nbytes <= a0 + arena.numel()
+        v = arena[start - a0:start - a0 + nbytes]
+        assert v.data_ptr() % (1 << 32) > (v.data_ptr() + nbytes - 1) % (1 << 32) or (v.data_ptr() % (1 << 32) < (1 << 31) <= (v.data_ptr() + nbytes - 1) % (1 << 32))
+        return v
+
+    def operands(sizes, which, into):
+        """device byte buffers of the given sizes: number `which` straddles the boundary, the others are ordinary allocations"""
+        return [hot(n, into) if k == which else torch.zeros((n,), dtype=torch.uint8, device="cuda") for k, n in enumerate(sizes)]
+
+    W, H = 1024, 512
+    nblk = (W // 8) * (H // 8)
+    ctb = (nblk + 255) // 256 * 256
+    lut8, lut2000, lut100 = lut_x(8), lut_x(2000), lut_x(100)
+    img_np = synth.plane_u8_np(W, H, "photo", seed=17)
+    d_img = torch.from_numpy(img_np.reshape(-1)).cuda()
+    stride = M.huffman_seg_stride(W)
+    wl, wr, wc = O.u8_records(img_np, W, H, lut=lut100)
+    ws, wn, _ = O.huffman_rows(wl, wr, wc, W, H)
+    wo, woff = O.jpeg_pack_rows(ws, wn, stride)
+    d_lv, d_rn, d_ct = torch.from_numpy(wl).cuda(), torch.from_numpy(wr).cuda(), torch.from_numpy(wc).cuda()
+    d_seg, d_nb = torch.from_numpy(ws).cuda(), torch.from_numpy(wn.view(np.int32)).cuda()
+    for into in (1 << 31, 0):
+        # the three byte layouts as sources of the scan: source, levels, runs, counts in turn on the boundary
+        for kind, layout, profile, lut, rows in (("q32", M.LAYOUT_Q32, M.PROFILE_REF_AVX, lut2000, H // 8), ("stereo", M.LAYOUT_STEREO, M.PROFILE_REF_SSE, lut8, H // 16),
+                                                 ("block", M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, lut8, H // 8)):
+            coded0 = torch.empty(W * H, dtype=torch.uint8, device="cuda")
+            M.fwd_quant_u8(d_img, coded0, lut, W, H, 0, rows, layout=layout, profile=profile)
+            want = O.zigzag_rle(kind, coded0.cpu().numpy(), W, H)
+            for which in range(4):
+                coded, lvb, rn, ctp = operands((W * H, nblk * 128, nblk * 64, ctb), which, into)
+                coded.copy_(coded0)
+                lv, rn, ct = lvb.view(torch.int16).reshape(nblk, 64), rn.reshape(nblk, 64), ctp[:nblk]
+                if kind == "q32":
+                    M.zigzag_rle_q32(coded, W, H, lv, rn, ct)
+                else:
+                    M.zigzag_rle_u8(coded, layout, W, H, lv, rn, ct)
+                for got, w in zip((lv, rn, ct), want):
+                    assert np.array_equal(got.cpu().numpy(), w), (kind, which, hex(into))
+        # the forward products themselves, input and output in turn
+        for beh, layout, profile, lut, rows in (("q32_avx", M.LAYOUT_Q32, M.PROFILE_REF_AVX, lut2000, H // 8), ("stereo_sse", M.LAYOUT_STEREO, M.PROFILE_REF_SSE, lut8, H // 16),
+                                                ("encq_sse", M.LAYOUT_BLOCK_SSE, M.PROFILE_REF_SSE, lut8, H // 8), ("encq_scalar", M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, lut8, H // 8)):
+            ref = torch.full((W * H,), CANARY, dtype=torch.uint8, device="cuda")
+            M.fwd_quant_u8(d_img, ref, lut, W, H, 0, rows, layout=layout, profile=profile)
+            for which in range(2):
+                src, dst = operands((W * H, W * H), which, into)
+                src.copy_(d_img)
+                dst.fill_(CANARY)
+                M.fwd_quant_u8(src, dst, lut, W, H, 0, rows, layout=layout, profile=profile)
+                assert torch.equal(dst, ref), (beh, which, hex(into))
+        # pixels -> records (fused)
+        for which in range(4):
+            src, lvb, rn, ctp = operands((W * H, nblk * 128, nblk * 64, ctb), which, into)
+            src.copy_(d_img)
+            lv, rn, ct = lvb.view(torch.int16).reshape(nblk, 64), rn.reshape(nblk, 64), ctp[:nblk]
+            M.fwd_u8_records(src, W, H, lv, rn, ct, lut=lut100)
+            assert np.array_equal(lv.cpu().numpy(), wl) and np.array_equal(rn.cpu().numpy(), wr) and np.array_equal(ct.cpu().numpy(), wc), (which, hex(into))
+        # records -> Huffman rows
+        for which in range(5):
+            lvb, rnb, ctp, seg, nbb = operands((nblk * 128, nblk * 64, ctb, (H // 8) * stride, 1024), which, into)
+            lv, rn, ct, nb = lvb.view(torch.int16).reshape(nblk, 64), rnb.reshape(nblk, 64), ctp[:nblk], nbb.view(torch.int32)[: H // 8]
+            lv.copy_(d_lv); rn.copy_(d_rn); ct.copy_(d_ct)
+            M.huffman_rows(lv, rn, ct, W, H, seg, nb)
+            gs = seg.cpu().numpy()
+            assert np.array_equal(nb.cpu().numpy().astype(np.uint32), wn), (which, hex(into))
+            for r in range(H // 8):
+                assert np.array_equal(gs[r * stride:r * stride + wn[r]], ws[r * stride:r * stride + wn[r]]), (which, r, hex(into))
+        # row segments -> packed scan
+        for which in range(4):
+            seg, nbb, scan, offb = operands(((H // 8) * stride, 1024, W * H, 4096), which, into)
+            nb, off = nbb.view(torch.int32)[: H // 8], offb.view(torch.int64)[: H // 8 + 1]
+            seg.copy_(d_seg); nb.copy_(d_nb)
+            M.jpeg_pack_rows(seg, nb, stride, H // 8, scan, off)
+            total = int(woff[-1])
+            assert np.array_equal(off.cpu().numpy().astype(np.uint64), woff) and np.array_equal(scan[:total].cpu().numpy(), wo[:total]), (which, hex(into))
+    del arena
