@@ -370,6 +370,8 @@ def main():
             hseg = torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda")
             hnb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
             extras["zigzag_rle_i16"] = rate(lambda i: M.zigzag_rle_i16(dsts[0], W, H, lv, rn, ct), 5 * W * H + nblk, n=100, warm=200)
+            extras["fwd_u8_records_fused"] = rate(lambda i: M.fwd_u8_records(u8s[i % NSETS], W, H, lv, rn, ct, lut=q60), 4 * W * H + nblk, n=100, warm=200)
+            M.zigzag_rle_i16(dsts[0], W, H, lv, rn, ct)  # back to the dense records the Huffman figure is quoted on
             extras["huffman_rows"] = rate(lambda i: M.huffman_rows(lv, rn, ct, W, H, hseg, hnb), 3 * W * H + nblk, n=100, warm=200)
             extras["huffman_rows"]["pairs_per_block"] = round(float(ct.float().mean()), 1)
             extras["huffman_rows"]["bits_per_px"] = round(float(hnb.sum()) * 8 / (W * H), 3)
