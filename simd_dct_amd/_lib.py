@@ -121,10 +121,11 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  simd_dct_amd has no CPU fallback."
         )
-    try:
-        import torch  # noqa: F401  (side effect: loads torch's HIP runtime before ours resolves)
-    except Exception:
-        pass
+    if os.environ.get("MDCT_NO_TORCH_PRELOAD") != "1":  # host-only users (e.g. the CPU multi-rank test's children) skip the import
+        try:
+            import torch  # noqa: F401  (side effect: loads torch's HIP runtime before ours resolves)
+        except Exception:
+            pass
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -8,6 +8,10 @@
 //
 // RCCL is bound at run time (dlopen of librccl.so.1; a copy already loaded by the process,
 // e.g. PyTorch's, is reused), so single-GPU users of libmdct_hip.so never load it.
+// MDCT_RCCL_LIB=<path> names the library to bind instead: a site's own RCCL build, or the
+// shared-memory stand-in tests/fake_rccl.c with which the multi-rank paths below (in-place
+// all-gather, ragged broadcasts, the 64 grouped stereo pieces) run with world > 1 on host
+// buffers on a machine without GPUs (tests/test_comm_multirank.py).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -15,6 +19,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "mdct.h"
@@ -36,6 +42,7 @@ struct Rccl
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok = false;
+  char why[256] = "symbols missing"; // dlerror() text of the failed load, captured once inside the call_once
 };
 
 Rccl g_rccl;
@@ -45,13 +52,23 @@ const Rccl *rccl()
 {
   std::call_once(g_rccl_once, [] {
     Rccl &r = g_rccl;
-    r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD); // the copy the process already uses, if any
+    const char *override_lib = getenv("MDCT_RCCL_LIB");
+    if (override_lib && *override_lib)
+      r.handle = dlopen(override_lib, RTLD_NOW | RTLD_LOCAL);
+    else
+    {
+      r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD); // the copy the process already uses, if any
+      if (!r.handle)
+        r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+      if (!r.handle)
+        r.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    }
     if (!r.handle)
-      r.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!r.handle)
-      r.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!r.handle)
+    {
+      const char *e = dlerror(); // one call: a second one returns NULL
+      snprintf(r.why, sizeof r.why, "%s", e ? e : "dlopen failed");
       return;
+    }
 #define MDCT_SYM(name) r.name = reinterpret_cast<decltype(r.name)>(dlsym(r.handle, "nccl" #name))
     MDCT_SYM(GetUniqueId);
     MDCT_SYM(CommInitRank);
@@ -67,7 +84,7 @@ const Rccl *rccl()
   return g_rccl.ok ? &g_rccl : nullptr;
 }
 
-int no_rccl() { return mdct_set_error(MDCT_NOT_SUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"); }
+int no_rccl() { return mdct_set_error(MDCT_NOT_SUPPORTED, "RCCL (librccl.so.1 or MDCT_RCCL_LIB) could not be bound: %s", g_rccl.why); }
 
 int nccl_fail(const Rccl *r, ncclResult_t e, const char *what) { return mdct_set_error(MDCT_NOT_SUPPORTED, "%s: %s", what, r->GetErrorString(e)); }
 
