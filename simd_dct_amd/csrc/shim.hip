@@ -7,13 +7,10 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
-#include <condition_variable>
 #include <cstring>
-#include <deque>
-#include <mutex>
-#include <thread>
 
 #include "mdct.h"
+#include "shim_host.h"
 #include "simd_dct_shim.h"
 
 // The reference's dispatchers read mutable CPU-flag globals (simd_platform.h:21-46, C linkage)
@@ -42,124 +39,34 @@ struct ThreadConfig
 };
 thread_local ThreadConfig tl_cfg;
 
+static_assert(MDCT_SIMD_NONE == mdct_host::LEVEL_NONE && MDCT_SIMD_SSE2 == mdct_host::LEVEL_SSE2 && MDCT_SIMD_SSSE3 == mdct_host::LEVEL_SSSE3 &&
+                  MDCT_SIMD_SSE41 == mdct_host::LEVEL_SSE41 && MDCT_SIMD_AVX2 == mdct_host::LEVEL_AVX2,
+              "shim_host.h restates the tier levels of simd_dct_shim.h");
+
 int effective_level()
-{
-  const int set = g_max_simd.load();
-  if (set >= 0)
-    return set;
-  if (&sse2Supported && &ssse3Supported && &sse41Supported && &avx2Supported && &avx512VLSupported)
-  {
-    if (avx512VLSupported || avx2Supported)
-      return MDCT_SIMD_AVX2;
-    if (sse41Supported && sse2Supported)
-      return MDCT_SIMD_SSE41;
-    if (ssse3Supported && sse2Supported)
-      return MDCT_SIMD_SSSE3;
-    if (sse2Supported)
-      return MDCT_SIMD_SSE2;
-    return MDCT_SIMD_NONE;
-  }
-  return MDCT_SIMD_AVX2;
+{ // (the addresses of undefined weak symbols are null)
+  return mdct_host::level_from_flags(g_max_simd.load(), &sse2Supported, &ssse3Supported, &sse41Supported, &avx2Supported, &avx512VLSupported);
 }
 
-// The host pipeline's extra hands.  Copying between the caller's pageable memory and the pinned bounce buffers is what
-// bounds a host-pointer call: one core sustains ~15 GB/s of memcpy, PCIe moves ~26 GB/s each way at once.  Three helper
-// threads per calling thread (started on first use, joined when the thread's staging is released) take (a) half of every
-// chunk's input copy and (b) the output copies -- wait for the chunk's stream, then pinned -> caller memory, in two halves
-// -- while the calling thread copies the next chunk's input.  A latch per pipeline slot and direction says when a
-// slot's buffers are free again.
-struct CopyPool
+// The HIP runtime as back end of the host-only pipeline logic (shim_host.h: CopyPool, StripPipeline -- the part of this
+// file that also runs under the CPU sanitizers, tests/shim_host_driver.cpp).  The per-call fields are set by run()
+// on the calling thread; helper threads use bind_thread() and stream_wait() only.
+struct HipDev
 {
-  struct Job
-  {
-    hipStream_t stream; // not null: wait for it first
-    uint8_t *dst;
-    const uint8_t *src;
-    size_t len;         // 0: nothing to copy (the data was DMA'd straight into pinned caller memory)
-    std::atomic<int> *latch;
-  };
-  enum { kThreads = 3 };
-  std::thread th[kThreads];
-  int started = 0;
-  std::mutex m;
-  std::condition_variable cv_job, cv_done;
-  std::deque<Job> q;
-  bool stop = false;
-  std::atomic<bool> failed{false};
+  typedef hipStream_t stream_t;
   int device = 0;
+  // the call being served
+  const uint8_t *d_in = nullptr;
+  uint8_t *d_out = nullptr;
+  const float *lut = nullptr;
+  size_t sizeX = 0, sizeY = 0;
+  int layout = 0, profile = 0;
 
-  void run()
-  {
-    (void)hipSetDevice(device);
-    for (;;)
-    {
-      Job j;
-      {
-        std::unique_lock<std::mutex> lk(m);
-        cv_job.wait(lk, [&] { return stop || !q.empty(); });
-        if (q.empty())
-          return;
-        j = q.front();
-        q.pop_front();
-      }
-      const bool ok = !j.stream || hipStreamSynchronize(j.stream) == hipSuccess;
-      if (ok && j.len)
-        memcpy(j.dst, j.src, j.len);
-      if (!ok)
-        failed = true;
-      {
-        std::lock_guard<std::mutex> lk(m); // the waiter checks the latch under this mutex: no lost wake-up
-        j.latch->fetch_sub(1);
-      }
-      cv_done.notify_all();
-    }
-  }
-  bool start(int dev)
-  {
-    if (started == kThreads)
-      return true;
-    if (started) // a partial start earlier: do without helpers
-      return false;
-    device = dev;
-    stop = false;
-    try
-    {
-      for (; started < kThreads; started++)
-        th[started] = std::thread([this] { run(); });
-    }
-    catch (...)
-    {
-      shutdown();
-      return false;
-    }
-    return true;
-  }
-  void push(const Job &j)
-  {
-    {
-      std::lock_guard<std::mutex> lk(m);
-      q.push_back(j);
-    }
-    cv_job.notify_one();
-  }
-  void wait(std::atomic<int> &latch)
-  {
-    std::unique_lock<std::mutex> lk(m);
-    cv_done.wait(lk, [&] { return latch.load() == 0; });
-  }
-  void shutdown()
-  {
-    {
-      std::lock_guard<std::mutex> lk(m);
-      stop = true;
-    }
-    cv_job.notify_all();
-    for (int i = 0; i < started; i++)
-      if (th[i].joinable())
-        th[i].join();
-    started = 0;
-    q.clear();
-  }
+  void bind_thread() { (void)hipSetDevice(device); }
+  bool stream_wait(hipStream_t s) { return hipStreamSynchronize(s) == hipSuccess; }
+  bool h2d_async(uint8_t *dev, const uint8_t *host, size_t n, hipStream_t s) { return hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, s) == hipSuccess; }
+  bool d2h_async(uint8_t *host, const uint8_t *dev, size_t n, hipStream_t s) { return hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, s) == hipSuccess; }
+  int launch(size_t r0, size_t r1, hipStream_t s) { return mdct_fwd_quant_u8(d_in, d_out, sizeX, lut, sizeX, sizeY, r0, r1, layout, profile, s); }
 };
 
 struct Staging
@@ -171,7 +78,8 @@ struct Staging
   size_t pin_cap = 0;
   hipStream_t stream[2] = {nullptr, nullptr};
   int device = -1;
-  CopyPool pool;
+  HipDev hip;
+  mdct_host::CopyPool<HipDev> pool;
   std::atomic<int> in_latch[2] = {{0}, {0}}, out_latch[2] = {{0}, {0}}; // outstanding helper jobs per pipeline slot
 
   void release()
@@ -266,19 +174,8 @@ PtrKind classify(const void *p)
 
 bool is_device_ptr(const void *p) { return classify(p) == PTR_DEVICE; }
 
-size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
-
-// Block rows the reference's loop `for (y = 0; y < sizeY/2; y += 8)` processes
-// (simd_dct.cpp:2243-2261): step = 16 for the `y*2` tiers, 8 for the scalar encq tier (:375-387).
-void ref_range(size_t sizeY, size_t startY, size_t endY, size_t step, size_t *b0, size_t *b1)
-{
-  const size_t rows = ceil_div(sizeY / 2, 8);
-  *b0 = ceil_div(startY, step);
-  const size_t last = endY / step + 1;
-  *b1 = last < rows ? last : rows;
-  if (*b0 > *b1)
-    *b0 = *b1;
-}
+using mdct_host::ceil_div;
+using mdct_host::ref_range; // simd_dct.cpp:2243-2261, :375-387
 
 // both pipeline streams idle before an error return: no copy may still target the caller's memory
 simdDctResult pipeline_failed(Staging &st)
@@ -337,77 +234,20 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
     rows_per_chunk = rows_per_chunk < 1 ? 1 : rows_per_chunk;
     if (reserve(st.in, st.in_cap, total) && reserve(st.out, st.out_cap, total) && reserve_pipeline(st, rows_per_chunk * strip))
     {
-      const size_t nchunks = ceil_div(b1 - b0, rows_per_chunk);
-      int r = MDCT_SUCCESS;
-      const bool helpers = nchunks > 1 && !(pinned_in && pinned_out) && st.pool.start(dev); // see CopyPool
-      if (helpers)
-        st.pool.failed = false;
-      auto drain = [&](size_t c) { // chunk c has left both bounce buffers of its slot; its output is with the caller
-        const int sl = (int)(c & 1);
-        if (helpers)
-        {
-          st.pool.wait(st.out_latch[sl]);
-          return !st.pool.failed.load();
-        }
-        const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
-        if (hipStreamSynchronize(st.stream[sl]) != hipSuccess)
-          return false;
-        if (!pinned_out)
-          memcpy(pTo + r0 * strip, st.pin_out[sl], (r1 - r0) * strip);
-        return true;
-      };
-      auto abandon = [&]() { // every job handed to the helpers finishes before the buffers are reused or freed
-        if (helpers)
-          for (int sl = 0; sl < 2; sl++)
-          {
-            st.pool.wait(st.in_latch[sl]);
-            st.pool.wait(st.out_latch[sl]);
-          }
+      st.hip.device = dev;
+      st.hip.d_in = st.in;
+      st.hip.d_out = st.out;
+      st.hip.lut = lut;
+      st.hip.sizeX = sizeX;
+      st.hip.sizeY = sizeY;
+      st.hip.layout = layout;
+      st.hip.profile = profile;
+      mdct_host::StripPipeline<HipDev> pl{&st.hip, &st.pool, pFrom, pTo, st.in, st.out, {st.pin_in[0], st.pin_in[1]}, {st.pin_out[0], st.pin_out[1]},
+                                          {st.stream[0], st.stream[1]}, st.in_latch, st.out_latch, strip, rows_per_chunk, pinned_in, pinned_out, true};
+      const int r = pl.run(b0, b1); // shim_host.h
+      if (r == mdct_host::PIPELINE_FAILED)
         return pipeline_failed(st);
-      };
-      for (size_t c = 0; c < nchunks && r == MDCT_SUCCESS; c++)
-      {
-        const int sl = (int)(c & 1);
-        if (c >= 2 && !drain(c - 2))
-          return abandon();
-        const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
-        const size_t off = r0 * strip, len = (r1 - r0) * strip;
-        const uint8_t *h_in = pFrom + off; // pinned caller memory is DMA'd in place
-        if (!pinned_in)
-        {
-          const size_t mine = helpers ? (len / 2) & ~(size_t)63 : len; // a helper copies the rest meanwhile
-          if (helpers)
-          {
-            st.in_latch[sl] = 1;
-            st.pool.push({nullptr, st.pin_in[sl] + mine, pFrom + off + mine, len - mine, &st.in_latch[sl]});
-          }
-          memcpy(st.pin_in[sl], pFrom + off, mine);
-          if (helpers)
-            st.pool.wait(st.in_latch[sl]);
-          h_in = st.pin_in[sl];
-        }
-        if (hipMemcpyAsync(st.in + off, h_in, len, hipMemcpyHostToDevice, st.stream[sl]) != hipSuccess)
-          return abandon();
-        r = mdct_fwd_quant_u8(st.in, st.out, sizeX, lut, sizeX, sizeY, r0, r1, layout, profile, st.stream[sl]);
-        if (r == MDCT_SUCCESS && hipMemcpyAsync(pinned_out ? pTo + off : st.pin_out[sl], st.out + off, len, hipMemcpyDeviceToHost, st.stream[sl]) != hipSuccess)
-          return abandon();
-        if (helpers)
-        { // queued even when the launch failed: the slot's earlier copies still have to be waited for
-          const size_t out_len = pinned_out || r != MDCT_SUCCESS ? 0 : len, half = (out_len / 2) & ~(size_t)63;
-          st.out_latch[sl] = 2;
-          st.pool.push({st.stream[sl], pTo + off, st.pin_out[sl], half, &st.out_latch[sl]});
-          st.pool.push({st.stream[sl], pTo + off + half, st.pin_out[sl] + half, out_len - half, &st.out_latch[sl]});
-        }
-      }
-      if (r != MDCT_SUCCESS)
-      {
-        (void)abandon();
-        return (simdDctResult)r;
-      }
-      for (size_t c = nchunks >= 2 ? nchunks - 2 : 0; c < nchunks; c++)
-        if (!drain(c))
-          return abandon();
-      return sdr_Success;
+      return (simdDctResult)r;
     }
     (void)hipGetLastError(); // could not set the pipeline up: fall through to the plain path
   }

@@ -91,6 +91,17 @@ def main():
     lut8 = (QUANTIZE_BASE * np.float32(8.0)).astype(np.float32)
     rc, out = O.run_behaviour("stereo_sse", img, lut8, W0, H0, 0, H0, use_reference=True)
     cfg0["stereo_sse__photo__8192x8192__x8"] = hashlib.sha256(out.tobytes()).hexdigest()
+    # the remaining tiers at the same size (bench.py verifies every timed u8 kernel against these).  "half" = the call
+    # main.cpp makes; "full" = the sizeY = 2H form.  The SSE encq tier's one surviving spill (simd_dct.cpp:1676) lands
+    # 64 bytes past a W*H buffer in the full form: the reference gets 64 spare bytes, the hash covers the W*H bytes.
+    rc, out = O.run_behaviour("stereo_scalar", img, lut8, W0, H0, 0, H0, use_reference=True)
+    cfg0["stereo_scalar__photo__8192x8192__x8"] = hashlib.sha256(out.tobytes()).hexdigest()
+    for beh in ("encq_sse", "encq_scalar"):
+        rc, out = O.run_behaviour(beh, img, lut8, W0, H0, 0, H0, use_reference=True)
+        cfg0[f"{beh}__photo__8192x8192__x8__half"] = hashlib.sha256(out.tobytes()).hexdigest()
+        big_out = np.zeros(W0 * H0 + 64, dtype=np.uint8)
+        O.run_behaviour(beh, img, lut8, W0, 2 * H0, 0, 2 * H0, out=big_out, use_reference=True)
+        cfg0[f"{beh}__photo__8192x8192__x8__full"] = hashlib.sha256(big_out[:W0 * H0].tobytes()).hexdigest()
     meta["config0_sha256"] = cfg0
     meta["tiers_verified_identical_to_the_fixtures"] = sorted(verified)
     np.savez_compressed(os.path.join(HERE, "ref_vectors.npz"), **vec)

@@ -1,0 +1,358 @@
+// shim_host_driver.cpp -- TEST INFRASTRUCTURE: the host-only logic of the drop-in shim (csrc/shim_host.h: ref_range,
+// level_from_flags, CopyPool, StripPipeline) on a back end made of worker-thread "streams" over plain heap memory,
+// built by tests/test_shim_host.py with -fsanitize=thread and with -fsanitize=address,undefined.  Every buffer is an
+// exact-size heap allocation that is freed the moment the pipeline returns, so a job that outlives its call, a copy
+// past a strip or a race between the helpers and the caller is a sanitizer report.
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "shim_host.h"
+
+using namespace mdct_host;
+
+#define CHECK(c)                                                     \
+  do                                                                 \
+  {                                                                  \
+    if (!(c))                                                        \
+    {                                                                \
+      fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); \
+      exit(1);                                                       \
+    }                                                                \
+  } while (0)
+
+// a "stream": one worker thread running queued closures in order
+struct FakeStream
+{
+  std::mutex m;
+  std::condition_variable cv, idle;
+  std::deque<std::function<void()>> q;
+  bool stop = false, busy = false;
+  std::thread th;
+  FakeStream() : th([this] { loop(); }) {}
+  ~FakeStream()
+  {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv.notify_all();
+    th.join();
+  }
+  void loop()
+  {
+    for (;;)
+    {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty())
+          return;
+        f = std::move(q.front());
+        q.pop_front();
+        busy = true;
+      }
+      f();
+      {
+        std::lock_guard<std::mutex> lk(m);
+        busy = false;
+      }
+      idle.notify_all();
+    }
+  }
+  void push(std::function<void()> f)
+  {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      q.push_back(std::move(f));
+    }
+    cv.notify_one();
+  }
+  void sync()
+  {
+    std::unique_lock<std::mutex> lk(m);
+    idle.wait(lk, [&] { return q.empty() && !busy; });
+  }
+};
+
+static uint8_t kernel_byte(uint8_t in, size_t i) { return (uint8_t)(in * 31u + (uint8_t)(i * 7u) + (uint8_t)(i >> 11)); }
+
+struct FakeDev
+{
+  typedef FakeStream *stream_t;
+  const uint8_t *d_in = nullptr;
+  uint8_t *d_out = nullptr;
+  size_t strip = 0;
+  // failure injection: the n-th call of each kind fails (counted from 0; -1 = never)
+  std::atomic<int> h2d_calls{0}, d2h_calls{0}, launch_calls{0}, wait_calls{0};
+  int fail_h2d = -1, fail_d2h = -1, fail_launch = -1, fail_wait = -1;
+  std::atomic<int> bound_threads{0};
+
+  void bind_thread() { bound_threads++; }
+  bool stream_wait(stream_t s)
+  {
+    s->sync();
+    return wait_calls++ != fail_wait;
+  }
+  bool h2d_async(uint8_t *dev, const uint8_t *host, size_t n, stream_t s)
+  {
+    if (h2d_calls++ == fail_h2d)
+      return false;
+    s->push([=] { memcpy(dev, host, n); });
+    return true;
+  }
+  bool d2h_async(uint8_t *host, const uint8_t *dev, size_t n, stream_t s)
+  {
+    if (d2h_calls++ == fail_d2h)
+      return false;
+    s->push([=] { memcpy(host, dev, n); });
+    return true;
+  }
+  int launch(size_t r0, size_t r1, stream_t s)
+  {
+    if (launch_calls++ == fail_launch)
+      return 2; // "not supported", like a failed kernel launch
+    const uint8_t *in = d_in;
+    uint8_t *out = d_out;
+    const size_t st = strip;
+    s->push([=] {
+      for (size_t i = r0 * st; i < r1 * st; i++)
+        out[i] = kernel_byte(in[i], i);
+    });
+    return 0;
+  }
+};
+
+// one calling thread's staging, as thread_local Staging of shim.hip: everything exact-size on the heap
+struct Rig
+{
+  size_t strip, rows, rpc;
+  std::unique_ptr<uint8_t[]> d_in, d_out, pin_in[2], pin_out[2];
+  FakeStream streams[2];
+  FakeDev dev;
+  CopyPool<FakeDev> pool;
+  std::atomic<int> in_latch[2] = {{0}, {0}}, out_latch[2] = {{0}, {0}};
+  Rig(size_t strip_, size_t rows_, size_t rpc_) : strip(strip_), rows(rows_), rpc(rpc_)
+  {
+    d_in.reset(new uint8_t[strip * rows]);
+    d_out.reset(new uint8_t[strip * rows]);
+    for (int i = 0; i < 2; i++)
+    {
+      pin_in[i].reset(new uint8_t[strip * rpc]);
+      pin_out[i].reset(new uint8_t[strip * rpc]);
+    }
+    dev.d_in = d_in.get();
+    dev.d_out = d_out.get();
+    dev.strip = strip;
+  }
+  int run(const uint8_t *from, uint8_t *to, size_t b0, size_t b1, bool helpers, bool pinned_in, bool pinned_out)
+  {
+    StripPipeline<FakeDev> pl{&dev, &pool, from, to, d_in.get(), d_out.get(), {pin_in[0].get(), pin_in[1].get()}, {pin_out[0].get(), pin_out[1].get()},
+                              {&streams[0], &streams[1]}, in_latch, out_latch, strip, rpc, pinned_in, pinned_out, helpers};
+    return pl.run(b0, b1);
+  }
+  bool quiescent()
+  {
+    std::lock_guard<std::mutex> lk(pool.m);
+    return pool.q.empty() && in_latch[0] == 0 && in_latch[1] == 0 && out_latch[0] == 0 && out_latch[1] == 0;
+  }
+};
+
+static std::vector<uint8_t> make_plane(size_t n, unsigned seed)
+{
+  std::vector<uint8_t> v(n);
+  unsigned x = seed * 2654435761u + 12345u;
+  for (size_t i = 0; i < n; i++)
+  {
+    x = x * 1664525u + 1013904223u;
+    v[i] = (uint8_t)(x >> 24);
+  }
+  return v;
+}
+
+static void check_rows(const std::vector<uint8_t> &in, const uint8_t *out, size_t strip, size_t rows, size_t b0, size_t b1, uint8_t canary)
+{
+  for (size_t i = 0; i < strip * rows; i++)
+  {
+    const size_t r = i / strip;
+    const uint8_t want = (r >= b0 && r < b1) ? kernel_byte(in[i], i) : canary;
+    if (out[i] != want)
+    {
+      fprintf(stderr, "byte %zu (row %zu): got %u want %u\n", i, r, out[i], want);
+      exit(1);
+    }
+  }
+}
+
+static void test_single_caller()
+{
+  const size_t strip = 1024;
+  for (size_t rows : {1, 2, 3, 7, 16})
+    for (size_t rpc : {1, 2, 3})
+      for (int helpers = 0; helpers < 2; helpers++)
+        for (int pins = 0; pins < 4; pins++)
+        {
+          const std::vector<uint8_t> in = make_plane(strip * rows, (unsigned)(rows * 16 + rpc));
+          std::unique_ptr<uint8_t[]> out(new uint8_t[strip * rows]);
+          for (size_t b0 = 0; b0 < rows; b0 += (rows > 4 ? 3 : 1))
+          {
+            memset(out.get(), 0xC3, strip * rows);
+            Rig rig(strip, rows, rpc);
+            CHECK(rig.run(in.data(), out.get(), b0, rows, helpers, pins & 1, pins & 2) == PIPELINE_OK);
+            CHECK(rig.quiescent());
+            check_rows(in, out.get(), strip, rows, b0, rows, 0xC3);
+          }
+        }
+  puts("single caller: ok");
+}
+
+// the reference's intended multi-core use: concurrent calls on disjoint row ranges of the SAME planes
+static void test_four_callers()
+{
+  const size_t strip = 4096, rows = 64, rpc = 3, T = 4;
+  const std::vector<uint8_t> in = make_plane(strip * rows, 77);
+  std::unique_ptr<uint8_t[]> out(new uint8_t[strip * rows]);
+  memset(out.get(), 0x5A, strip * rows);
+  std::vector<std::thread> th;
+  std::atomic<int> bad{0};
+  for (size_t t = 0; t < T; t++)
+    th.emplace_back([&, t] {
+      Rig rig(strip, rows, rpc); // per-thread staging, like thread_local Staging
+      for (int rep = 0; rep < 3; rep++)
+        if (rig.run(in.data(), out.get(), rows * t / T, rows * (t + 1) / T, true, false, false) != PIPELINE_OK)
+          bad++;
+      if (!rig.quiescent())
+        bad++;
+    }); // the Rig dies here: helper threads joined, buffers freed
+  for (auto &x : th)
+    x.join();
+  CHECK(bad == 0);
+  check_rows(in, out.get(), strip, rows, 0, rows, 0x5A);
+  puts("four callers on disjoint ranges: ok");
+}
+
+// early-error paths: whatever fails, on return nothing is queued, no latch is up, both streams are idle -- the
+// buffers are freed right after the call, so a straggler would be a use-after-free / race report
+static void test_failures()
+{
+  const size_t strip = 2048, rows = 9, rpc = 2;
+  const std::vector<uint8_t> in = make_plane(strip * rows, 5);
+  for (int helpers = 0; helpers < 2; helpers++)
+    for (int kind = 0; kind < 4; kind++)
+      for (int at = 0; at < 5; at++)
+      {
+        std::unique_ptr<uint8_t[]> out(new uint8_t[strip * rows]);
+        memset(out.get(), 0x11, strip * rows);
+        int r;
+        {
+          Rig rig(strip, rows, rpc);
+          if (kind == 0) rig.dev.fail_h2d = at;
+          if (kind == 1) rig.dev.fail_d2h = at;
+          if (kind == 2) rig.dev.fail_launch = at;
+          if (kind == 3) rig.dev.fail_wait = at;
+          r = rig.run(in.data(), out.get(), 0, rows, helpers, false, false);
+          CHECK(rig.quiescent());
+          {
+            std::lock_guard<std::mutex> a(rig.streams[0].m), b(rig.streams[1].m);
+            CHECK(rig.streams[0].q.empty() && rig.streams[1].q.empty() && !rig.streams[0].busy && !rig.streams[1].busy);
+          }
+          if (kind == 2)
+            CHECK(r == 2);
+          else if (kind == 3 && at >= (helpers ? 10 : 5)) // (never: at < 5 always lands on a wait that exists)
+            CHECK(r == PIPELINE_OK);
+          else
+            CHECK(r == PIPELINE_FAILED || r == PIPELINE_OK); // a failing wait during abandon()'s own drain does not change a success
+        } // rig and its buffers are gone
+        out.reset();
+      }
+  puts("early-error paths: ok");
+}
+
+// a thread that exits with jobs still queued: shutdown() serves them all before the helpers leave
+static void test_exit_with_jobs_queued()
+{
+  for (int rep = 0; rep < 20; rep++)
+  {
+    FakeDev dev;
+    FakeStream s;
+    std::vector<uint8_t> src = make_plane(1 << 16, (unsigned)rep), dst(1 << 16, 0);
+    std::atomic<int> latch{64};
+    {
+      CopyPool<FakeDev> pool;
+      CHECK(pool.start(&dev));
+      for (int i = 0; i < 64; i++)
+        pool.push({(i & 1) != 0, &s, dst.data() + i * 1024, src.data() + i * 1024, 1024, &latch});
+    } // ~CopyPool with most of the 64 jobs still queued
+    CHECK(latch == 0 && dst == src);
+    CHECK(dev.bound_threads == CopyPool<FakeDev>::kThreads);
+  }
+  puts("exit with jobs queued: ok");
+}
+
+// ref_range against the reference's own loop (simd_dct.cpp:2243-2261 with y*2, :375-387 without)
+static void test_ref_range()
+{
+  for (size_t sizeY = 0; sizeY <= 160; sizeY += 8)
+    for (size_t startY = 0; startY <= sizeY + 24; startY++)
+      for (size_t endY = 0; endY <= sizeY + 24; endY++)
+        for (size_t step : {(size_t)16, (size_t)8})
+        {
+          std::vector<size_t> rows;
+          for (size_t y = 0; y < sizeY / 2; y += 8)
+          {
+            const size_t yy = step == 16 ? y * 2 : y;
+            if (yy < startY)
+              continue;
+            else if (yy > endY)
+              break;
+            rows.push_back(y / 8);
+          }
+          size_t b0, b1;
+          ref_range(sizeY, startY, endY, step, &b0, &b1);
+          CHECK(b1 - b0 == rows.size());
+          if (!rows.empty())
+            CHECK(rows.front() == b0 && rows.back() + 1 == b1);
+        }
+  puts("ref_range == the reference's loop: ok");
+}
+
+// level_from_flags against the three dispatchers' if-chains (simd_dct.cpp:78-85, :100-105, :120-127)
+static void test_levels()
+{
+  for (int m = 0; m < 32; m++)
+  {
+    const bool sse2 = m & 1, ssse3 = m & 2, sse41 = m & 4, avx2 = m & 8, avx512vl = m & 16;
+    const int lv = level_from_flags(-1, &sse2, &ssse3, &sse41, &avx2, &avx512vl);
+    // q32 (:120-127): AVX-512VL -> AVX2 -> [SSE4.1 variant, not reproduced] -> not supported
+    CHECK((lv >= LEVEL_AVX2) == (avx512vl || avx2));
+    if (!(avx512vl || avx2))
+    {
+      // stereo (:78-85): sse41&&sse2 -> ssse3&&sse2 -> sse2 -> scalar: SSE bytes iff any of them
+      const bool stereo_sse = (sse41 && sse2) || (ssse3 && sse2) || sse2;
+      CHECK((lv >= LEVEL_SSE2) == stereo_sse);
+      // encq (:100-105): sse41&&sse2 -> ssse3&&sse2 -> scalar
+      const bool encq_sse = (sse41 && sse2) || (ssse3 && sse2);
+      CHECK((lv >= LEVEL_SSSE3) == encq_sse);
+    }
+  }
+  CHECK(level_from_flags(-1, nullptr, nullptr, nullptr, nullptr, nullptr) == LEVEL_AVX2);
+  const bool f = false;
+  CHECK(level_from_flags(LEVEL_SSE2, &f, &f, &f, &f, &f) == LEVEL_SSE2);
+  CHECK(level_from_flags(-1, &f, &f, &f, &f, &f) == LEVEL_NONE); // all-false until _DetectCPUFeatures()
+  puts("tier choice == the dispatchers: ok");
+}
+
+int main()
+{
+  test_ref_range();
+  test_levels();
+  test_single_caller();
+  test_four_callers();
+  test_failures();
+  test_exit_with_jobs_queued();
+  puts("shim host ok");
+  return 0;
+}

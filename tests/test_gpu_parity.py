@@ -739,6 +739,27 @@ def test_config0_full_size_hash_of_the_real_reference(golden):
     out.zero_()
     assert M.simdDCT_EncodeQuantizeReorderStereoBuffer(img, out, lut_x(8), W, H, 0, H) == 0
     assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == meta["config0_sha256"]["stereo_sse__photo__8192x8192__x8"]
+    # the remaining tiers: main.cpp's own calls through the drop-in API under its --max-simd caps ("half"), and the
+    # whole plane through the native entry point ("full": what bench.py times and hashes)
+    sha = meta["config0_sha256"]
+    try:
+        out.zero_()
+        assert M.simdDCT_EncodeQuantizeBuffer(img, out, lut_x(8), W, H, 0, H) == 0
+        assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == sha["encq_sse__photo__8192x8192__x8__half"]
+        M.set_max_simd(0)  # --max-simd none: the scalar tiers
+        out.zero_()
+        assert M.simdDCT_EncodeQuantizeBuffer(img, out, lut_x(8), W, H, 0, H) == 0
+        assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == sha["encq_scalar__photo__8192x8192__x8__half"]
+        out.zero_()
+        assert M.simdDCT_EncodeQuantizeReorderStereoBuffer(img, out, lut_x(8), W, H, 0, H) == 0
+        assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == sha["stereo_scalar__photo__8192x8192__x8"]
+    finally:
+        M.set_max_simd(M.SIMD_AVX2)
+    for layout, profile, key in ((M.LAYOUT_BLOCK_SSE, M.PROFILE_REF_SSE, "encq_sse__photo__8192x8192__x8__full"),
+                                 (M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, "encq_scalar__photo__8192x8192__x8__full")):
+        out.zero_()
+        M.fwd_quant_u8(img, out, lut_x(8), W, H, 0, H // 8, layout=layout, profile=profile)
+        assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == sha[key], key
 
 
 def test_u8_i16_codec_pair_matches_oracle():

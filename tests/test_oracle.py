@@ -248,6 +248,25 @@ def test_config0_full_size_reference_cpu_path(golden):
         assert np.array_equal(ref, out)
 
 
+def test_config0_full_size_every_behaviour_hashes_to_the_real_reference(golden):
+    """the other four behaviours at 8192x8192: the restatement (no reference needed) reproduces the SHA-256 the REAL
+    reference's bytes were recorded under (tests/golden/make_golden.py) -- the hashes bench.py checks the GPU against"""
+    meta, _ = golden
+    sha = meta["config0_sha256"]
+    W = H = 8192
+    img = synth.plane_u8_np(W, H, "photo")
+    lut8 = (QUANTIZE_BASE * np.float32(8)).astype(np.float32)
+    for beh in ("stereo_sse", "stereo_scalar"):
+        rc, out = O.run_behaviour(beh, img, lut8, W, H, 0, H)
+        assert rc == 0 and hashlib.sha256(out.tobytes()).hexdigest() == sha[f"{beh}__photo__8192x8192__x8"], beh
+    for beh in ("encq_sse", "encq_scalar"):
+        rc, out = O.run_behaviour(beh, img, lut8, W, H, 0, H)  # main.cpp's call: top half
+        assert rc == 0 and hashlib.sha256(out.tobytes()).hexdigest() == sha[f"{beh}__photo__8192x8192__x8__half"], beh
+        big = np.zeros(W * H + 64, dtype=np.uint8)  # sizeY = 2H form; 64 spare bytes take the SSE tier's surviving spill (:1676)
+        rc, _ = O.run_behaviour(beh, img, lut8, W, 2 * H, 0, 2 * H, out=big)
+        assert rc == 0 and hashlib.sha256(big[:W * H].tobytes()).hexdigest() == sha[f"{beh}__photo__8192x8192__x8__full"], beh
+
+
 def test_oracle_under_address_and_ub_sanitizers(tmp_path):
     """the checker itself is memory-safe: every entry point on exact-size heap buffers under
     ASan + UBSan (CPU only; GPU sanitizers are not available on the pool)"""

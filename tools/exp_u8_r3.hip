@@ -1,0 +1,268 @@
+// exp_u8_r3.hip -- round-3 diagnostics and A/B harness for the u8 kernels (q32 first).
+//   timeline   the product q32 body with s_memrealtime / s_memtime stamps at the phase boundaries of every wave
+//              (0 entry, 1 rows arrived, 2 transform done + bytes staged in LDS, 3 read back + stores issued, 4 stores acknowledged) and the
+//              wave's placement (HW_ID, XCC_ID) -> gpurun_out/q32_timeline.bin, analysed by tools/q32_timeline.py.
+//              A diagnostic build: the stamped kernel is never the product.
+//   ab         variants against the product kernel's bytes, interleaved rounds in one process
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -Iinclude -Isimd_dct_amd/csrc tools/exp_u8_r3.hip -o tools/exp_u8_r3
+#include "../simd_dct_amd/csrc/mdct_kernels.hip"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <vector>
+using namespace mdct;
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+#define GETREG(id) __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | (id))
+struct Stamp
+{
+  uint32_t hw_id, xcc_id, wave_t0, pad;
+  uint32_t rt[6]; // s_memrealtime (100 MHz, chip-wide), low 32 bits
+  uint32_t ck[6]; // s_memtime (shader clock of the XCD), low 32 bits
+};
+static_assert(sizeof(Stamp) == 64, "16 dwords per wave");
+
+// the stamp leaves at once (lane 0, 8 bytes): the kernel's SGPRs are full of quantiser multipliers, held stamps would spill
+#define STAMP(i)                                                                                       \
+  do                                                                                                   \
+  {                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    const uint32_t rt_ = (uint32_t)__builtin_amdgcn_s_memrealtime();                                   \
+    const uint32_t ck_ = (uint32_t)__builtin_amdgcn_s_memtime();                                       \
+    if ((threadIdx.x & 63) == 0)                                                                       \
+    {                                                                                                  \
+      Stamp *st_ = stamps + ((blockIdx.x * kWG + (threadIdx.x & ~63u)) >> 6);                          \
+      st_->rt[i] = rt_;                                                                                \
+      st_->ck[i] = ck_;                                                                                \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+  } while (0)
+
+// the product kernel's fast path (k_q32_avx<false,false>), stamped
+template <int MINW>
+__global__ __launch_bounds__(kWG, MINW) void v_timeline(U8Args a, Stamp *stamps)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWG / 64][64 * kQ32RowStride];
+  STAMP(0);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t wave_t0 = blockIdx.x * kWG + wave * 64;
+  const uint32_t t = wave_t0 + lane;
+  uint32_t q[64];
+  {
+    const uint32_t row = t / a.bpr;
+    const uint32_t bx = t - row * a.bpr;
+    uint2 rows[8];
+    load_block_rows(a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)bx * 8, a.pitch, rows);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(1);
+    encode_block_avx_pk<false>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
+  }
+  uint8_t *wl = lds[wave];
+#pragma unroll
+  for (int c = 0; c < 64; c++)
+    wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  uint8_t *outw = a.to + ((size_t)a.by0 * a.bpr + wave_t0) * 64;
+  const uint32_t c2 = (lane & 31) * 2;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // transform done and all 64 byte writes landed (the compiler interleaves them, as in the product)
+  STAMP(2);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const uint32_t g = 2 * k + (lane >> 5);
+    const uint2 lo = *reinterpret_cast<const uint2 *>(wl + c2 * kQ32RowStride + g * 8);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(wl + (c2 + 1) * kQ32RowStride + g * 8);
+    const u32x4_t v = ~u32x4_t{lo.x, lo.y, hi.x, hi.y};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t *>(outw + g * 512 + c2 * 8));
+  }
+  STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(4);
+  if (lane == 0)
+  {
+    Stamp *s = stamps + (wave_t0 >> 6);
+    s->hw_id = GETREG(4);
+    s->xcc_id = GETREG(20);
+    s->wave_t0 = wave_t0;
+    s->pad = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Variant: stores issued as soon as their coefficient pairs exist (review item ii).  The column
+// pairs are processed in the order j = 0, 2, 3, 1 so that after two of them the coefficients
+// (v, 0) and (v, 1) of all v are complete (one quarter of the wave's 16-byte chunks), after the
+// third (v, 4), (v, 5), after the fourth the rest.
+// ---------------------------------------------------------------------------------------
+template <int MINW>
+__global__ __launch_bounds__(kWG, MINW) void v_early(U8Args a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[kWG / 64][64 * kQ32RowStride];
+  const PkConsts &K = reinterpret_cast<const PkConsts &>(a.pk);
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t wave_t0 = blockIdx.x * kWG + wave * 64;
+  const uint32_t t = wave_t0 + lane;
+  const uint32_t row = t / a.bpr;
+  const uint32_t bx = t - row * a.bpr;
+  uint2 rows[8];
+  load_block_rows(a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)bx * 8, a.pitch, rows);
+  f32x2 col[4][8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    const f32x2 a01 = {ubyte_to_float<0>(rows[r].x), ubyte_to_float<1>(rows[r].x)};
+    const f32x2 a23 = {ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
+    const f32x2 a45 = {ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)};
+    const f32x2 a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
+    dct8_h<K_AVX>(K, a01, a23, a45, a67, col[0][r], col[1][r], col[2][r], col[3][r]);
+  }
+  uint8_t *wl = lds[wave];
+  uint8_t *outw = a.to + ((size_t)a.by0 * a.bpr + wave_t0) * 64;
+  // 8-byte pieces: lane l of store s handles coefficient c = ..., group g: [coef c][8 blocks of group g] = 8 contiguous output bytes at g*512 + c*8
+  auto quant_stage = [&](auto j_) {
+    constexpr int j = decltype(j_)::value;
+    dct8_v<K_AVX>(K, col[j]);
+#pragma unroll
+    for (int v = 0; v < 8; v++)
+    {
+      const f32x2 qp = reinterpret_cast<const f32x2 *>(a.qt.q)[v * 4 + j];
+      f32x2 m, tt;
+      MDCT_PKM(m, col[j][v], qp, MDCT_K_LH);
+      m.x = __builtin_amdgcn_fmed3f(m.x, -128.0f, 127.0f);
+      m.y = __builtin_amdgcn_fmed3f(m.y, -128.0f, 127.0f);
+      MDCT_PKA(tt, m, K.nm, MDCT_K_HH);
+      wl[(v * 8 + kPairA[j]) * kQ32RowStride + lane] = (uint8_t)__float_as_uint(tt.x);
+      wl[(v * 8 + kPairB[j]) * kQ32RowStride + lane] = (uint8_t)__float_as_uint(tt.y);
+    }
+  };
+  // coefficients (v, u0) and (v, u0+1) for the lane's v: 16 contiguous bytes per (group, v)
+  auto store_pair = [&](int u0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t g = lane >> 3, v = lane & 7; // 8 groups x 8 coefficient rows = 64 lanes
+    const uint32_t c = v * 8 + u0;
+    const uint2 lo = *reinterpret_cast<const uint2 *>(wl + c * kQ32RowStride + g * 8);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(wl + (c + 1) * kQ32RowStride + g * 8);
+    const u32x4_t w = ~u32x4_t{lo.x, lo.y, hi.x, hi.y};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t *>(outw + g * 512 + c * 8));
+  };
+  using std::integral_constant;
+  quant_stage(integral_constant<int, 0>{}); // u = 0, 4
+  quant_stage(integral_constant<int, 2>{}); // u = 1, 3
+  store_pair(0);
+  quant_stage(integral_constant<int, 3>{}); // u = 5, 7
+  store_pair(4);
+  quant_stage(integral_constant<int, 1>{}); // u = 2, 6
+  store_pair(2);
+  store_pair(6);
+}
+
+int main(int argc, char **argv)
+{
+  const char *mode = argc > 1 ? argv[1] : "ab";
+  const size_t W = 8192, H = 8192, bytes = W * H;
+  const int NS = 4;
+  std::vector<uint8_t *> A(NS), B(NS);
+  std::vector<uint8_t> host(W * H);
+  for (size_t i = 0; i < W * H; i++) host[i] = (uint8_t)((i * 2654435761u) >> 24);
+  for (int i = 0; i < NS; i++)
+  {
+    if (hipMalloc(&A[i], bytes + 64) != hipSuccess || hipMalloc(&B[i], bytes) != hipSuccess) { puts("alloc failed"); return 1; }
+    hipMemcpy(A[i], host.data(), bytes, hipMemcpyHostToDevice);
+  }
+  U8Args a;
+  memset(&a, 0, sizeof(a));
+  a.consts = DctConsts();
+  float q[64];
+  for (int i = 0; i < 64; i++) q[i] = 255.0f / ((0.1f + 0.01f * i) * 2000 * 0.95f);
+  a.pitch = W; a.sizeX = W; a.out_strip = 8 * W; a.out_tight = 1; a.bpr = W / 8; a.by0 = 0; a.nblocks = (uint32_t)(W / 8 * H / 8);
+  const float magicC = 12582912.0f + 128.0f;
+  for (int v = 0; v < 8; v++)
+    for (int j = 0; j < 4; j++)
+    {
+      a.qt.q[(v * 4 + j) * 2] = -q[v * 8 + kPairA[j]];
+      a.qt.q[(v * 4 + j) * 2 + 1] = -q[v * 8 + kPairB[j]];
+    }
+  a.pk = PkConstsArg{{a.consts.a, a.consts.f}, {a.consts.c, a.consts.d}, {a.consts.b, a.consts.e}, {a.consts.n, magicC}};
+  auto args = [&](int s) { U8Args x = a; x.from = A[s]; x.to = B[s]; return x; };
+  const uint32_t nwg = a.nblocks / 256, nwaves = a.nblocks / 64;
+
+  if (!strcmp(mode, "timeline"))
+  {
+    Stamp *d;
+    hipMalloc(&d, sizeof(Stamp) * nwaves);
+    // steady state first (power management), then ONE stamped launch directly behind product launches
+    for (int i = 0; i < 1500; i++) launch_fwd_quant_u8(args(i % NS), MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX, false, 0);
+    for (int rep = 0; rep < 3; rep++)
+    {
+      for (int i = 0; i < 50; i++) launch_fwd_quant_u8(args(i % NS), MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX, false, 0);
+      hipLaunchKernelGGL((v_timeline<6>), dim3(nwg), dim3(256), 0, 0, args(rep % NS), d);
+    }
+    hipDeviceSynchronize();
+    std::vector<Stamp> hs(nwaves);
+    hipMemcpy(hs.data(), d, sizeof(Stamp) * nwaves, hipMemcpyDeviceToHost);
+    const char *path = argc > 2 ? argv[2] : "gpurun_out/q32_timeline.bin";
+    FILE *f = fopen(path, "wb");
+    if (!f) { perror(path); return 1; }
+    fwrite(hs.data(), sizeof(Stamp), nwaves, f);
+    fclose(f);
+    // bytes of the stamped kernel == product
+    std::vector<uint8_t> ref(bytes), got(bytes);
+    launch_fwd_quant_u8(args(0), MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX, false, 0);
+    hipMemcpy(ref.data(), B[0], bytes, hipMemcpyDeviceToHost);
+    hipMemset(B[0], 0x55, bytes);
+    hipLaunchKernelGGL((v_timeline<6>), dim3(nwg), dim3(256), 0, 0, args(0), d);
+    hipMemcpy(got.data(), B[0], bytes, hipMemcpyDeviceToHost);
+    printf("timeline kernel %s; %u waves -> %s\n", memcmp(ref.data(), got.data(), bytes) ? "!! MISMATCH" : "bit-exact", nwaves, path);
+    return 0;
+  }
+
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  struct V { const char *name; std::function<void(int)> f; std::vector<float> t; bool check; };
+  std::vector<V> vs;
+  vs.push_back({"product q32", [&](int s) { launch_fwd_quant_u8(args(s), MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX, false, 0); }, {}, false});
+  vs.push_back({"early stores 6w", [&](int s) { hipLaunchKernelGGL((v_early<6>), dim3(nwg), dim3(256), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"early stores 5w", [&](int s) { hipLaunchKernelGGL((v_early<5>), dim3(nwg), dim3(256), 0, 0, args(s)); }, {}, true});
+  {
+    std::vector<uint8_t> ref(bytes), got(bytes);
+    vs[0].f(0); hipMemcpy(ref.data(), B[0], bytes, hipMemcpyDeviceToHost);
+    for (auto &v : vs)
+    {
+      if (!v.check) continue;
+      hipMemset(B[0], 0x55, bytes);
+      v.f(0);
+      if (hipMemcpy(got.data(), B[0], bytes, hipMemcpyDeviceToHost) != hipSuccess) { printf("!! %s: launch failed\n", v.name); return 1; }
+      size_t bad = 0;
+      for (size_t i = 0; i < bytes; i++) bad += got[i] != ref[i];
+      printf("%-28s %s (%zu mismatching bytes)\n", v.name, bad ? "!! MISMATCH" : "bit-exact", bad);
+    }
+    fflush(stdout);
+  }
+  for (auto &v : vs) for (int i = 0; i < 300; i++) v.f(i % NS);
+  hipDeviceSynchronize();
+  for (int round = 0; round < 7; round++)
+    for (auto &v : vs)
+    {
+      for (int i = 0; i < 40; i++) v.f(i % NS);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 40; i++) v.f(i % NS);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      v.t.push_back(ms / 40);
+    }
+  for (auto &v : vs)
+  {
+    std::sort(v.t.begin(), v.t.end());
+    printf("%-28s median %7.2f us  min %7.2f us\n", v.name, v.t[v.t.size() / 2] * 1e3, v.t[0] * 1e3);
+  }
+  return 0;
+}
