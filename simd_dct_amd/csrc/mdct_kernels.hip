@@ -154,9 +154,127 @@ static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernel
 //   K_AVX  :2176-2183  o1 = t1 + (Cd x25m - Cf x43m)       o3 = t3 - (Ca x25m + Cd x43m)   (k=3 quirk)
 //   K_SSE  :547-577    o1 = t1 + (Cd x25m + Cf x43m) (k=1 quirk)  o3 = t3 + (Cd x43m - Ca x25m)
 //   K_TRUE :163-171    left to right: o1 = (t1 + Cd x25m) - Cf x43m, o3 = (t3 - Ca x25m) + Cd x43m, ...
+// Statement order matters for speed, not for bits: every MDCT_PK* is a separate inline-asm statement, and for an asm
+// statement that reads a VGPR written by the asm statement IMMEDIATELY before it the compiler inserts a wait state
+// (it cannot see inside and assumes the gfx940 dst_sel forwarding hazard): 64-76 s_nop per wave in the order the
+// formulas are usually written in.  The operations are therefore emitted so that none consumes its predecessor's
+// result (MDCT_PK_REORDER=0 keeps the textbook order for A/B runs, tools/exp_u8_r3.hip).
+#ifndef MDCT_PK_REORDER
+#define MDCT_PK_REORDER 2
+#endif
 template <int K1D>
 __device__ __forceinline__ void dct8_h(const PkConsts &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o13, f32x2 &o57)
 {
+#if MDCT_PK_REORDER == 2
+  if constexpr (K1D != K_TRUE)
+  { // The whole line as ONE asm statement, registers allocated by hand: the four input pairs are reused as scratch
+    // (A = a01, B = a23, C = a45, D = a67) plus three temporaries, 28 instructions, no compiler-inserted wait states
+    // inside; results leave in T0 = (o0,o4), T1 = (o2,o6), C = (o1,o3), D = (o5,o7).  Same operations, same operands,
+    // same modifiers as the statement-per-operation form below (MDCT_PK_REORDER 0 / 1), which stays the readable spec.
+    f32x2 T0, T1, T2;
+#define MDCT_XS " op_sel:[0,1] op_sel_hi:[1,0]"
+#define MDCT_DCT8_H_ASM(U13MOD, O13MOD) \
+    asm("v_pk_add_f32 %4, %0, %3" MDCT_XS "\n\t"                                  /* T0 = s1 = (p0+p7, p1+p6) */ \
+        "v_pk_add_f32 %5, %1, %2" MDCT_XS "\n\t"                                  /* T1 = s2 = (p2+p5, p3+p4) */ \
+        "v_pk_add_f32 %0, %0, %3" MDCT_XS " neg_lo:[0,1] neg_hi:[1,0]\n\t"        /* A = d = (p0-p7, p6-p1) */ \
+        "v_pk_add_f32 %1, %1, %2" MDCT_XS " neg_lo:[0,1] neg_hi:[1,0]\n\t"        /* B = e = (p2-p5, p4-p3) */ \
+        "v_pk_add_f32 %2, %4, %5" MDCT_XS "\n\t"                                  /* C = (pp, qp) */ \
+        "v_pk_add_f32 %3, %4, %5" MDCT_XS " neg_lo:[0,1] neg_hi:[0,1]\n\t"        /* D = (pm, qm) */ \
+        "v_pk_add_f32 %4, %2, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"   /* T0 = (pp+qp, pp-qp) */ \
+        "v_pk_mul_f32 %5, %3, %9 op_sel:[0,0] op_sel_hi:[1,0]\n\t"                /* T1 = r = (Cb pm, Cb qm) */ \
+        "v_pk_mul_f32 %2, %0, %7 op_sel:[0,0] op_sel_hi:[1,1]\n\t"                /* C = m1 = (Ca x07m, Cf x61m) */ \
+        "v_pk_mul_f32 %3, %3, %9 op_sel:[0,1] op_sel_hi:[1,1]\n\t"                /* D = t = (Ce pm, Ce qm) */ \
+        "v_pk_mul_f32 %6, %0, %8 op_sel:[0,0] op_sel_hi:[1,0]\n\t"                /* T2 = m2 = (Cc x07m, Cc x61m) */ \
+        "v_pk_add_f32 %5, %5, %3" MDCT_XS " neg_hi:[1,0]\n\t"                     /* T1 = (Cb pm + Ce qm, Ce pm - Cb qm) */ \
+        "v_pk_add_f32 %2, %2, %6" MDCT_XS " neg_lo:[0,1]\n\t"                     /* C = t13 */ \
+        "v_pk_mul_f32 %3, %0, %8 op_sel:[0,1] op_sel_hi:[1,1]\n\t"                /* D = m3 = (Cd x07m, Cd x61m) */ \
+        "v_pk_mul_f32 %6, %0, %7 op_sel:[0,1] op_sel_hi:[1,0]\n\t"                /* T2 = m4 = (Cf x07m, Ca x61m) */ \
+        "v_pk_mul_f32 %0, %1, %8 op_sel:[0,1] op_sel_hi:[1,1]\n\t"                /* A = n1 = (Cd x25m, Cd x43m) */ \
+        "v_pk_add_f32 %3, %3, %6" MDCT_XS "\n\t"                                  /* D = t57 */ \
+        "v_pk_mul_f32 %6, %1, %7 op_sel:[0,0] op_sel_hi:[1,1]\n\t"                /* T2 = n2 = (Ca x25m, Cf x43m) */ \
+        "v_pk_mul_f32 %4, %4, %10 op_sel:[0,0] op_sel_hi:[1,0]\n\t"               /* T0 *= Cn */ \
+        "v_pk_add_f32 %0, %0, %6" MDCT_XS " " U13MOD "\n\t"                              /* A = u13: K_AVX neg_lo:[0,1] (Cd x25m - Cf x43m, ..), K_SSE neg_hi:[0,1] (k=1 quirk, :550) */ \
+        "v_pk_mul_f32 %6, %1, %7 op_sel:[0,1] op_sel_hi:[1,0]\n\t"                /* T2 = n3 = (Cf x25m, Ca x43m) */ \
+        "v_pk_mul_f32 %1, %1, %8 op_sel:[0,0] op_sel_hi:[1,0]\n\t"                /* B = n4 = (Cc x25m, Cc x43m) */ \
+        "v_pk_mul_f32 %5, %5, %10 op_sel:[0,0] op_sel_hi:[1,0]\n\t"               /* T1 *= Cn */ \
+        "v_pk_add_f32 %6, %6, %1" MDCT_XS " neg_lo:[0,1]\n\t"                     /* T2 = u57 */ \
+        "v_pk_add_f32 %2, %2, %0 " O13MOD "\n\t"                                        /* C = o13: K_AVX neg_hi:[0,1] (the k=3 quirk of :2181), K_SSE plain */ \
+        "v_pk_add_f32 %3, %3, %6\n\t"                                            /* D = o57 */ \
+        "v_pk_mul_f32 %2, %2, %10 op_sel:[0,0] op_sel_hi:[1,0]\n\t" \
+        "v_pk_mul_f32 %3, %3, %10 op_sel:[0,0] op_sel_hi:[1,0]" \
+        : "+v"(a01), "+v"(a23), "+v"(a45), "+v"(a67), "=&v"(T0), "=&v"(T1), "=&v"(T2) \
+        : "s"(K.af), "s"(K.cd), "s"(K.be), "s"(K.nm))
+    if constexpr (K1D == K_AVX)
+      MDCT_DCT8_H_ASM("neg_lo:[0,1]", "neg_hi:[0,1]");
+    else
+      MDCT_DCT8_H_ASM("neg_hi:[0,1]", "");
+#undef MDCT_DCT8_H_ASM
+#undef MDCT_XS
+    o04 = T0; o26 = T1; o13 = a45; o57 = a67;
+    return;
+  }
+#endif
+#if MDCT_PK_REORDER
+  f32x2 s1, s2, d, e, pqp, pqm, r, t, m1, m2, m3, m4, t13, t57;
+  MDCT_PKA(s1, a01, a67, MDCT_X);                                  // (p0+p7, p1+p6)
+  MDCT_PKA(s2, a23, a45, MDCT_X);                                  // (p2+p5, p3+p4)
+  MDCT_PKA(d, a01, a67, MDCT_X " neg_lo:[0,1] neg_hi:[1,0]");      // (p0-p7, p6-p1)
+  MDCT_PKA(e, a23, a45, MDCT_X " neg_lo:[0,1] neg_hi:[1,0]");      // (p2-p5, p4-p3)
+  MDCT_PKA(pqp, s1, s2, MDCT_X);                                   // (x07p+x34p, x16p+x25p)
+  MDCT_PKA(pqm, s1, s2, MDCT_X " " MDCT_NEG_B);                    // (x07p-x34p, x16p-x25p)
+  MDCT_PKM(m1, d, K.af, MDCT_K_LH);                                // (Ca x07m, Cf x61m)
+  MDCT_PKA(o04, pqp, pqp, "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]"); // (pp+qp, pp-qp)
+  MDCT_PKM(r, pqm, K.be, MDCT_K_LL);                               // (Cb pm, Cb qm)
+  MDCT_PKM(t, pqm, K.be, MDCT_K_HH);                               // (Ce pm, Ce qm)
+  MDCT_PKM(m2, d, K.cd, MDCT_K_LL);                                // (Cc x07m, Cc x61m)
+  MDCT_PKA(o26, r, t, MDCT_X " neg_hi:[1,0]");                     // (Cb pm + Ce qm, Ce pm - Cb qm)
+  MDCT_PKM(m3, d, K.cd, MDCT_K_HH);                                // (Cd x07m, Cd x61m)
+  MDCT_PKM(m4, d, K.af, MDCT_K_HL);                                // (Cf x07m, Ca x61m)
+  MDCT_PKA(t13, m1, m2, MDCT_X " neg_lo:[0,1]");                   // (Ca x07m - Cc x61m, Cf x61m + Cc x07m)
+  if constexpr (K1D == K_TRUE)
+  { // sequential association: two more terms added one after the other
+    f32x2 g1, g2, g3, g4, h13, h57;
+    MDCT_PKM(g1, e, K.da, "op_sel:[0,0] op_sel_hi:[0,1]");         // (Cd x25m, Ca x25m)
+    MDCT_PKA(t57, m3, m4, MDCT_X);                                 // (Cd x07m + Ca x61m, Cd x61m + Cf x07m)
+    MDCT_PKM(g3, e, K.fc, "op_sel:[0,0] op_sel_hi:[0,1]");         // (Cf x25m, Cc x25m)
+    MDCT_PKM(g2, e, K.fd, "op_sel:[1,0] op_sel_hi:[1,1]");         // (Cf x43m, Cd x43m)
+    MDCT_PKA(h13, t13, g1, "neg_hi:[0,1]");                        // (t1 + Cd x25m, t3 - Ca x25m)
+    MDCT_PKM(g4, e, K.ca, "op_sel:[1,0] op_sel_hi:[1,1]");         // (Cc x43m, Ca x43m)
+    MDCT_PKA(h57, t57, g3, "");                                    // (t5 + Cf x25m, t7 + Cc x25m)
+    MDCT_PKM(o04, o04, K.nm, MDCT_K_LL);
+    MDCT_PKA(o13, h13, g2, "neg_lo:[0,1]");                        // (.. - Cf x43m, .. + Cd x43m)
+    MDCT_PKM(o26, o26, K.nm, MDCT_K_LL);
+    MDCT_PKA(o57, h57, g4, "neg_lo:[0,1]");                        // (.. - Cc x43m, .. + Ca x43m)
+    MDCT_PKM(o13, o13, K.nm, MDCT_K_LL);
+    MDCT_PKM(o57, o57, K.nm, MDCT_K_LL);
+  }
+  else
+  {
+    f32x2 n1, n2, n3, n4, u13, u57;
+    MDCT_PKM(n1, e, K.cd, MDCT_K_HH);                              // (Cd x25m, Cd x43m)
+    MDCT_PKA(t57, m3, m4, MDCT_X);                                 // (Cd x07m + Ca x61m, Cd x61m + Cf x07m)
+    MDCT_PKM(n2, e, K.af, MDCT_K_LH);                              // (Ca x25m, Cf x43m)
+    MDCT_PKM(n3, e, K.af, MDCT_K_HL);                              // (Cf x25m, Ca x43m)
+    MDCT_PKM(n4, e, K.cd, MDCT_K_LL);                              // (Cc x25m, Cc x43m)
+    if constexpr (K1D == K_AVX)
+      MDCT_PKA(u13, n1, n2, MDCT_X " neg_lo:[0,1]");               // (Cd x25m - Cf x43m, Cd x43m + Ca x25m)
+    else
+    {
+      static_assert(K1D == K_SSE, "unknown 1-D kernel");
+      MDCT_PKA(u13, n1, n2, MDCT_X " neg_hi:[0,1]");               // (Cd x25m + Cf x43m [k=1 quirk, :550], Cd x43m - Ca x25m)
+    }
+    MDCT_PKM(o04, o04, K.nm, MDCT_K_LL);
+    MDCT_PKA(u57, n3, n4, MDCT_X " neg_lo:[0,1]");                 // (Cf x25m - Cc x43m, Ca x43m + Cc x25m)
+    MDCT_PKM(o26, o26, K.nm, MDCT_K_LL);
+    if constexpr (K1D == K_AVX)
+      MDCT_PKA(o13, t13, u13, "neg_hi:[0,1]");                     // (t1 + u1, t3 - u3): the k=3 quirk of :2181
+    else
+      MDCT_PKA(o13, t13, u13, "");
+    MDCT_PKA(o57, t57, u57, "");                                   // (t5 + u5, t7 + u7)
+    MDCT_PKM(o13, o13, K.nm, MDCT_K_LL);
+    MDCT_PKM(o57, o57, K.nm, MDCT_K_LL);
+  }
+#else
   f32x2 s1, s2, d, e, pqp, pqm, r, t, m1, m2, m3, m4, t13, t57;
   MDCT_PKA(s1, a01, a67, MDCT_X);                                  // (p0+p7, p1+p6)
   MDCT_PKA(s2, a23, a45, MDCT_X);                                  // (p2+p5, p3+p4)
@@ -211,12 +329,137 @@ __device__ __forceinline__ void dct8_h(const PkConsts &K, f32x2 a01, f32x2 a23, 
   MDCT_PKM(o26, o26, K.nm, MDCT_K_LL);
   MDCT_PKM(o13, o13, K.nm, MDCT_K_LL);
   MDCT_PKM(o57, o57, K.nm, MDCT_K_LL);
+#endif
 }
 
 // the same transform down a PAIR of independent columns (or rows), p[r] = (B[r][u1], B[r][u2]), in place
 template <int K1D>
 __device__ __forceinline__ void dct8_v(const PkConsts &K, f32x2 (&p)[8])
 {
+#if MDCT_PK_REORDER == 2
+  // Plain vector code: this pass needs no cross-half operand selection -- only whole-pair adds / subtracts and products
+  // with one broadcast constant, which the compiler turns into v_pk_add_f32 / v_pk_mul_f32 itself (the broadcast and the
+  // subtraction's sign fold into op_sel / neg modifiers: (-x)*c == -(x*c) and a + (-b) == a - b exactly; contraction is
+  // off for the whole file).  Compiler-visible operations are scheduled with their latencies and draw no conservative
+  // wait states (the asm statements of the horizontal pass do, see above).
+  const f32x2 Ca = K.af.xx, Cf = K.af.yy, Cc = K.cd.xx, Cd = K.cd.yy, Cb = K.be.xx, Ce = K.be.yy, Cn = K.nm.xx;
+  const f32x2 x07p = p[0] + p[7], x16p = p[1] + p[6], x25p = p[2] + p[5], x34p = p[3] + p[4];
+  const f32x2 x07m = p[0] - p[7], x61m = p[6] - p[1], x25m = p[2] - p[5], x43m = p[4] - p[3];
+  const f32x2 pp = x07p + x34p, pm = x07p - x34p, qp = x16p + x25p, qm = x16p - x25p;
+  const f32x2 o0 = pp + qp, o4 = pp - qp;
+  const f32x2 o2 = (Cb * pm) + (Ce * qm), o6 = (Ce * pm) - (Cb * qm);
+  const f32x2 t1 = (Ca * x07m) - (Cc * x61m), t3 = (Cc * x07m) + (Cf * x61m);
+  const f32x2 t5 = (Cd * x07m) + (Ca * x61m), t7 = (Cf * x07m) + (Cd * x61m);
+  f32x2 o1, o3, o5, o7;
+  if constexpr (K1D == K_TRUE)
+  { // ((t + c1 x25m) +- c2 x43m), :166-171
+    o1 = (t1 + (Cd * x25m)) - (Cf * x43m);
+    o3 = (t3 - (Ca * x25m)) + (Cd * x43m);
+    o5 = (t5 + (Cf * x25m)) - (Cc * x43m);
+    o7 = (t7 + (Cc * x25m)) + (Ca * x43m);
+  }
+  else
+  {
+    const f32x2 u5 = (Cf * x25m) - (Cc * x43m), u7 = (Cc * x25m) + (Ca * x43m);
+    if constexpr (K1D == K_AVX)
+    {
+      const f32x2 u1 = (Cd * x25m) - (Cf * x43m), u3 = (Ca * x25m) + (Cd * x43m);
+      o1 = t1 + u1;
+      o3 = t3 - u3; // the k=3 quirk of :2181
+    }
+    else
+    {
+      const f32x2 u1 = (Cd * x25m) + (Cf * x43m), u3 = (Cd * x43m) - (Ca * x25m); // k=1 quirk, :550
+      o1 = t1 + u1;
+      o3 = t3 + u3;
+    }
+    o5 = t5 + u5;
+    o7 = t7 + u7;
+  }
+  p[0] = Cn * o0; p[1] = Cn * o1; p[2] = Cn * o2; p[3] = Cn * o3;
+  p[4] = Cn * o4; p[5] = Cn * o5; p[6] = Cn * o6; p[7] = Cn * o7;
+#elif MDCT_PK_REORDER
+  // products and sums software-pipelined: mul A(i+1) sits between mul B(i) and add(i), so no statement reads its predecessor
+  f32x2 x07p, x16p, x25p, x34p, x07m, x61m, x25m, x43m, pp, pm, qp, qm, o0, o1, o2, o3, o4, o5, o6, o7;
+  MDCT_PKA(x07p, p[0], p[7], ""); MDCT_PKA(x16p, p[1], p[6], ""); MDCT_PKA(x25p, p[2], p[5], ""); MDCT_PKA(x34p, p[3], p[4], "");
+  MDCT_PKA(x07m, p[0], p[7], MDCT_NEG_B); MDCT_PKA(x61m, p[6], p[1], MDCT_NEG_B);
+  MDCT_PKA(x25m, p[2], p[5], MDCT_NEG_B); MDCT_PKA(x43m, p[4], p[3], MDCT_NEG_B);
+  MDCT_PKA(pp, x07p, x34p, ""); MDCT_PKA(pm, x07p, x34p, MDCT_NEG_B);
+  MDCT_PKA(qp, x16p, x25p, ""); MDCT_PKA(qm, x16p, x25p, MDCT_NEG_B);
+  f32x2 a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, t1, t3, t5, t7;
+  MDCT_PKM(a1, pm, K.be, MDCT_K_LL);                       // Cb pm
+  MDCT_PKA(o0, pp, qp, "");
+  MDCT_PKM(b1, qm, K.be, MDCT_K_HH);                       // Ce qm
+  MDCT_PKA(o4, pp, qp, MDCT_NEG_B);
+  MDCT_PKM(a2, pm, K.be, MDCT_K_HH);                       // Ce pm
+  MDCT_PKA(o2, a1, b1, "");                                // Cb pm + Ce qm
+  MDCT_PKM(b2, qm, K.be, MDCT_K_LL);                       // Cb qm
+  MDCT_PKM(a3, x07m, K.af, MDCT_K_LL);                     // Ca x07m
+  MDCT_PKA(o6, a2, b2, MDCT_NEG_B);                        // Ce pm - Cb qm
+  MDCT_PKM(b3, x61m, K.cd, MDCT_K_LL);                     // Cc x61m
+  MDCT_PKM(a4, x07m, K.cd, MDCT_K_LL);                     // Cc x07m
+  MDCT_PKA(t1, a3, b3, MDCT_NEG_B);                        // Ca x07m - Cc x61m
+  MDCT_PKM(b4, x61m, K.af, MDCT_K_HH);                     // Cf x61m
+  MDCT_PKM(a5, x07m, K.cd, MDCT_K_HH);                     // Cd x07m
+  MDCT_PKA(t3, a4, b4, "");                                // Cc x07m + Cf x61m
+  MDCT_PKM(b5, x61m, K.af, MDCT_K_LL);                     // Ca x61m
+  MDCT_PKM(a6, x07m, K.af, MDCT_K_HH);                     // Cf x07m
+  MDCT_PKA(t5, a5, b5, "");                                // Cd x07m + Ca x61m
+  MDCT_PKM(b6, x61m, K.cd, MDCT_K_HH);                     // Cd x61m
+  if constexpr (K1D == K_TRUE)
+  { // ((t + c1 x25m) +- c2 x43m), :166-171
+    f32x2 c1, c3, c5, c7, d1, d3, d5, d7;
+    MDCT_PKM(c1, x25m, K.cd, MDCT_K_HH);                   // Cd x25m
+    MDCT_PKA(t7, a6, b6, "");                              // Cf x07m + Cd x61m
+    MDCT_PKM(c3, x25m, K.af, MDCT_K_LL);                   // Ca x25m
+    MDCT_PKM(c5, x25m, K.af, MDCT_K_HH);                   // Cf x25m
+    MDCT_PKA(t1, t1, c1, "");
+    MDCT_PKM(c7, x25m, K.cd, MDCT_K_LL);                   // Cc x25m
+    MDCT_PKA(t3, t3, c3, MDCT_NEG_B);
+    MDCT_PKM(d1, x43m, K.af, MDCT_K_HH);                   // Cf x43m
+    MDCT_PKA(t5, t5, c5, "");
+    MDCT_PKM(d3, x43m, K.cd, MDCT_K_HH);                   // Cd x43m
+    MDCT_PKA(t7, t7, c7, "");
+    MDCT_PKM(d5, x43m, K.cd, MDCT_K_LL);                   // Cc x43m
+    MDCT_PKA(o1, t1, d1, MDCT_NEG_B);
+    MDCT_PKM(d7, x43m, K.af, MDCT_K_LL);                   // Ca x43m
+    MDCT_PKA(o3, t3, d3, "");
+    MDCT_PKA(o5, t5, d5, MDCT_NEG_B);
+    MDCT_PKA(o7, t7, d7, "");
+  }
+  else
+  {
+    f32x2 c7, d7, c8, d8, c9, d9, c10, d10, u1, u3, u5, u7;
+    MDCT_PKM(c7, x25m, K.af, MDCT_K_HH);                   // Cf x25m
+    MDCT_PKA(t7, a6, b6, "");                              // Cf x07m + Cd x61m
+    MDCT_PKM(d7, x43m, K.cd, MDCT_K_LL);                   // Cc x43m
+    MDCT_PKM(c8, x25m, K.cd, MDCT_K_LL);                   // Cc x25m
+    MDCT_PKA(u5, c7, d7, MDCT_NEG_B);                      // Cf x25m - Cc x43m
+    MDCT_PKM(d8, x43m, K.af, MDCT_K_LL);                   // Ca x43m
+    MDCT_PKM(c9, x25m, K.cd, MDCT_K_HH);                   // Cd x25m
+    MDCT_PKA(u7, c8, d8, "");                              // Cc x25m + Ca x43m
+    MDCT_PKM(d9, x43m, K.af, MDCT_K_HH);                   // Cf x43m
+    MDCT_PKM(c10, x25m, K.af, MDCT_K_LL);                  // Ca x25m
+    if constexpr (K1D == K_AVX)
+      MDCT_PKA(u1, c9, d9, MDCT_NEG_B);                    // Cd x25m - Cf x43m
+    else
+      MDCT_PKA(u1, c9, d9, "");                            // Cd x25m + Cf x43m (k=1 quirk, :550)
+    MDCT_PKM(d10, x43m, K.cd, MDCT_K_HH);                  // Cd x43m
+    MDCT_PKA(o5, t5, u5, "");
+    if constexpr (K1D == K_AVX)
+      MDCT_PKA(u3, c10, d10, "");                          // Ca x25m + Cd x43m
+    else
+      MDCT_PKA(u3, d10, c10, MDCT_NEG_B);                  // Cd x43m - Ca x25m
+    MDCT_PKA(o7, t7, u7, "");
+    MDCT_PKA(o1, t1, u1, "");
+    if constexpr (K1D == K_AVX)
+      MDCT_PKA(o3, t3, u3, MDCT_NEG_B);                    // the k=3 quirk of :2181
+    else
+      MDCT_PKA(o3, t3, u3, "");
+  }
+  MDCT_PKM(p[0], o0, K.nm, MDCT_K_LL); MDCT_PKM(p[4], o4, K.nm, MDCT_K_LL); MDCT_PKM(p[2], o2, K.nm, MDCT_K_LL); MDCT_PKM(p[6], o6, K.nm, MDCT_K_LL);
+  MDCT_PKM(p[5], o5, K.nm, MDCT_K_LL); MDCT_PKM(p[7], o7, K.nm, MDCT_K_LL); MDCT_PKM(p[1], o1, K.nm, MDCT_K_LL); MDCT_PKM(p[3], o3, K.nm, MDCT_K_LL);
+#else
   f32x2 x07p, x16p, x25p, x34p, x07m, x61m, x25m, x43m, pp, pm, qp, qm, o0, o4, a, b, o2, o6;
   MDCT_PKA(x07p, p[0], p[7], ""); MDCT_PKA(x16p, p[1], p[6], ""); MDCT_PKA(x25p, p[2], p[5], ""); MDCT_PKA(x34p, p[3], p[4], "");
   MDCT_PKA(x07m, p[0], p[7], MDCT_NEG_B); MDCT_PKA(x61m, p[6], p[1], MDCT_NEG_B);
@@ -259,6 +502,7 @@ __device__ __forceinline__ void dct8_v(const PkConsts &K, f32x2 (&p)[8])
   }
   MDCT_PKM(p[0], o0, K.nm, MDCT_K_LL); MDCT_PKM(p[1], o1, K.nm, MDCT_K_LL); MDCT_PKM(p[2], o2, K.nm, MDCT_K_LL); MDCT_PKM(p[3], o3, K.nm, MDCT_K_LL);
   MDCT_PKM(p[4], o4, K.nm, MDCT_K_LL); MDCT_PKM(p[5], o5, K.nm, MDCT_K_LL); MDCT_PKM(p[6], o6, K.nm, MDCT_K_LL); MDCT_PKM(p[7], o7, K.nm, MDCT_K_LL);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -355,7 +599,11 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
     {
       const f32x2 qp = reinterpret_cast<const f32x2 *>(qt.q)[v * 4 + j];
       f32x2 m;
+#if MDCT_PK_REORDER == 2
+      m = col[j][v] * qp;
+#else
       MDCT_PKM(m, col[j][v], qp, MDCT_K_LH);
+#endif
       if constexpr (SAFE)
       {
         out[v * 8 + kPairA[j]] = (uint32_t)clamp255((int32_t)((uint32_t)cvtps_epi32_exact(m.x) + 127u));
@@ -366,7 +614,11 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
         f32x2 t;
         m.x = __builtin_amdgcn_fmed3f(m.x, -128.0f, 127.0f);
         m.y = __builtin_amdgcn_fmed3f(m.y, -128.0f, 127.0f);
+#if MDCT_PK_REORDER == 2
+        t = m + K.nm.yy; // + (magic, magic)
+#else
         MDCT_PKA(t, m, K.nm, MDCT_K_HH); // + (magic, magic)
+#endif
         out[v * 8 + kPairA[j]] = __float_as_uint(t.x);
         out[v * 8 + kPairB[j]] = __float_as_uint(t.y);
       }
@@ -411,10 +663,14 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
     f32x2 a67 = {at(integral_constant<int, 6>{}), at(integral_constant<int, 7>{})};
     if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
     { // px * (1.0f / 255.0f), :949
+#if MDCT_PK_REORDER == 2
+      a01 = a01 * K.bias.xx; a23 = a23 * K.bias.xx; a45 = a45 * K.bias.xx; a67 = a67 * K.bias.xx;
+#else
       MDCT_PKM(a01, a01, K.bias, MDCT_K_LL);
       MDCT_PKM(a23, a23, K.bias, MDCT_K_LL);
       MDCT_PKM(a45, a45, K.bias, MDCT_K_LL);
       MDCT_PKM(a67, a67, K.bias, MDCT_K_LL);
+#endif
     }
     dct8_h<K1D>(K, a01, a23, a45, a67, P[0][i], P[1][i], P[2][i], P[3][i]);
   };
@@ -430,10 +686,18 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
       const f32x2 qp = reinterpret_cast<const f32x2 *>(qt.q)[m * 4 + j];
       const int sa = kPairA[j] * 8 + m, sb = kPairB[j] * 8 + m;
       f32x2 v;
+#if MDCT_PK_REORDER == 2
+      v = P[j][m] * qp;
+#else
       MDCT_PKM(v, P[j][m], qp, MDCT_K_LH);
+#endif
       if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
       { // B2/B3 :1020  clamp(rne(f*q + 127.0f), 0, 255)
+#if MDCT_PK_REORDER == 2
+        v = v + K.bias.yy;
+#else
         MDCT_PKA(v, v, K.bias, MDCT_K_HH);
+#endif
         if constexpr (SAFE)
         {
           out[sa] = (uint32_t)clamp255(cvtps_epi32_exact(v.x));
@@ -444,7 +708,11 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
           f32x2 t;
           v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 255.0f);
           v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 255.0f);
+#if MDCT_PK_REORDER == 2
+          t = v + K.nm.yy;
+#else
           MDCT_PKA(t, v, K.nm, MDCT_K_HH);
+#endif
           out[sa] = __float_as_uint(t.x);
           out[sb] = __float_as_uint(t.y);
         }
@@ -452,14 +720,26 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
       else
       { // B4/B5 :245, :362  (uint8_t)roundf(_clamp(f*qs + 127/255, 0, 1) * 255), see quant_scalar
         f32x2 x, t, r, d;
+#if MDCT_PK_REORDER == 2
+        v = v + K.bias.xx;
+#else
         MDCT_PKA(v, v, K.bias, MDCT_K_LL);
+#endif
         // _clamp(v, 0, 1) of :50-54 with NaN -> 0: v_med3_f32 returns min3 when an operand is NaN, and min ignores NaN
         v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 1.0f);
         v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 1.0f);
+#if MDCT_PK_REORDER == 2
+        x = v * K.bias.yy;
+        t = x + K.nm.yy;
+        asm volatile("" : "+v"(t)); // keeps (x + magic) - magic from being folded back to x
+        r = t - K.nm.yy;
+        d = x - r;
+#else
         MDCT_PKM(x, v, K.bias, MDCT_K_HH);
         MDCT_PKA(t, x, K.nm, MDCT_K_HH);
         MDCT_PKA(r, t, K.nm, MDCT_K_HH " " MDCT_NEG_B);
         MDCT_PKA(d, x, r, MDCT_NEG_B);
+#endif
         out[sa] = __float_as_uint(t.x) + (d.x == 0.5f ? 1u : 0u);
         out[sb] = __float_as_uint(t.y) + (d.y == 0.5f ? 1u : 0u);
       }
@@ -493,6 +773,42 @@ __device__ __forceinline__ uint32_t wg_index()
   return blockIdx.x;
 #endif
 }
+// ---------------------------------------------------------------------------------------
+// Wave-uniform addressing.  The u8 kernels are bound by VALU issue at the clock the chip holds under their load
+// (profiles/r03_q32_timeline.md: every SIMD retires one wave per ~1.5 us, two waves in their compute phase saturate
+// it, loads are hidden), so every VALU instruction that is not the reference's arithmetic costs time.  Per-lane
+// 64-bit address arithmetic (an integer division, v_mad_u64_u32 per row) was ~100 of ~840 instructions per wave.
+// Where a wave's 64 blocks lie in one block row (sizeX % 512 == 0) the launch is a 2-D grid -- blockIdx.y = block
+// row, blockIdx.x = position in the row -- every base address is computed once per wave on the scalar unit, and a
+// lane contributes only a 32-bit offset: global_load / global_store with an SGPR base.  sgpr_ptr() pins a
+// (wave-uniform) pointer in SGPRs and keeps it in the global address space.
+// ---------------------------------------------------------------------------------------
+typedef const uint8_t __attribute__((address_space(1))) *gcptr_t;
+typedef uint8_t __attribute__((address_space(1))) *gptr_t;
+__device__ __forceinline__ gptr_t sgpr_ptr(const void *p)
+{
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (gptr_t)(((uint64_t)hi << 32) | lo); // (uint32_t halves: a sign-extended low half would corrupt the high one)
+}
+typedef unsigned int u32x2_unaligned_g __attribute__((ext_vector_type(2), aligned(1)));
+typedef unsigned int u32x4_g __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_unaligned_g __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __forceinline__ uint2 load8_g(gcptr_t p)
+{
+  const u32x2_unaligned_g v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_unaligned_g __attribute__((address_space(1))) *>(p));
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ void store16_g(gptr_t p, u32x4_g v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_g __attribute__((address_space(1))) *>(p)); }
+__device__ __forceinline__ void store16_unaligned_g(gptr_t p, u32x4_unaligned_g v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_unaligned_g __attribute__((address_space(1))) *>(p)); }
+// the lane's block as eight 8-byte rows: `base` = row 0 of the wave's first block (wave-uniform), lane offset in bytes
+__device__ __forceinline__ void load_block_rows_g(const uint8_t *base, size_t pitch, uint32_t lane_off, uint2 (&rows)[8])
+{
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    rows[r] = load8_g(sgpr_ptr(base + (size_t)r * pitch) + lane_off);
+}
+
 constexpr int kQ32RowStride = 72;  // 64 lanes + 8 pad: keeps rows 8-byte aligned for ds_read_b64
 constexpr int kStereoRowStride = kWG + 16; // 256 blocks + pad, rows stay 16-byte aligned for ds_read_b128
 
@@ -582,6 +898,40 @@ __global__ __launch_bounds__(kWG, (SAFE || GENERAL) ? 1 : MDCT_Q32_MINW) void k_
   }
 }
 
+// The same product for launches whose waves each lie in one block row (sizeX % 512 == 0, tight output): one workgroup =
+// one wave = one 64-block tile, 2-D grid (x = tile in the row, y = block row), wave-uniform addressing (above).
+// 8192^2: 28.6-28.8 us against 30.4-30.7 for k_q32_avx<false,false> (profiles/r03_exp_q32_addressing.log).
+__global__ __launch_bounds__(64, MDCT_Q32_MINW) void k_q32_tile(U8Args a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t wl[64 * kQ32RowStride];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tile = blockIdx.x, row = blockIdx.y;
+  uint32_t q[64];
+  {
+    uint2 rows[8];
+    load_block_rows_g(a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)tile * 512, a.pitch, lane * 8, rows);
+    encode_block_avx_pk<false>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
+  }
+#pragma unroll
+  for (int c = 0; c < 64; c++)
+    wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // the wave's 4 KiB of output (:2227-2230): store k, lane l -> coefficients c2 = 2 (l & 31), c2 + 1 of group 2k + (l >> 5),
+  // at group * 512 + c2 * 8 == k * 1024 + l * 16
+  const gptr_t outw = sgpr_ptr(a.to + ((size_t)(a.by0 + row) * a.bpr + (size_t)tile * 64) * 64);
+  const uint32_t rd = (lane & 31) * (2 * kQ32RowStride) + (lane >> 5) * 8;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const uint2 lo = *reinterpret_cast<const uint2 *>(wl + rd + k * 16);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(wl + rd + k * 16 + kQ32RowStride);
+    const u32x4_g v = ~u32x4_g{lo.x, lo.y, hi.x, hi.y}; // the fast quantiser staged complemented bytes (encode_block_avx_pk)
+    store16_g(outw + k * 1024 + lane * 16, v);
+  }
+}
+
 // The other tiers / layouts.  Occupancy steering, measured optimum of {default, 3..6} waves/SIMD
 // (profiles/r02_u8_tiers_waves_per_eu.log): the SSE encq tier 4 (30.8 us; 31.2 at 3, 31.0 at 5, 32.9 unsteered, 37.6 at 6 --
 // with the pair-swapped 16-byte stores; its scattered dword stores before that took 38.8 at 3), the scalar stereo tier 4
@@ -593,25 +943,35 @@ constexpr int u8_waves_lo(int profile, int layout) { return layout == MDCT_LAYOU
 constexpr int u8_waves_hi(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 4 : ((layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR) ? 4 : 8); }
 #define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(u8_waves_lo(PROFILE, LAYOUT), u8_waves_hi(PROFILE, LAYOUT))))
 #endif
-template <int PROFILE, int LAYOUT, bool SAFE>
+// TILED: 2-D grid for launches whose workgroups each lie in one row of blocks (sizeX % 2048 == 0): blockIdx.y = row of
+// the launch ((block row, eye) for STEREO), blockIdx.x = 256-block tile of that row; no division, wave-uniform base
+// addresses (see sgpr_ptr).  Otherwise the linear form: any shape, partial last workgroup.
+template <int PROFILE, int LAYOUT, bool SAFE, bool TILED>
 __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
 {
-  const uint32_t t = wg_index() * kWG + threadIdx.x; // linear block index within the launch
-  const bool valid = t < a.nblocks;
-
-  // block coordinates.  STEREO enumerates (block row, eye, block x): simd_dct.cpp:1089-1099.
-  uint32_t by, bx, eye = 0;
+  // linear block index within the launch, block coordinates.  STEREO enumerates (block row, eye, block x): simd_dct.cpp:1089-1099.
+  uint32_t t, row, bx;
+  if constexpr (TILED)
   {
-    const uint32_t row = t / a.bpr;
-    bx = t - row * a.bpr;
-    if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
-    {
-      by = a.by0 + (row >> 1);
-      eye = row & 1;
-    }
-    else
-      by = a.by0 + row;
+    row = blockIdx.y;
+    bx = blockIdx.x * kWG + threadIdx.x;
+    t = row * a.bpr + bx;
   }
+  else
+  {
+    t = wg_index() * kWG + threadIdx.x;
+    row = t / a.bpr;
+    bx = t - row * a.bpr;
+  }
+  const bool valid = TILED || t < a.nblocks;
+  uint32_t by, eye = 0;
+  if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
+  {
+    by = a.by0 + (row >> 1);
+    eye = row & 1;
+  }
+  else
+    by = a.by0 + row;
 
   // scalar tiers: the 256 possible values of px / 255.f, each computed ONCE per workgroup with
   // the same IEEE division the reference performs per pixel (one thread per value, kWG == 256)
@@ -628,11 +988,22 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
   uint32_t q[64];
   if (valid)
   {
-    const uint8_t *src = a.from + (size_t)by * 8 * a.pitch + (size_t)bx * 8;
-    if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
-      src += (size_t)eye * a.eye_offset;
     uint2 rows[8];
-    load_block_rows(src, a.pitch, rows);
+    if constexpr (TILED)
+    { // base of the wave's first block: wave-uniform; the lane adds 8 bytes per block
+      const uint32_t wave_bx0 = blockIdx.x * kWG + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
+      const uint8_t *base = a.from + (size_t)by * 8 * a.pitch + (size_t)wave_bx0 * 8;
+      if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
+        base += (size_t)eye * a.eye_offset;
+      load_block_rows_g(base, a.pitch, (threadIdx.x & 63) * 8, rows);
+    }
+    else
+    {
+      const uint8_t *src = a.from + (size_t)by * 8 * a.pitch + (size_t)bx * 8;
+      if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
+        src += (size_t)eye * a.eye_offset;
+      load_block_rows(src, a.pitch, rows);
+    }
     encode_block_pk<PROFILE, LAYOUT, SAFE>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, px_div255, q);
   }
 
@@ -642,8 +1013,8 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
     // (:1061-1099), so a full workgroup owns 256 consecutive bytes per plane.  Stage them in LDS
     // as [coef][block] and store 16 B per lane (4 wide stores instead of 64 byte stores per lane).
     __shared__ __attribute__((aligned(16))) uint8_t slds[64 * kStereoRowStride];
-    const uint32_t wg_t0 = wg_index() * kWG;
-    const bool full_wg = wg_t0 + kWG <= a.nblocks; // workgroup-uniform
+    const uint32_t wg_t0 = TILED ? blockIdx.y * a.bpr + blockIdx.x * kWG : wg_index() * kWG;
+    const bool full_wg = TILED || wg_t0 + kWG <= a.nblocks; // workgroup-uniform
     if (full_wg)
     {
 #pragma unroll
@@ -675,6 +1046,7 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
     if (valid)
     {
       uint8_t *dst = a.to + (size_t)by * a.out_strip + (size_t)bx * 64;
+      const gptr_t dst_g = sgpr_ptr(TILED ? a.to + (size_t)by * a.out_strip + (size_t)(blockIdx.x * kWG) * 64 : a.to);
 #pragma unroll
       for (int k = 0; k < 4; k++)
       {
@@ -682,7 +1054,10 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
 #pragma unroll
         for (int j = 0; j < 4; j++)
           w[j] = pack4_lo8(q[k * 16 + j * 4], q[k * 16 + j * 4 + 1], q[k * 16 + j * 4 + 2], q[k * 16 + j * 4 + 3]);
-        *reinterpret_cast<uint4 *>(dst + k * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        if constexpr (TILED)
+          *reinterpret_cast<u32x4_g __attribute__((address_space(1))) *>(dst_g + threadIdx.x * 64 + k * 16) = u32x4_g{w[0], w[1], w[2], w[3]};
+        else
+          *reinterpret_cast<uint4 *>(dst + k * 16) = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
   }
@@ -709,8 +1084,18 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
       uint8_t *pair = a.to + (size_t)by * 8 * a.sizeX + (size_t)(bx >> 1) * 128;
       typedef unsigned int u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
       const u32x4_unaligned v0 = {w[0], w[1], w[2], w[3]}, v1 = {w[4], w[5], w[6], w[7]};
-      *reinterpret_cast<u32x4_unaligned *>(pair + ab * 32) = v0;
-      *reinterpret_cast<u32x4_unaligned *>(pair + ab * 32 + 16) = v1;
+      if constexpr (TILED)
+      { // pair p of the workgroup's 128 pairs at 128 p; this lane's 32 bytes at + 32 ab: thread i -> 64 (i >> 1) * 2 + 32 (i & 1) = 64 i - 32 (i & 1) ... spelled out:
+        const gptr_t wg_out = sgpr_ptr(a.to + (size_t)by * 8 * a.sizeX + (size_t)(blockIdx.x * kWG) * 64);
+        const uint32_t off = (threadIdx.x >> 1) * 128 + ab * 32;
+        *reinterpret_cast<u32x4_unaligned __attribute__((address_space(1))) *>(wg_out + off) = v0;
+        *reinterpret_cast<u32x4_unaligned __attribute__((address_space(1))) *>(wg_out + off + 16) = v1;
+      }
+      else
+      {
+        *reinterpret_cast<u32x4_unaligned *>(pair + ab * 32) = v0;
+        *reinterpret_cast<u32x4_unaligned *>(pair + ab * 32 + 16) = v1;
+      }
       const bool spill = (by == a.by_last) && ((bx | 1u) == a.bpr - 1) && a.spill_ok;
       if (spill)
       { // the surviving spill of the plane's last pair (:1676): the other columns, one pair further
@@ -1361,10 +1746,20 @@ static inline uint32_t grid_for(uint32_t nblocks) { return (nblocks + kWG - 1) /
 template <int PROFILE, int LAYOUT>
 static hipError_t launch_u8_pl(const U8Args &a, bool safe, hipStream_t s)
 {
+  const uint32_t launch_rows = a.nblocks / a.bpr; // rows of blocks in the launch: (block row, eye) pairs for STEREO
+  if (a.bpr % kWG == 0 && launch_rows <= 65535u && a.out_tight)
+  { // every workgroup inside one row of blocks: 2-D grid, wave-uniform addressing (TILED)
+    const dim3 g(a.bpr / kWG, launch_rows);
+    if (safe)
+      hipLaunchKernelGGL((k_fwd_quant_u8<PROFILE, LAYOUT, true, true>), g, dim3(kWG), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_fwd_quant_u8<PROFILE, LAYOUT, false, true>), g, dim3(kWG), 0, s, a);
+    return hipGetLastError();
+  }
   if (safe)
-    hipLaunchKernelGGL((k_fwd_quant_u8<PROFILE, LAYOUT, true>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
+    hipLaunchKernelGGL((k_fwd_quant_u8<PROFILE, LAYOUT, true, false>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
   else
-    hipLaunchKernelGGL((k_fwd_quant_u8<PROFILE, LAYOUT, false>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
+    hipLaunchKernelGGL((k_fwd_quant_u8<PROFILE, LAYOUT, false, false>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
   return hipGetLastError();
 }
 
@@ -1375,6 +1770,12 @@ hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool sa
   if (layout == MDCT_LAYOUT_Q32 && profile == MDCT_PROFILE_REF_AVX)
   {
     const bool general = a.nblocks % 64 != 0 || !a.out_tight;
+    const uint32_t launch_rows = a.nblocks / a.bpr;
+    if (!safe && !general && a.bpr % 64 == 0 && launch_rows <= 65535u)
+    { // every wave inside one block row: the tile kernel with wave-uniform addressing
+      hipLaunchKernelGGL(k_q32_tile, dim3(a.bpr / 64, launch_rows), dim3(64), 0, s, a);
+      return hipGetLastError();
+    }
     const dim3 g(grid_for(a.nblocks)), b(kWG);
     if (safe && general)
       hipLaunchKernelGGL((k_q32_avx<true, true>), g, b, 0, s, a);

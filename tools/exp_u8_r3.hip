@@ -164,6 +164,186 @@ __global__ __launch_bounds__(kWG, MINW) void v_early(U8Args a)
   store_pair(6);
 }
 
+// ---------------------------------------------------------------------------------------
+// Variant: wave-uniform addressing.  The timeline (profiles/r03_q32_timeline.md) shows the kernel VALU-bound at the
+// clock the chip holds under this load (~1.97 GHz): every SIMD retires one wave per ~1.5 us, 2 waves in their compute
+// phase saturate it, loads are hidden.  So only fewer VALU cycles per wave help.  Of the product's ~840 VALU
+// instructions ~100 are address arithmetic done per lane in 64 bits (v_mad_u64_u32, v_lshl_add_u64, an integer
+// division).  Here one workgroup = one wave = one 64-block tile of one block row (2-D grid: x = tile, y = block row,
+// needs sizeX % 512 == 0), every base address is wave-uniform (SALU) and the lane contributes a 32-bit offset.
+// STAGGER: waves of the first resident generation sleep by their slot number so that each SIMD's first rows arrive
+// early instead of all 6 slots' requests queueing behind one another.
+// ---------------------------------------------------------------------------------------
+template <int MINW, int STAGGER>
+__global__ __launch_bounds__(64, MINW) void v_sa64(U8Args a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t wl[64 * kQ32RowStride];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tile = blockIdx.x, row = blockIdx.y;
+  if constexpr (STAGGER > 0)
+  {
+    if (row * gridDim.x + tile < 6144u)
+    {
+      const uint32_t slot = GETREG(4) & 15u;
+      for (uint32_t i = 0; i < slot; i++)
+        __builtin_amdgcn_s_sleep(STAGGER);
+    }
+  }
+  const uint8_t *src = a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)tile * 512;
+  const uint32_t voff = lane * 8;
+  uint2 rows[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    rows[r] = load8_g(sgpr_ptr(src + (size_t)r * a.pitch) + voff);
+  uint32_t q[64];
+  encode_block_avx_pk<false>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
+#pragma unroll
+  for (int c = 0; c < 64; c++)
+    wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const gptr_t outw = sgpr_ptr(a.to + ((size_t)(a.by0 + row) * a.bpr + (size_t)tile * 64) * 64);
+  const uint32_t rd = (lane & 31) * (2 * kQ32RowStride) + (lane >> 5) * 8; // coefficient rows c2, c2+1 at group 2k + (lane >> 5)
+  const uint32_t wr = lane * 16;                                          // == (2k + (lane >> 5)) * 512 + c2 * 8 - k * 1024
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const uint2 lo = *reinterpret_cast<const uint2 *>(wl + rd + k * 16);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(wl + rd + k * 16 + kQ32RowStride);
+    const u32x4_t v = ~u32x4_t{lo.x, lo.y, hi.x, hi.y};
+    store16_g(outw + k * 1024 + wr, v);
+  }
+}
+
+// the same addressing with the product's 4-wave workgroups (1-D grid, a workgroup = 256 consecutive blocks of one block
+// row: needs sizeX % 2048 == 0) -- separates the effect of the addressing from that of the dispatch granularity
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void v_sa256(U8Args a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t lds[4][64 * kQ32RowStride];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t tile = blockIdx.x * 4 + wave, row = blockIdx.y;
+  const uint8_t *src = a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)tile * 512;
+  const uint32_t voff = lane * 8;
+  uint2 rows[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    rows[r] = load8_g(sgpr_ptr(src + (size_t)r * a.pitch) + voff);
+  uint32_t q[64];
+  encode_block_avx_pk<false>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
+  uint8_t *wl = lds[wave];
+#pragma unroll
+  for (int c = 0; c < 64; c++)
+    wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const gptr_t outw = sgpr_ptr(a.to + ((size_t)(a.by0 + row) * a.bpr + (size_t)tile * 64) * 64);
+  const uint32_t rd = (lane & 31) * (2 * kQ32RowStride) + (lane >> 5) * 8;
+  const uint32_t wr = lane * 16;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const uint2 lo = *reinterpret_cast<const uint2 *>(wl + rd + k * 16);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(wl + rd + k * 16 + kQ32RowStride);
+    const u32x4_t v = ~u32x4_t{lo.x, lo.y, hi.x, hi.y};
+    store16_g(outw + k * 1024 + wr, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// What does the LDS reorder cost?  (encq/SSE, 786 VALU and no LDS, runs in 23.7 us; q32, 663 VALU + 64 ds_write_b8, 27.5.)
+//   LDSMODE 0  the product tile kernel's reorder: 64 ds_write_b8 + 4 ds_read2_b64 per lane
+//   LDSMODE 1  NO reorder (wrong bytes, timing only): the 64 bytes packed with 48 v_perm and stored 4 x 16 B
+//   LDSMODE 2  NO reorder, NO packing (wrong bytes): 16 of the 64 words stored as they are -- the transform + quantiser alone
+//   LDSMODE 3  byte pairs: coefficients (v,u) and (v,u+4)... merged with one v_perm per pair, 32 ds_write_b16 into rows
+//              [pair][lane][2], read back 16 B per lane and de-interleaved with 4 v_perm per 16 B (bit-exact)
+// ---------------------------------------------------------------------------------------
+template <int LDSMODE>
+__global__ __launch_bounds__(64, 6) void v_ldscost(U8Args a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t wl[64 * kQ32RowStride * (LDSMODE == 3 ? 2 : 1)];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tile = blockIdx.x, row = blockIdx.y;
+  uint32_t q[64];
+  {
+    uint2 rows[8];
+    load_block_rows_g(a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)tile * 512, a.pitch, lane * 8, rows);
+    encode_block_avx_pk<false>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
+  }
+  const gptr_t outw = sgpr_ptr(a.to + ((size_t)(a.by0 + row) * a.bpr + (size_t)tile * 64) * 64);
+  if constexpr (LDSMODE == 0)
+  {
+#pragma unroll
+    for (int c = 0; c < 64; c++)
+      wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t rd = (lane & 31) * (2 * kQ32RowStride) + (lane >> 5) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const uint2 lo = *reinterpret_cast<const uint2 *>(wl + rd + k * 16);
+      const uint2 hi = *reinterpret_cast<const uint2 *>(wl + rd + k * 16 + kQ32RowStride);
+      store16_g(outw + k * 1024 + lane * 16, ~u32x4_g{lo.x, lo.y, hi.x, hi.y});
+    }
+  }
+  else if constexpr (LDSMODE == 1)
+  {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      u32x4_g v;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        v[j] = pack4_lo8(q[k * 16 + j * 4], q[k * 16 + j * 4 + 1], q[k * 16 + j * 4 + 2], q[k * 16 + j * 4 + 3]);
+      store16_g(outw + k * 1024 + lane * 16, ~v);
+    }
+  }
+  else if constexpr (LDSMODE == 2)
+  {
+    uint32_t acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      acc[i] = q[i];
+#pragma unroll
+    for (int i = 16; i < 64; i++)
+      asm volatile("" ::"v"(q[i]));
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      store16_g(outw + k * 1024 + lane * 16, u32x4_g{acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]});
+  }
+  else
+  { // pairs (c, c + 1) with c even: rows [c / 2][lane][2] of 2 * 72 bytes
+    constexpr int kRow2 = 2 * kQ32RowStride;
+#pragma unroll
+    for (int c = 0; c < 64; c += 2)
+    {
+      const uint32_t w = __builtin_amdgcn_perm(q[c + 1], q[c], 0x0c0c0400u); // byte0 = coef c, byte1 = coef c + 1
+      *reinterpret_cast<uint16_t *>(wl + (c / 2) * kRow2 + lane * 2) = (uint16_t)w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // store k, lane l: coefficients c2 = 2 (l & 31), c2 + 1 of group g = 2k + (l >> 5): pair row l & 31, lanes 8g .. 8g+7 = 16 interleaved bytes
+    const uint32_t rd = (lane & 31) * kRow2 + (lane >> 5) * 16;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const uint4 d = *reinterpret_cast<const uint4 *>(wl + rd + k * 32);
+      u32x4_g v;
+      v[0] = __builtin_amdgcn_perm(d.y, d.x, 0x06040200u); // even bytes: coef c2 of blocks 0..3
+      v[1] = __builtin_amdgcn_perm(d.w, d.z, 0x06040200u);
+      v[2] = __builtin_amdgcn_perm(d.y, d.x, 0x07050301u); // odd bytes: coef c2 + 1
+      v[3] = __builtin_amdgcn_perm(d.w, d.z, 0x07050301u);
+      store16_g(outw + k * 1024 + lane * 16, ~v);
+    }
+  }
+}
+
 int main(int argc, char **argv)
 {
   const char *mode = argc > 1 ? argv[1] : "ab";
@@ -229,6 +409,18 @@ int main(int argc, char **argv)
   struct V { const char *name; std::function<void(int)> f; std::vector<float> t; bool check; };
   std::vector<V> vs;
   vs.push_back({"product q32", [&](int s) { launch_fwd_quant_u8(args(s), MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX, false, 0); }, {}, false});
+  const dim3 g64((unsigned)(a.bpr / 64), (unsigned)(H / 8)), g256((unsigned)(a.bpr / 256), (unsigned)(H / 8));
+  vs.push_back({"sa64 6w", [&](int s) { hipLaunchKernelGGL((v_sa64<6, 0>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"sa64 5w", [&](int s) { hipLaunchKernelGGL((v_sa64<5, 0>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"sa64 4w", [&](int s) { hipLaunchKernelGGL((v_sa64<4, 0>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"sa64 6w stagger 4", [&](int s) { hipLaunchKernelGGL((v_sa64<6, 4>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"sa64 6w stagger 8", [&](int s) { hipLaunchKernelGGL((v_sa64<6, 8>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"sa256 6w", [&](int s) { hipLaunchKernelGGL((v_sa256<6>), g256, dim3(256), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"sa256 5w", [&](int s) { hipLaunchKernelGGL((v_sa256<5>), g256, dim3(256), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"tile: lds b8 (product)", [&](int s) { hipLaunchKernelGGL((v_ldscost<0>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"tile: no lds, 48 perm", [&](int s) { hipLaunchKernelGGL((v_ldscost<1>), g64, dim3(64), 0, 0, args(s)); }, {}, false});
+  vs.push_back({"tile: no lds, no pack", [&](int s) { hipLaunchKernelGGL((v_ldscost<2>), g64, dim3(64), 0, 0, args(s)); }, {}, false});
+  vs.push_back({"tile: lds b16 pairs", [&](int s) { hipLaunchKernelGGL((v_ldscost<3>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"early stores 6w", [&](int s) { hipLaunchKernelGGL((v_early<6>), dim3(nwg), dim3(256), 0, 0, args(s)); }, {}, true});
   vs.push_back({"early stores 5w", [&](int s) { hipLaunchKernelGGL((v_early<5>), dim3(nwg), dim3(256), 0, 0, args(s)); }, {}, true});
   {
