@@ -101,6 +101,11 @@ void mdct_shim_set_stream(void *stream);
 void mdct_shim_set_async(int enabled);
 /* frees the calling thread's staging buffers and ends its helper threads now (both also happen when the thread exits) */
 void mdct_shim_release(void);
+/* Optional: pay the one-time costs of the calling thread's first host-pointer call NOW instead of inside it -- HIP and
+ * device initialisation, code-object load, the device mirrors of a plane of `plane_bytes` (sizeX * sizeY) in each
+ * direction, the pinned bounce buffers, streams and helper threads of the chunk pipeline.  A caller that times calls
+ * the way main.cpp:510-523 does otherwise sees one call of ~0.2 s among calls of ~1.5 ms.  Returns 0 / 1 / 2. */
+int mdct_shim_warmup(size_t plane_bytes);
 /* Optional: page-lock a caller-owned host buffer that is reused across calls (hipHostRegister).
  * Host-pointer calls then DMA to/from it in place instead of bouncing through the shim's pinned
  * buffers with memcpy.  Unpin before freeing it.  Returns 0 / 1 / 2 like every entry point. */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "mdct_shim_set_stream": (None, [c_void_p]),
     "mdct_shim_set_async": (None, [c_int]),
     "mdct_shim_release": (None, []),
+    "mdct_shim_warmup": (c_int, [c_size_t]),
     "mdct_shim_pin": (c_int, [c_void_p, c_size_t]),
     "mdct_shim_unpin": (c_int, [c_void_p]),
     "mdct_shim_call": (c_int, _REF),

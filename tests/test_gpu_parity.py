@@ -483,6 +483,41 @@ def test_worker_threads_give_their_staging_back_on_exit():
     assert free0 - free1 < 48 * 1024 * 1024, (free0, free1)
 
 
+def test_shim_warmup_moves_the_one_time_costs_out_of_the_first_call():
+    """mdct_shim_warmup (include/simd_dct_shim.h): on a fresh host thread the first host-pointer call after a warm-up
+    costs what later calls cost (no staging allocation, no helper-thread start inside it), and writes the same bytes"""
+    import threading
+    import time
+
+    from simd_dct_amd import _lib
+
+    W, H = 4096, 4096
+    img = synth.plane_u8_np(W, H, "photo").reshape(-1)
+    lut = lut_x(2000)
+    rc, want = O.run_behaviour("q32_avx", img, lut, W, 2 * H, 0, 2 * H)
+    res = {}
+
+    def work(warm):
+        out = np.zeros(W * H, dtype=np.uint8)
+        if warm:
+            assert _lib.load().mdct_shim_warmup(W * H) == 0
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            assert M.simdDCT_EncodeQuantize32ReorderBuffer(img, out, lut, W, 2 * H, 0, 2 * H) == 0
+            ts.append(time.perf_counter() - t0)
+        assert np.array_equal(out, want)
+        res[warm] = ts
+
+    for warm in (False, True):  # each on its own thread: staging is per host thread
+        t = threading.Thread(target=work, args=(warm,))
+        t.start()
+        t.join()
+    steady = min(res[True][1:] + res[False][1:])
+    assert res[True][0] < 3 * steady + 2e-3, res   # warmed: the first call is an ordinary call
+    assert _lib.load().mdct_shim_warmup(0) == 0     # idempotent, any size
+
+
 def test_pitched_output_strips():
     """mdct_fwd_quant_u8_pitched: Q32 and BLOCK strips at a caller-chosen pitch; the padding keeps
     the canary, the strips equal the tight result"""
@@ -521,6 +556,13 @@ def test_cxx_cli_on_the_reference_api(tmp_path):
                                capture_output=True, text=True, timeout=120)
             assert r.returncode == 0, r.stdout + r.stderr
             assert "sdr_Success" in r.stdout
+            # the reference's table (main.cpp:72-73: min / mean clk/byte, min / mean MiB/s) plus GB/s and the roofline shares
+            head = next(l for l in r.stdout.splitlines() if l.startswith("mode "))
+            for col in ("min clk/byte", "mean clk/byte (sigma)", "min MiB/s (nominal)", "mean MiB/s", "alg. GB/s", "% of 8 TB/s", "% of measured copy"):
+                assert col in head, (col, head)
+            row = [c.strip() for c in next(l for l in r.stdout.splitlines() if l.startswith(mode + " ")).split("|")]
+            assert len(row) == len(head.split("|")) and float(row[2]) > 0 and float(row[4].split()[0]) > 0  # clk/byte and ns/byte were measured
+            assert (row[-1] != "-") == bool(extra) and ("measured copy of" in r.stdout) == bool(extra)  # copy roofline: --resident only
             got = np.fromfile(dump, dtype=np.uint8)
             rc, want = O.run_behaviour(beh, img, lut_x(8), W, H, 0, H)
             assert np.array_equal(got, want), (mode, extra)

@@ -1,5 +1,5 @@
 """Launch ONE engine kernel repeatedly on the bench workload (for rocprofv3 --pmc passes):
-    python3 tools/run_kernel.py {roundtrip|fwd|inv|q32|copy|huffman|huffman_k1} [launches]"""
+    python3 tools/run_kernel.py {roundtrip|fwd|inv|q32|stereo_sse|encq_sse|stereo_scalar|encq_scalar|scan_q32|u8_records|copy|huffman|huffman_k1} [launches]"""
 import os
 import sys
 
@@ -38,6 +38,17 @@ if which.startswith("huffman"):
     hnb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     print("pairs per block", float(recs[0][2].float().mean()))
+lut8 = (M.QUANTIZE_BASE * np.float32(8)).astype(np.float32)
+U8 = {"stereo_sse": (M.LAYOUT_STEREO, M.PROFILE_REF_SSE, H // 16), "encq_sse": (M.LAYOUT_BLOCK_SSE, M.PROFILE_REF_SSE, H // 8),
+      "stereo_scalar": (M.LAYOUT_STEREO, M.PROFILE_REF_SCALAR, H // 16), "encq_scalar": (M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, H // 8)}
+if which in ("scan_q32", "u8_records"):
+    nblk = (W // 8) * (H // 8)
+    lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
+    rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
+    ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
+    q60 = (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32)
+    for s_ in range(4):
+        M.fwd_quant_u8(u8s[s_], u8d[s_], lut, W, H, 0, H // 8)
 torch.cuda.synchronize()
 for i in range(n):
     s = i % 4
@@ -49,6 +60,12 @@ for i in range(n):
         M.inv_i16(srcs[s], dsts[s], W, H)
     elif which == "q32":
         M.fwd_quant_u8(u8s[s], u8d[s], lut, W, H, 0, H // 8)
+    elif which in U8:
+        M.fwd_quant_u8(u8s[s], u8d[s], lut8, W, H, 0, U8[which][2], layout=U8[which][0], profile=U8[which][1])
+    elif which == "scan_q32":
+        M.zigzag_rle_q32(u8d[s], W, H, lv, rn, ct)
+    elif which == "u8_records":
+        M.fwd_u8_records(u8s[s], W, H, lv, rn, ct, lut=q60)
     elif which.startswith("huffman"):
         M.huffman_rows(*recs[i % 2], W, H, hseg, hnb)
     elif which == "copy":

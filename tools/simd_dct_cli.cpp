@@ -9,15 +9,17 @@
 //
 //   simd_dct_cli <raw_grayscale_image_file | synthetic:noise | synthetic:photo> <X> <Y>
 //        [--to <file>] [--quality <n>] [--runs <n>] [--mode enc-quant|enc-quant32|enc-quant-stereo]...
-//        [--max-simd avx512bw|avx512f|avx2|avx|sse4.2|sse4.1|ssse3|sse3|sse2|none] [--cpu-core <n>] [--resident] [--pin] [--device <n>]
+//        [--max-simd avx512bw|avx512f|avx2|avx|sse4.2|sse4.1|ssse3|sse3|sse2|none] [--cpu-core <n>] [--resident] [--pin] [--cold] [--device <n>] [--gpus <n>]
 //
 // Build: hipcc -O2 -std=c++17 -Iinclude tools/simd_dct_cli.cpp -Lsimd_dct_amd -lmdct_hip -Wl,-rpath,'$ORIGIN/../simd_dct_amd' -o tools/simd_dct_cli
 #include <hip/hip_runtime_api.h>
 #include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <x86intrin.h>
 
 #include <atomic>
 
@@ -77,6 +79,7 @@ struct Stats
   double min_ns, mean_ns, sd_ns;
 };
 
+// min / mean / sigma of one series (nanoseconds or TSC clocks alike)
 Stats stats(const std::vector<double> &ns)
 {
   Stats s{1e300, 0, 0};
@@ -99,11 +102,24 @@ struct Shared
 {
   unsigned char id[MDCT_UNIQUE_ID_BYTES];
   std::atomic<int> id_ready;
+  std::atomic<int> abort; // a rank failed: nobody enters another collective
   double compute_ns[64], gather_ns[64];
   int rc[64];
 };
 
+int run_rank_body(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file);
+
+// whatever goes wrong in a rank, the others learn of it before their next collective (and the parent ends those that
+// are already inside one, run_multi_gpu)
 int run_rank(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file)
+{
+  const int rc = run_rank_body(sh, rank, world, in, X, Y, table, stereo, runs, out_file);
+  if (rc != 0)
+    sh->abort.store(1);
+  return rc;
+}
+
+int run_rank_body(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file)
 {
   if (mdct_init(rank) != MDCT_SUCCESS)
   {
@@ -120,9 +136,9 @@ int run_rank(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, si
     }
     sh->id_ready.store(1);
   }
-  while (sh->id_ready.load() == 0)
+  while (sh->id_ready.load() == 0 && !sh->abort.load())
     usleep(1000);
-  if (sh->id_ready.load() < 0)
+  if (sh->id_ready.load() <= 0 || sh->abort.load())
     return 2;
   mdct_comm *comm = nullptr;
   if (mdct_comm_init(&comm, rank, world, sh->id) != MDCT_SUCCESS)
@@ -160,6 +176,12 @@ int run_rank(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, si
       break;
     }
     const double t1 = now_ns();
+    if (sh->abort.load())
+    {
+      printf("rank %d: another rank failed, leaving before the all-gather\n", rank);
+      rc = 3;
+      break;
+    }
     const int g = stereo ? mdct_allgather_stereo(comm, d_out, X, Y, stream) : mdct_allgather_rows(comm, d_out, 8 * X, Y / 8, stream);
     if (g != MDCT_SUCCESS || hipStreamSynchronize(stream) != hipSuccess)
     {
@@ -203,6 +225,7 @@ int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y,
     return 2;
   new (sh) Shared();
   sh->id_ready.store(0);
+  sh->abort.store(0);
   std::vector<pid_t> kids;
   for (int r = 0; r < world; r++)
   {
@@ -211,13 +234,47 @@ int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y,
       _exit(run_rank(sh, r, world, in, X, Y, table, stereo, runs, out_file));
     kids.push_back(p);
   }
+  // Poll, with a deadline: a rank that fails while the others are already inside a collective (ncclCommInitRank, the
+  // all-gather) would leave them blocked for good.  Once one rank has failed the rest get a grace period, then SIGKILL;
+  // the same when the whole job exceeds MDCT_CLI_GPUS_TIMEOUT seconds (default 600).
+  const char *te = getenv("MDCT_CLI_GPUS_TIMEOUT");
+  const double deadline_ns = now_ns() + (te ? atof(te) : 600.0) * 1e9;
   int rc = 0;
-  for (pid_t p : kids)
+  size_t alive = kids.size();
+  std::vector<bool> done(kids.size(), false);
+  double kill_at_ns = 0;
+  while (alive)
   {
-    int st = 0;
-    waitpid(p, &st, 0);
-    const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 4;
-    rc = code > rc ? code : rc;
+    for (size_t i = 0; i < kids.size(); i++)
+    {
+      if (done[i])
+        continue;
+      int st = 0;
+      const pid_t w = waitpid(kids[i], &st, WNOHANG);
+      if (w == 0)
+        continue;
+      done[i] = true;
+      alive--;
+      const int code = (w > 0 && WIFEXITED(st)) ? WEXITSTATUS(st) : 4;
+      rc = code > rc ? code : rc;
+      if (code != 0 && kill_at_ns == 0)
+      {
+        sh->abort.store(1);
+        kill_at_ns = now_ns() + 5e9;
+      }
+    }
+    const double t = now_ns();
+    if (alive && ((kill_at_ns != 0 && t > kill_at_ns) || t > deadline_ns))
+    {
+      printf("--gpus: %s; ending %zu remaining rank(s)\n", t > deadline_ns ? "timed out" : "a rank failed", alive);
+      for (size_t i = 0; i < kids.size(); i++)
+        if (!done[i])
+          kill(kids[i], SIGKILL);
+      rc = rc ? rc : 5;
+      kill_at_ns = deadline_ns + 1e18; // once
+    }
+    if (alive)
+      usleep(2000);
   }
   if (rc == 0)
   {
@@ -252,6 +309,7 @@ int main(int argc, char **argv)
     puts("\t--mode <enc-quant / enc-quant32 / enc-quant-stereo>\tOnly execute a specified mode (repeatable).");
     puts("\t--resident\t\t\tKeep input and output in HBM (device pointers through the same API).");
     puts("\t--pin\t\t\t\tPage-lock the host buffers once (mdct_shim_pin): host-pointer calls then DMA in place.");
+    puts("\t--cold\t\t\t\tDo not call mdct_shim_warmup() first: the first run then contains the one-time initialisation.");
     puts("\t--device <n>\t\t\tHIP device ordinal.");
     puts("\t--gpus <n>\t\t\tOne process per GPU: block rows sharded, coefficients all-gathered over RCCL (enc-quant32 or enc-quant-stereo, device-resident).");
     return 1;
@@ -266,7 +324,7 @@ int main(int argc, char **argv)
   const char *out_file = nullptr;
   size_t runs = 128; // main.cpp:21
   float quality = 1.0f;
-  bool resident = false, pin = false;
+  bool resident = false, pin = false, cold = false;
   int device = 0, max_simd = MDCT_SIMD_AVX2, gpus = 0;
   bool m_encq = false, m_q32 = false, m_stereo = false;
   for (int i = 4; i < argc; i++)
@@ -278,6 +336,7 @@ int main(int argc, char **argv)
     else if (a == "--runs") runs = strtoull(next(), nullptr, 10);
     else if (a == "--resident") resident = true;
     else if (a == "--pin") pin = true;
+    else if (a == "--cold") cold = true;
     else if (a == "--device") device = atoi(next());
     else if (a == "--gpus") gpus = atoi(next());
     else if (a == "--mode")
@@ -379,6 +438,24 @@ int main(int argc, char **argv)
     p_out = d_out;
   }
 
+  if (!cold && mdct_shim_warmup(fileSize) != MDCT_SUCCESS)
+    printf("mdct_shim_warmup failed: %s\n", mdct_last_error());
+  // --resident: this box's measured copy rate for the same footprint (read N + write N bytes), the "measured roofline"
+  double copy_GBps = 0;
+  if (resident)
+  {
+    for (int i = 0; i < 20; i++)
+      (void)mdct_stream_copy(d_in, d_out, fileSize, nullptr);
+    (void)hipDeviceSynchronize();
+    const int reps = 50;
+    const double t0 = now_ns();
+    for (int i = 0; i < reps; i++)
+      (void)mdct_stream_copy(d_in, d_out, fileSize, nullptr);
+    (void)hipDeviceSynchronize();
+    copy_GBps = 2.0 * fileSize * reps / (now_ns() - t0);
+    (void)hipMemset(d_out, 0, fileSize);
+  }
+
   struct Mode
   {
     const char *name;
@@ -387,19 +464,27 @@ int main(int argc, char **argv)
     double covered; // fraction of the plane the reference semantics really transform
   };
   const Mode modes[] = {{"enc-quant", m_encq, simdDCT_EncodeQuantizeBuffer, 0.5}, {"enc-quant32", m_q32, simdDCT_EncodeQuantize32ReorderBuffer, 0.5}, {"enc-quant-stereo", m_stereo, simdDCT_EncodeQuantizeReorderStereoBuffer, 1.0}};
-  puts("mode             | result               |   min ns/byte |  mean ns/byte (sigma) |  min MiB/s (nominal) | mean MiB/s | actual Mpx/s (min) | alg. GB/s");
+  // the reference's columns (print_perf_info, main.cpp:72-73: min and mean clk/byte, min and mean MiB/s, nominal = whole
+  // file / time) next to ns/byte, the pixels really transformed, algorithmic GB/s (2 B/px) and its share of the HBM
+  // spec (8 TB/s) and of the copy rate measured above (--resident only)
+  puts("mode             | result               |  min clk/byte | mean clk/byte (sigma) |   min ns/byte |  mean ns/byte (sigma) |  min MiB/s (nominal) | mean MiB/s | actual Mpx/s (min) | alg. GB/s | % of 8 TB/s | % of measured copy");
+  if (resident)
+    printf("(measured copy of %.1f MiB in + out: %.1f GB/s)\n", fileSize / 1048576.0, copy_GBps);
   int rc_all = 0;
   for (const Mode &m : modes)
   {
     if (!m.on)
       continue;
-    std::vector<double> ns(runs);
+    std::vector<double> ns(runs), clk(runs);
     simdDctResult r = sdr_Success;
     for (size_t i = 0; i < runs && r == sdr_Success; i++)
     {
       const double t0 = now_ns();
+      const uint64_t c0 = __rdtsc();            // main.cpp:512
       r = m.fn(p_in, p_out, table, X, Y, 0, Y); // main.cpp:514
+      const uint64_t c1 = __rdtsc();
       ns[i] = now_ns() - t0;
+      clk[i] = (double)(c1 - c0);
     }
     if (r != sdr_Success)
     {
@@ -407,11 +492,15 @@ int main(int argc, char **argv)
       rc_all = 3;
       continue;
     }
-    const Stats s = stats(ns);
+    const Stats s = stats(ns), c = stats(clk);
     const double mib = fileSize / (1024.0 * 1024.0);
     const double px = fileSize * m.covered;
-    printf("%-16s | %-20s | %13.5f | %10.5f (%8.5f) | %20.2f | %10.2f | %18.1f | %9.1f\n", m.name, result_name(r), s.min_ns / fileSize, s.mean_ns / fileSize, s.sd_ns / fileSize, mib / (s.min_ns * 1e-9),
-           mib / (s.mean_ns * 1e-9), px / (s.min_ns * 1e-9) / 1e6, 2.0 * px / s.min_ns);
+    const double alg = 2.0 * px / s.min_ns; // bytes per ns == GB/s
+    char of_copy[32] = "-";
+    if (copy_GBps > 0)
+      snprintf(of_copy, sizeof of_copy, "%.1f", 100.0 * alg / copy_GBps);
+    printf("%-16s | %-20s | %13.5f | %10.5f (%8.5f) | %13.5f | %10.5f (%8.5f) | %20.2f | %10.2f | %18.1f | %9.1f | %11.1f | %18s\n", m.name, result_name(r), c.min_ns / fileSize, c.mean_ns / fileSize,
+           c.sd_ns / fileSize, s.min_ns / fileSize, s.mean_ns / fileSize, s.sd_ns / fileSize, mib / (s.min_ns * 1e-9), mib / (s.mean_ns * 1e-9), px / (s.min_ns * 1e-9) / 1e6, alg, 100.0 * alg / 8000.0, of_copy);
   }
 
   if (out_file)
