@@ -318,15 +318,15 @@ def main():
         u8d = [torch.zeros(W * H, dtype=torch.uint8, device="cuda") for _ in range(NSETS)]  # zeroed: the SSE encq tier leaves half of every block pair untouched (simd_dct.cpp:1662-1676)
         # (kernel name, table scale, layout, profile, block rows of the call, golden key, reference lines)
         products = {
-            "fwd_quant_u8_q32": ("mdct::k_q32_avx<false, false>", 2000, M.LAYOUT_Q32, M.PROFILE_REF_AVX, H // 8, "q32_avx__photo__8192x8192__x2000__full",
+            "fwd_quant_u8_q32": ("mdct::k_q32_tile", 2000, M.LAYOUT_Q32, M.PROFILE_REF_AVX, H // 8, "q32_avx__photo__8192x8192__x2000__full",
                                  "simdDCT_EncodeQuantize32ReorderBuffer, AVX2 = AVX-512VL tier, simd_dct.cpp:2064-2262"),
-            "fwd_quant_u8_stereo_sse": ("mdct::k_fwd_quant_u8<REF_SSE, STEREO, false>", 8, M.LAYOUT_STEREO, M.PROFILE_REF_SSE, H // 16, "stereo_sse__photo__8192x8192__x8",
+            "fwd_quant_u8_stereo_sse": ("mdct::k_fwd_quant_u8<REF_SSE, STEREO, false, TILED>", 8, M.LAYOUT_STEREO, M.PROFILE_REF_SSE, H // 16, "stereo_sse__photo__8192x8192__x8",
                                         "simdDCT_EncodeQuantizeReorderStereoBuffer, SSE4.1 = SSSE3 = SSE2 tiers, simd_dct.cpp:896-1103"),
-            "fwd_quant_u8_stereo_scalar": ("mdct::k_fwd_quant_u8<REF_SCALAR, STEREO, false>", 8, M.LAYOUT_STEREO, M.PROFILE_REF_SCALAR, H // 16, "stereo_scalar__photo__8192x8192__x8",
+            "fwd_quant_u8_stereo_scalar": ("mdct::k_fwd_quant_u8<REF_SCALAR, STEREO, false, TILED>", 8, M.LAYOUT_STEREO, M.PROFILE_REF_SCALAR, H // 16, "stereo_scalar__photo__8192x8192__x8",
                                            "simdDCT_EncodeQuantizeReorderStereoBuffer, scalar tier, simd_dct.cpp:177-298"),
-            "fwd_quant_u8_encq_sse": ("mdct::k_fwd_quant_u8<REF_SSE, BLOCK_SSE, false>", 8, M.LAYOUT_BLOCK_SSE, M.PROFILE_REF_SSE, H // 8, "encq_sse__photo__8192x8192__x8__full",
+            "fwd_quant_u8_encq_sse": ("mdct::k_fwd_quant_u8<REF_SSE, BLOCK_SSE, false, TILED>", 8, M.LAYOUT_BLOCK_SSE, M.PROFILE_REF_SSE, H // 8, "encq_sse__photo__8192x8192__x8__full",
                                       "simdDCT_EncodeQuantizeBuffer, SSE4.1 = SSSE3 tiers (half-written block pairs), simd_dct.cpp:1540-1704"),
-            "fwd_quant_u8_encq_scalar": ("mdct::k_fwd_quant_u8<REF_SCALAR, BLOCK, false>", 8, M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, H // 8, "encq_scalar__photo__8192x8192__x8__full",
+            "fwd_quant_u8_encq_scalar": ("mdct::k_fwd_quant_u8<REF_SCALAR, BLOCK, false, TILED>", 8, M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, H // 8, "encq_scalar__photo__8192x8192__x8__full",
                                          "simdDCT_EncodeQuantizeBuffer, scalar tier, simd_dct.cpp:300-395"),
         }
         # VALU-heavy kernels after HBM-bound ones: the change of load sends the chip through a ~400-launch power-management

@@ -494,7 +494,7 @@ def test_shim_warmup_moves_the_one_time_costs_out_of_the_first_call():
     W, H = 4096, 4096
     img = synth.plane_u8_np(W, H, "photo").reshape(-1)
     lut = lut_x(2000)
-    rc, want = O.run_behaviour("q32_avx", img, lut, W, 2 * H, 0, 2 * H)
+    rc, want = O.q32_native(img.reshape(H, W), lut, W, H, 0, H // 8)  # the sizeY = 2H call form covers the whole plane
     res = {}
 
     def work(warm):

@@ -1,7 +1,7 @@
 """Steady-state duration per kernel from a rocprofv3 --kernel-trace run of bench.py:
     python3 tools/trace_steady.py <trace dir>
 bench.py times every kernel after untimed pre-conditioning launches, back to back: for each kernel name the LAST run of
-consecutive dispatches of that kernel is its timed region (plus warm-up); the statistics below are over the last
+consecutive dispatches is what matters; the LONGEST such run of a kernel is its pre-conditioning + warm-up + timed region; the statistics below are over the last
 `n_timed` dispatches of that run (2000 for the headline kernel, 500 for the u8 products, 100-200 for the others), so the
 from-idle power transient and the verification launches are outside."""
 import csv
@@ -24,8 +24,8 @@ for r in rows:
     else:
         runs.append([k, [r]])
 last_run = {}
-for k, rs in runs:
-    if "mdct::" in k and len(rs) >= 50:
+for k, rs in runs:  # the longest back-to-back run of each kernel = its pre-conditioning + warm-up + timed region
+    if "mdct::" in k and len(rs) >= 50 and len(rs) > len(last_run.get(k, [])):
         last_run[k] = rs
 print(f"{'kernel':88s} {'n':>5s} {'mean ns':>9s} {'median':>8s} {'min':>8s} {'gap':>6s}")
 for k, rs in sorted(last_run.items()):
