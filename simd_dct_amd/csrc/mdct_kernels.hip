@@ -1128,6 +1128,31 @@ __device__ __forceinline__ void st_stream16(void *p, uint32_t x, uint32_t y, uin
   __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
 }
 
+// Where a lane finds the eight 16-byte rows of its block.  Linear: one pointer per lane (any shape).  Tiled: the wave's 64
+// blocks lie in one block row; `src` / `dst` are the wave-uniform addresses of row 0 of its first block (kept in SGPRs,
+// sgpr_ptr) and the lane adds a 32-bit offset -- no per-lane 64-bit address arithmetic, 2 address registers instead of 32.
+struct RowsLinear
+{
+  const int16_t *src;
+  int16_t *dst;
+  size_t pitch_in, pitch_out; // elements
+  __device__ __forceinline__ uint4 ld(int r) const { return ld_stream16(src + (size_t)r * pitch_in); }
+  __device__ __forceinline__ void st(int r, uint32_t x, uint32_t y, uint32_t z, uint32_t w) const { st_stream16(dst + (size_t)r * pitch_out, x, y, z, w); }
+};
+struct RowsTiled
+{
+  const int16_t *src;
+  int16_t *dst;
+  size_t pitch_in, pitch_out; // elements
+  uint32_t lane_off;          // bytes
+  __device__ __forceinline__ uint4 ld(int r) const
+  {
+    const u32x4_g v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_g __attribute__((address_space(1))) *>(sgpr_ptr(src + (size_t)r * pitch_in) + lane_off));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  __device__ __forceinline__ void st(int r, uint32_t x, uint32_t y, uint32_t z, uint32_t w) const { store16_g(sgpr_ptr(dst + (size_t)r * pitch_out) + lane_off, u32x4_g{x, y, z, w}); }
+};
+
 __device__ __forceinline__ void unpack_i16x8(const uint4 v, float (&row)[8])
 {
   row[0] = (float)(int16_t)(v.x & 0xFFFF); row[1] = (float)(int16_t)(v.x >> 16);
@@ -1170,13 +1195,13 @@ __device__ __forceinline__ void store_i16x8(const DctConsts &C, int16_t *dst, co
   st_stream16(dst, pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
 }
 
-template <int MODE, bool HAS_LUT>
-__device__ __forceinline__ void i16_block(const DctConsts &C, const int16_t *src, int16_t *dst, size_t pitch_in, size_t pitch_out, const OwnTables &tb)
+template <int MODE, bool HAS_LUT, class Rows>
+__device__ __forceinline__ void i16_block(const DctConsts &C, const Rows rows, const OwnTables &tb)
 {
   float b[8][8];
 #pragma unroll
   for (int r = 0; r < 8; r++)
-    unpack_i16x8(ld_stream16(src + (size_t)r * pitch_in), b[r]);
+    unpack_i16x8(rows.ld(r), b[r]);
 
   if constexpr (MODE == MODE_INV)
   {
@@ -1208,7 +1233,13 @@ __device__ __forceinline__ void i16_block(const DctConsts &C, const int16_t *src
   constexpr int SHIFT = (MODE == MODE_ROUNDTRIP && !HAS_LUT) ? 6 : 0;
 #pragma unroll
   for (int r = 0; r < 8; r++)
-    store_i16x8<SHIFT>(C, dst + (size_t)r * pitch_out, b[r]);
+  {
+    uint32_t t[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++)
+      t[c] = rne_i16_bits<SHIFT>(C, b[r][c]);
+    rows.st(r, pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
+  }
 }
 
 // The AAN butterflies on packed fp32 (fused round trip; profiles/r02_exp_i16_packed.log).  Same idea as the u8
@@ -1333,14 +1364,36 @@ __device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, 
 // inverse rows (h).  With a table, `tb` holds the multipliers in the pair order of the column pass,
 // (v*4 + j)*2 + {0,1} = coefficient (v, A[j]) / (v, B[j]) with A = {0,2,5,1}, B = {4,6,3,7}: the pairs aan_fwd_h
 // produces and aan_inv_h consumes (mdct_api.hip: make_own_tables).
+// PRIO: the wave raises its issue priority as it advances (forward rows 1, columns 2, inverse rows + stores 3), so that of
+// the waves sharing a SIMD the one closest to its stores goes first (shortest remaining work first)
+template <bool HAS_LUT, class Rows, bool PRIO = false>
+__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, const OwnTables &tb);
+
 template <bool HAS_LUT>
 __device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16_t *src, int16_t *dst, size_t pitch_in, size_t pitch_out, const OwnTables &tb)
+{
+  i16_roundtrip_rows<HAS_LUT>(C, RowsLinear{src, dst, pitch_in, pitch_out}, tb);
+}
+
+#define MDCT_PHASE_PRIO(n)                   \
+  do                                         \
+  {                                          \
+    if constexpr (PRIO)                      \
+    {                                        \
+      __builtin_amdgcn_sched_barrier(0);     \
+      __builtin_amdgcn_s_setprio(n);         \
+      __builtin_amdgcn_sched_barrier(0);     \
+    }                                        \
+  } while (0)
+template <bool HAS_LUT, class Rows, bool PRIO>
+__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, const OwnTables &tb)
 {
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
   uint4 in[8];
 #pragma unroll
   for (int r = 0; r < 8; r++)
-    in[r] = ld_stream16(src + (size_t)r * pitch_in);
+    in[r] = rows.ld(r);
+  MDCT_PHASE_PRIO(1);
   f32x2 P[4][8];
 #pragma unroll
   for (int r = 0; r < 8; r++)
@@ -1351,6 +1404,7 @@ __device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16
     const f32x2 a67 = {(float)(int16_t)(in[r].w & 0xFFFF), (float)(int16_t)(in[r].w >> 16)};
     aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
   }
+  MDCT_PHASE_PRIO(2);
 #pragma unroll
   for (int j = 0; j < 4; j++)
   {
@@ -1372,6 +1426,7 @@ __device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16
     }
     aan_inv_v(K, P[j]);
   }
+  MDCT_PHASE_PRIO(3);
   // without a table forward-scale * inverse-scale == 1/64 exactly and rides in the final rounding (rne_i16_bits<6>)
   constexpr float scale = HAS_LUT ? 1.0f : 64.0f;
 #pragma unroll
@@ -1390,8 +1445,8 @@ __device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16
       return t;
     };
     const f32x2 b07 = fin(o07), b16 = fin(o16), b25 = fin(o25), b43 = fin(o43);
-    st_stream16(dst + (size_t)r * pitch_out, pack_lo16(__float_as_uint(b07.x), __float_as_uint(b16.x)), pack_lo16(__float_as_uint(b25.x), __float_as_uint(b43.y)),
-                pack_lo16(__float_as_uint(b43.x), __float_as_uint(b25.y)), pack_lo16(__float_as_uint(b16.y), __float_as_uint(b07.y)));
+    rows.st(r, pack_lo16(__float_as_uint(b07.x), __float_as_uint(b16.x)), pack_lo16(__float_as_uint(b25.x), __float_as_uint(b43.y)),
+            pack_lo16(__float_as_uint(b43.x), __float_as_uint(b25.y)), pack_lo16(__float_as_uint(b16.y), __float_as_uint(b07.y)));
   }
 }
 
@@ -1415,7 +1470,26 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
   if constexpr (MODE == MODE_ROUNDTRIP)
     i16_roundtrip_pk<HAS_LUT>(a.consts, src, dst, a.pitch_in, a.pitch_out, a.tb);
   else
-    i16_block<MODE, HAS_LUT>(a.consts, src, dst, a.pitch_in, a.pitch_out, a.tb);
+    i16_block<MODE, HAS_LUT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, a.tb);
+}
+
+// The same for launches whose waves each lie in one block row (sizeX % 512 == 0): one workgroup = one wave = one 64-block
+// tile, 2-D grid (x = tile in the row, y = block row), wave-uniform addressing (RowsTiled).  One-wave workgroups matter
+// here: the per-wave timeline of the 4-wave form (profiles/r03_i16_timeline.md) shows a SIMD's slots idle 45 % of the
+// time with 2 of 3 waves resident -- a freed slot waits until the other three waves of its workgroup are done too.
+// scheduling steered per mode like k_i16 (measured, profiles/r03_exp_i16_tile_and_priorities.log): forward 42.7 us with 2
+// (44.1 with 3, 45.1 with 4; k_i16<FWD> 43.7; the copy kernel 43.4), inverse 43.2 with 2 (45.1 with 4; k_i16<INV> 45.4),
+// fused round trip 45.4-45.7 with 3 or 4 (47.5 with 2; k_i16<ROUNDTRIP> 47.1-48.0); with a table the round trip needs 160 registers
+constexpr int i16_tile_waves(int mode, bool has_lut) { return mode == MODE_ROUNDTRIP ? 3 : 2; }
+template <int MODE, bool HAS_LUT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(i16_tile_waves(MODE, HAS_LUT), i16_tile_waves(MODE, HAS_LUT)))) void k_i16_tile(I16Args a)
+{
+  const size_t by = a.by0 + blockIdx.y;
+  const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
+  if constexpr (MODE == MODE_ROUNDTRIP)
+    i16_roundtrip_rows<HAS_LUT>(a.consts, rows, a.tb);
+  else
+    i16_block<MODE, HAS_LUT>(a.consts, rows, a.tb);
 }
 
 // 8-bit pixels <-> int16 coefficients (JPEG-style pair): u8 rows are 8 B per lane (512 B per wave
@@ -1798,9 +1872,22 @@ hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool sa
   return hipErrorInvalidValue;
 }
 
+#ifndef MDCT_I16_TILED
+#define MDCT_I16_TILED 1
+#endif
 template <int MODE>
 static hipError_t launch_i16_m(const I16Args &a, bool has_lut, hipStream_t s)
 {
+  const uint32_t launch_rows = a.nblocks / a.bpr;
+  if (MDCT_I16_TILED && a.bpr % 64 == 0 && launch_rows <= 65535u)
+  {
+    const dim3 g(a.bpr / 64, launch_rows);
+    if (has_lut)
+      hipLaunchKernelGGL((k_i16_tile<MODE, true>), g, dim3(64), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_i16_tile<MODE, false>), g, dim3(64), 0, s, a);
+    return hipGetLastError();
+  }
   if (has_lut)
     hipLaunchKernelGGL((k_i16<MODE, true>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
   else

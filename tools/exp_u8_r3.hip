@@ -344,6 +344,65 @@ __global__ __launch_bounds__(64, 6) void v_ldscost(U8Args a)
   }
 }
 
+// the fused int16 round trip (k_i16<MODE_ROUNDTRIP, false>), stamped: 0 entry, 1 all 8 rows arrived, 3 stores issued, 4 acknowledged
+// (stamp 2 unused: transform and stores interleave row by row)
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(3, 3))) void v_timeline_i16(I16Args a, Stamp *stamps)
+{
+  STAMP(0);
+  const uint32_t t = blockIdx.x * kWG + threadIdx.x;
+  const uint32_t row = t / a.bpr;
+  const uint32_t bx = t - row * a.bpr;
+  const size_t by = a.by0 + row;
+  const int16_t *src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
+  int16_t *dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
+  i16_roundtrip_pk<false>(a.consts, src, dst, a.pitch_in, a.pitch_out, a.tb);
+  STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  STAMP(4);
+  if ((threadIdx.x & 63) == 0)
+  {
+    Stamp *s = stamps + ((blockIdx.x * kWG + (threadIdx.x & ~63u)) >> 6);
+    s->hw_id = GETREG(4);
+    s->xcc_id = GETREG(20);
+    s->wave_t0 = blockIdx.x * kWG + (threadIdx.x & ~63u);
+    s->pad = 0;
+    s->rt[1] = s->rt[2] = 0;
+    s->ck[1] = s->ck[2] = 0;
+  }
+}
+
+// int16 fused round trip as one-wave workgroups on a 2-D grid with wave-uniform addressing, occupancy steered to WAVES
+template <int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void v_i16_tile(I16Args a)
+{
+  const size_t by = a.by0 + blockIdx.y;
+  const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
+  i16_roundtrip_rows<false>(a.consts, rows, a.tb);
+}
+template <int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void v_i16_tile_prio(I16Args a)
+{
+  const size_t by = a.by0 + blockIdx.y;
+  const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
+  i16_roundtrip_rows<false, RowsTiled, true>(a.consts, rows, a.tb);
+}
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void v_i16_tile_mode(I16Args a)
+{
+  const size_t by = a.by0 + blockIdx.y;
+  const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
+  i16_block<MODE, false>(a.consts, rows, a.tb);
+}
+// the same addressing in 4-wave workgroups (256 consecutive blocks of one block row)
+template <int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void v_i16_tile256(I16Args a)
+{
+  const size_t by = a.by0 + blockIdx.y;
+  const uint32_t tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)tile * 512, a.to + by * 8 * a.pitch_out + (size_t)tile * 512, a.pitch_in, a.pitch_out, (threadIdx.x & 63) * 16};
+  i16_roundtrip_rows<false>(a.consts, rows, a.tb);
+}
+
 int main(int argc, char **argv)
 {
   const char *mode = argc > 1 ? argv[1] : "ab";
@@ -401,6 +460,102 @@ int main(int argc, char **argv)
     hipLaunchKernelGGL((v_timeline<6>), dim3(nwg), dim3(256), 0, 0, args(0), d);
     hipMemcpy(got.data(), B[0], bytes, hipMemcpyDeviceToHost);
     printf("timeline kernel %s; %u waves -> %s\n", memcmp(ref.data(), got.data(), bytes) ? "!! MISMATCH" : "bit-exact", nwaves, path);
+    return 0;
+  }
+
+  if (!strcmp(mode, "timeline_i16") || !strcmp(mode, "ab_i16"))
+  {
+    const size_t b16 = W * H * 2;
+    int16_t *S[NS], *D[NS];
+    for (int i = 0; i < NS; i++)
+    {
+      if (hipMalloc(&S[i], b16) != hipSuccess || hipMalloc(&D[i], b16) != hipSuccess) { puts("alloc failed"); return 1; }
+      hipMemcpy(S[i], host.data(), bytes, hipMemcpyHostToDevice);
+      hipMemcpy(reinterpret_cast<uint8_t *>(S[i]) + bytes, host.data(), bytes, hipMemcpyHostToDevice);
+    }
+    I16Args ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.consts = DctConsts();
+    ia.pitch_in = ia.pitch_out = W; ia.bpr = W / 8; ia.by0 = 0; ia.nblocks = (uint32_t)(W / 8 * H / 8);
+    auto iargs = [&](int s) { I16Args x = ia; x.from = S[s]; x.to = D[s]; return x; };
+    if (!strcmp(mode, "ab_i16"))
+    {
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      struct V { const char *name; std::function<void(int)> f; std::vector<float> t; };
+      std::vector<V> vs;
+      const dim3 g64((unsigned)(W / 512), (unsigned)(H / 8)), g256((unsigned)(W / 2048), (unsigned)(H / 8));
+      vs.push_back({"launch_i16 (library default)", [&](int s) { launch_i16(iargs(s), MODE_ROUNDTRIP, false, 0); }, {}});
+      vs.push_back({"k_i16<ROUNDTRIP> linear 256", [&](int s) { hipLaunchKernelGGL((k_i16<MODE_ROUNDTRIP, false>), dim3(nwg), dim3(256), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 64 thr, 2 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile<2>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 64 thr, 3 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile<3>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 64 thr, 4 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile<4>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 64 thr, 5 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile<5>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 64 thr, 6 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile<6>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 64 thr, 3 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_i16_tile_prio<3>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 64 thr, 4 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_i16_tile_prio<4>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 64 thr, 6 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_i16_tile_prio<6>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 256 thr, 3 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile256<3>), g256, dim3(256), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 256 thr, 4 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile256<4>), g256, dim3(256), 0, 0, iargs(s)); }, {}});
+      const size_t n_rt = vs.size();
+      vs.push_back({"fwd: k_i16<FWD> linear 256", [&](int s) { hipLaunchKernelGGL((k_i16<MODE_FWD, false>), dim3(nwg), dim3(256), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"fwd: tile 64 thr, 2 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile_mode<MODE_FWD, 2>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"fwd: tile 64 thr, 3 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile_mode<MODE_FWD, 3>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"fwd: tile 64 thr, 4 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile_mode<MODE_FWD, 4>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"fwd: tile 64 thr, 6 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile_mode<MODE_FWD, 6>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"inv: k_i16<INV> linear 256", [&](int s) { hipLaunchKernelGGL((k_i16<MODE_INV, false>), dim3(nwg), dim3(256), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"inv: tile 64 thr, 2 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile_mode<MODE_INV, 2>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"inv: tile 64 thr, 3 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile_mode<MODE_INV, 3>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"inv: tile 64 thr, 4 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile_mode<MODE_INV, 4>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"inv: tile 64 thr, 6 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile_mode<MODE_INV, 6>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"stream copy (roofline)", [&](int s) { launch_stream_copy(S[s], D[s], b16, 256, 0); }, {}});
+      std::vector<uint8_t> ref(b16), got(b16);
+      vs[1].f(0); hipMemcpy(ref.data(), D[0], b16, hipMemcpyDeviceToHost);
+      for (size_t i = 0; i < n_rt; i++)
+      {
+        hipMemset(D[0], 0x55, b16);
+        vs[i].f(0);
+        hipMemcpy(got.data(), D[0], b16, hipMemcpyDeviceToHost);
+        printf("%-30s %s\n", vs[i].name, memcmp(ref.data(), got.data(), b16) ? "!! MISMATCH" : "bit-exact");
+      }
+      for (auto &v : vs) for (int i = 0; i < 300; i++) v.f(i % NS);
+      hipDeviceSynchronize();
+      for (int round = 0; round < 15; round++)
+        for (auto &v : vs)
+        {
+          for (int i = 0; i < 40; i++) v.f(i % NS);
+          hipEventRecord(e0, 0);
+          for (int i = 0; i < 40; i++) v.f(i % NS);
+          hipEventRecord(e1, 0);
+          hipEventSynchronize(e1);
+          float ms; hipEventElapsedTime(&ms, e0, e1);
+          v.t.push_back(ms / 40);
+        }
+      for (auto &v : vs)
+      {
+        std::sort(v.t.begin(), v.t.end());
+        printf("%-34s median %7.2f us  min %7.2f us  max %7.2f us\n", v.name, v.t[v.t.size() / 2] * 1e3, v.t[0] * 1e3, v.t.back() * 1e3);
+      }
+      return 0;
+    }
+    Stamp *d;
+    hipMalloc(&d, sizeof(Stamp) * nwaves);
+    hipMemset(d, 0, sizeof(Stamp) * nwaves);
+    for (int i = 0; i < 1200; i++) launch_i16(iargs(i % NS), MODE_ROUNDTRIP, false, 0);
+    for (int rep = 0; rep < 3; rep++)
+    {
+      for (int i = 0; i < 50; i++) launch_i16(iargs(i % NS), MODE_ROUNDTRIP, false, 0);
+      hipLaunchKernelGGL(v_timeline_i16, dim3(nwg), dim3(256), 0, 0, iargs(rep % NS), d);
+    }
+    hipDeviceSynchronize();
+    std::vector<Stamp> hs(nwaves);
+    hipMemcpy(hs.data(), d, sizeof(Stamp) * nwaves, hipMemcpyDeviceToHost);
+    const char *path = argc > 2 ? argv[2] : "gpurun_out/i16_timeline.bin";
+    FILE *f = fopen(path, "wb");
+    if (!f) { perror(path); return 1; }
+    fwrite(hs.data(), sizeof(Stamp), nwaves, f);
+    fclose(f);
+    printf("i16 round-trip timeline: %u waves -> %s\n", nwaves, path);
     return 0;
   }
 
