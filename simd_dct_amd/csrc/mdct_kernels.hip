@@ -149,6 +149,20 @@ struct PkConsts
 static_assert(kMaxPlanes == 4, "k_i16_planes switches over four plane slots");
 static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernels.h) is the kernel-argument image of PkConsts");
 
+// Phase priorities (template flag PRIO of the block functions): a wave raises its issue priority as it advances through its
+// phases, so that of the waves sharing a SIMD the one closest to its stores goes first (shortest remaining work first)
+// instead of all of them finishing late together.  Measured on the fused int16 round trip at 3 waves/SIMD: 46.1 -> 44.7 us
+// (profiles/r03_exp_i16_tile_and_priorities.log).
+#define MDCT_PHASE_PRIO(n)                   \
+  do                                         \
+  {                                          \
+    if constexpr (PRIO)                      \
+    {                                        \
+      __builtin_amdgcn_sched_barrier(0);     \
+      __builtin_amdgcn_s_setprio(n);         \
+      __builtin_amdgcn_sched_barrier(0);     \
+    }                                        \
+  } while (0)
 // one block row (or column) held in 4 pairs -> (o0,o4) (o2,o6) (o1,o3) (o5,o7), each already times Cn.
 // K selects the reference 1-D kernel being reproduced; they differ in the odd part only:
 //   K_AVX  :2176-2183  o1 = t1 + (Cd x25m - Cf x43m)       o3 = t3 - (Ca x25m + Cd x43m)   (k=3 quirk)
@@ -577,9 +591,10 @@ __device__ __forceinline__ void load_block_rows(const uint8_t *src, size_t pitch
 // the stored byte is its complement.  The complement is applied to whole dwords after the LDS
 // reorder (4 v_not per lane instead of 64 integer adds).
 constexpr int kPairA[4] = {0, 2, 1, 5}, kPairB[4] = {4, 6, 3, 7};
-template <bool SAFE>
+template <bool SAFE, bool PRIO = false>
 __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uint2 (&rows)[8], const QuantTable &qt, uint32_t (&out)[64])
 {
+  MDCT_PHASE_PRIO(1);
   f32x2 col[4][8]; // col[j][r] = (B[r][kPairA[j]], B[r][kPairB[j]]) after the row pass
 #pragma unroll
   for (int r = 0; r < 8; r++)
@@ -590,6 +605,7 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
     const f32x2 a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
     dct8_h<K_AVX>(K, a01, a23, a45, a67, col[0][r], col[1][r], col[2][r], col[3][r]);
   }
+  MDCT_PHASE_PRIO(2);
 #pragma unroll
   for (int j = 0; j < 4; j++)
   {
@@ -1375,16 +1391,6 @@ __device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16
   i16_roundtrip_rows<HAS_LUT>(C, RowsLinear{src, dst, pitch_in, pitch_out}, tb);
 }
 
-#define MDCT_PHASE_PRIO(n)                   \
-  do                                         \
-  {                                          \
-    if constexpr (PRIO)                      \
-    {                                        \
-      __builtin_amdgcn_sched_barrier(0);     \
-      __builtin_amdgcn_s_setprio(n);         \
-      __builtin_amdgcn_sched_barrier(0);     \
-    }                                        \
-  } while (0)
 template <bool HAS_LUT, class Rows, bool PRIO>
 __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, const OwnTables &tb)
 {
@@ -1487,7 +1493,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(i16_tile_wav
   const size_t by = a.by0 + blockIdx.y;
   const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
   if constexpr (MODE == MODE_ROUNDTRIP)
-    i16_roundtrip_rows<HAS_LUT>(a.consts, rows, a.tb);
+    i16_roundtrip_rows<HAS_LUT, RowsTiled, true>(a.consts, rows, a.tb); // with phase priorities
   else
     i16_block<MODE, HAS_LUT>(a.consts, rows, a.tb);
 }
@@ -1788,6 +1794,74 @@ __global__ __launch_bounds__(kWG) MDCT_F32_ATTR void k_f32(F32Args a)
   }
 }
 
+// The WIDE form as one-wave tiles on a 2-D grid (x = 64-block tile of the row, y = block row; plane width % 512 == 0):
+// wave-uniform row bases in SGPRs, the lane adds (lane * 16) bytes for each of the row's two contiguous 1 KiB halves.
+#ifndef MDCT_F32_TILE_WAVES
+#define MDCT_F32_TILE_WAVES 2
+#endif
+template <int MODE>
+__device__ __forceinline__ void f32_tile_body(const F32Args &a);
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MDCT_F32_TILE_WAVES, MDCT_F32_TILE_WAVES))) void k_f32_tile(F32Args a)
+{
+  f32_tile_body<MODE>(a);
+}
+template <int MODE>
+__device__ __forceinline__ void f32_tile_body(const F32Args &a)
+{
+  typedef float f32x4_g __attribute__((ext_vector_type(4)));
+  const DctConsts &C = a.consts;
+  const uint32_t lane = threadIdx.x;
+  const bool odd = lane & 1;
+  const size_t by = a.by0 + blockIdx.y;
+  const float *src = a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512; // wave-uniform: 64 blocks x 8 floats
+  float *dst = a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512;
+  float b[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    const gptr_t rp = sgpr_ptr(src + (size_t)r * a.pitch_in);
+    const f32x4_g A = __builtin_nontemporal_load(reinterpret_cast<const f32x4_g __attribute__((address_space(1))) *>(rp + lane * 16));
+    const f32x4_g B = __builtin_nontemporal_load(reinterpret_cast<const f32x4_g __attribute__((address_space(1))) *>(rp + lane * 16 + 1024));
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      const float got = swap_pair(odd ? A[j] : B[j]); // even lanes receive A (right half), odd lanes B (left half)
+      b[r][j] = odd ? got : A[j];
+      b[r][4 + j] = odd ? B[j] : got;
+    }
+  }
+  if constexpr (MODE == MODE_FWD)
+  {
+    raw_fwd(C, b);
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+      b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.scale[i];
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i < 64; i++)
+      b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.scale[i];
+    raw_inv(C, b);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    f32x4_g A, B;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      const float got = swap_pair(odd ? b[r][j] : b[r][4 + j]); // even sends its right half, odd its left
+      A[j] = odd ? got : b[r][j];
+      B[j] = odd ? b[r][4 + j] : got;
+    }
+    const gptr_t rp = sgpr_ptr(dst + (size_t)r * a.pitch_out);
+    __builtin_nontemporal_store(A, reinterpret_cast<f32x4_g __attribute__((address_space(1))) *>(rp + lane * 16));
+    __builtin_nontemporal_store(B, reinterpret_cast<f32x4_g __attribute__((address_space(1))) *>(rp + lane * 16 + 1024));
+  }
+}
+
 // read-N / write-N stream copy, 8 x 16 B per lane, non-temporal: the box's measured HBM roofline
 // (tools/membench: this shape is the fastest of those tried, ~6.2 TB/s).
 constexpr int kCopyUnroll = 8;
@@ -1952,6 +2026,16 @@ hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s)
   if (a.nblocks == 0)
     return hipSuccess;
   const bool wide = a.bpr % 64 == 0; // every wave = 64 blocks of one block row, 2 KiB contiguous per pixel row
+  const uint32_t launch_rows = a.nblocks / a.bpr;
+  if (wide && launch_rows <= 65535u)
+  {
+    const dim3 g2(a.bpr / 64, launch_rows);
+    if (mode == MODE_FWD)
+      hipLaunchKernelGGL(k_f32_tile<MODE_FWD>, g2, dim3(64), 0, s, a);
+    else
+      hipLaunchKernelGGL(k_f32_tile<MODE_INV>, g2, dim3(64), 0, s, a);
+    return hipGetLastError();
+  }
   const dim3 g(grid_for(a.nblocks)), b(kWG);
   if (mode == MODE_FWD && wide)
     hipLaunchKernelGGL((k_f32<MODE_FWD, true>), g, b, 0, s, a);

@@ -403,6 +403,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   i16_roundtrip_rows<false>(a.consts, rows, a.tb);
 }
 
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void v_f32_tile(F32Args a)
+{
+  f32_tile_body<MODE>(a);
+}
+
+// k_q32_tile with phase priorities (1 row pass, 2 column pass + quantiser, 3 read back + stores)
+template <int MINW>
+__global__ __launch_bounds__(64, MINW) void v_q32_tile_prio(U8Args a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t wl[64 * kQ32RowStride];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tile = blockIdx.x, row = blockIdx.y;
+  uint32_t q[64];
+  {
+    uint2 rows[8];
+    load_block_rows_g(a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)tile * 512, a.pitch, lane * 8, rows);
+    encode_block_avx_pk<false, true>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
+  }
+#pragma unroll
+  for (int c = 0; c < 64; c++)
+    wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __builtin_amdgcn_s_setprio(3);
+  const gptr_t outw = sgpr_ptr(a.to + ((size_t)(a.by0 + row) * a.bpr + (size_t)tile * 64) * 64);
+  const uint32_t rd = (lane & 31) * (2 * kQ32RowStride) + (lane >> 5) * 8;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const uint2 lo = *reinterpret_cast<const uint2 *>(wl + rd + k * 16);
+    const uint2 hi = *reinterpret_cast<const uint2 *>(wl + rd + k * 16 + kQ32RowStride);
+    store16_g(outw + k * 1024 + lane * 16, ~u32x4_g{lo.x, lo.y, hi.x, hi.y});
+  }
+}
+
 int main(int argc, char **argv)
 {
   const char *mode = argc > 1 ? argv[1] : "ab";
@@ -463,6 +500,69 @@ int main(int argc, char **argv)
     return 0;
   }
 
+  if (!strcmp(mode, "ab_f32"))
+  {
+    const size_t b32 = W * H * 4;
+    float *S[2], *D[2];
+    std::vector<float> hf(W * H);
+    for (size_t i = 0; i < W * H; i++) hf[i] = (float)host[i] - 128.0f;
+    for (int i = 0; i < 2; i++)
+    {
+      if (hipMalloc(&S[i], b32) != hipSuccess || hipMalloc(&D[i], b32) != hipSuccess) { puts("alloc failed"); return 1; }
+      hipMemcpy(S[i], hf.data(), b32, hipMemcpyHostToDevice);
+    }
+    F32Args fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.consts = DctConsts();
+    for (int i = 0; i < 64; i++) fa.scale[i] = 0.125f + 0.001f * i;
+    fa.pitch_in = fa.pitch_out = W; fa.bpr = W / 8; fa.by0 = 0; fa.nblocks = (uint32_t)(W / 8 * H / 8);
+    auto fargs = [&](int s) { F32Args x = fa; x.from = S[s & 1]; x.to = D[s & 1]; return x; };
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    struct V { const char *name; std::function<void(int)> f; std::vector<float> t; };
+    std::vector<V> vs;
+    const dim3 g64((unsigned)(W / 512), (unsigned)(H / 8));
+    vs.push_back({"k_f32<FWD, WIDE> linear 256", [&](int s) { hipLaunchKernelGGL((k_f32<MODE_FWD, true>), dim3(nwg), dim3(256), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"f32 fwd tile, 2 waves", [&](int s) { hipLaunchKernelGGL((v_f32_tile<MODE_FWD, 2>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"f32 fwd tile, 3 waves", [&](int s) { hipLaunchKernelGGL((v_f32_tile<MODE_FWD, 3>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"f32 fwd tile, 4 waves", [&](int s) { hipLaunchKernelGGL((v_f32_tile<MODE_FWD, 4>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"k_f32<INV, WIDE> linear 256", [&](int s) { hipLaunchKernelGGL((k_f32<MODE_INV, true>), dim3(nwg), dim3(256), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"f32 inv tile, 2 waves", [&](int s) { hipLaunchKernelGGL((v_f32_tile<MODE_INV, 2>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"f32 inv tile, 3 waves", [&](int s) { hipLaunchKernelGGL((v_f32_tile<MODE_INV, 3>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"f32 inv tile, 4 waves", [&](int s) { hipLaunchKernelGGL((v_f32_tile<MODE_INV, 4>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"stream copy of the same bytes", [&](int s) { launch_stream_copy(S[s & 1], D[s & 1], b32, 256, 0); }, {}});
+    std::vector<uint8_t> ref(b32), got(b32);
+    for (int base : {0, 4})
+    {
+      vs[base].f(0); hipMemcpy(ref.data(), D[0], b32, hipMemcpyDeviceToHost);
+      for (int i = base + 1; i < base + 4; i++)
+      {
+        hipMemset(D[0], 0x55, b32);
+        vs[i].f(0);
+        hipMemcpy(got.data(), D[0], b32, hipMemcpyDeviceToHost);
+        printf("%-34s %s\n", vs[i].name, memcmp(ref.data(), got.data(), b32) ? "!! MISMATCH" : "bit-exact");
+      }
+    }
+    for (auto &v : vs) for (int i = 0; i < 200; i++) v.f(i);
+    hipDeviceSynchronize();
+    for (int round = 0; round < 9; round++)
+      for (auto &v : vs)
+      {
+        for (int i = 0; i < 30; i++) v.f(i);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 30; i++) v.f(i);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        v.t.push_back(ms / 30);
+      }
+    for (auto &v : vs)
+    {
+      std::sort(v.t.begin(), v.t.end());
+      printf("%-34s median %7.2f us  min %7.2f us\n", v.name, v.t[v.t.size() / 2] * 1e3, v.t[0] * 1e3);
+    }
+    return 0;
+  }
   if (!strcmp(mode, "timeline_i16") || !strcmp(mode, "ab_i16"))
   {
     const size_t b16 = W * H * 2;
@@ -572,6 +672,9 @@ int main(int argc, char **argv)
   vs.push_back({"sa64 6w stagger 8", [&](int s) { hipLaunchKernelGGL((v_sa64<6, 8>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"sa256 6w", [&](int s) { hipLaunchKernelGGL((v_sa256<6>), g256, dim3(256), 0, 0, args(s)); }, {}, true});
   vs.push_back({"sa256 5w", [&](int s) { hipLaunchKernelGGL((v_sa256<5>), g256, dim3(256), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"q32 tile (product kernel)", [&](int s) { hipLaunchKernelGGL(k_q32_tile, g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"q32 tile, phase prio 6w", [&](int s) { hipLaunchKernelGGL((v_q32_tile_prio<6>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"q32 tile, phase prio 5w", [&](int s) { hipLaunchKernelGGL((v_q32_tile_prio<5>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"tile: lds b8 (product)", [&](int s) { hipLaunchKernelGGL((v_ldscost<0>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"tile: no lds, 48 perm", [&](int s) { hipLaunchKernelGGL((v_ldscost<1>), g64, dim3(64), 0, 0, args(s)); }, {}, false});
   vs.push_back({"tile: no lds, no pack", [&](int s) { hipLaunchKernelGGL((v_ldscost<2>), g64, dim3(64), 0, 0, args(s)); }, {}, false});
