@@ -229,3 +229,43 @@ def test_operands_straddling_a_4GiB_address_boundary():
             total = int(woff[-1])
             assert np.array_equal(off.cpu().numpy().astype(np.uint64), woff) and np.array_equal(scan[:total].cpu().numpy(), wo[:total]), (which, hex(into))
     del arena
+
+
+def test_more_than_65535_block_rows_take_the_linear_kernels():
+    """the 2-D tile launches (k_q32_tile, k_fwd_quant_u8<TILED>, k_i16_tile, k_f32_tile) put the block row in blockIdx.y, which
+    ends at 65535: taller planes must fall back to the linear kernels and still be right.  Periodic input as above: every
+    period equals the first on the device, the first equals the oracle."""
+    n_per = 4112  # x 16 block rows = 65792 block rows
+    H = P * n_per
+    # q32 (512 wide: one tile per row) and the 256-thread layouts (2048 wide)
+    for W, beh, layout, profile, scale in ((512, "q32_avx", M.LAYOUT_Q32, M.PROFILE_REF_AVX, 2000.0), (2048, "encq_scalar", M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, 8.0)):
+        assert H // 8 > 65535
+        strip = synth.plane_u8_np(W, P, "photo", seed=5)
+        src = torch.from_numpy(strip).cuda().repeat(n_per, 1).contiguous()
+        out = torch.full((W * H,), CANARY, dtype=torch.uint8, device="cuda")
+        M.fwd_quant_u8(src, out, lut_x(scale), W, H, 0, H // 8, layout=layout, profile=profile)
+        torch.cuda.synchronize()
+        assert all_periods_equal_first(out, n_per), beh
+        if beh == "q32_avx":
+            rc, want = O.q32_native(strip, lut_x(scale), W, P, 0, P // 8)
+        else:
+            rc, want = O.run_behaviour(beh, np.ascontiguousarray(np.tile(strip, (2, 1))), lut_x(scale), W, 2 * P, 0, 2 * P)
+            want = want[: W * P]
+        assert np.array_equal(out[: W * P].cpu().numpy(), want), beh
+        del src, out
+    W = 512
+    s16 = synth.plane_i16_np(W, P, "photo", seed=6)
+    src = torch.from_numpy(s16).cuda().repeat(n_per, 1).contiguous()
+    dst = torch.empty_like(src)
+    for mode, fn in (("fwd", M.fwd_i16), ("roundtrip", M.roundtrip_i16)):
+        dst.fill_(-1)
+        fn(src, dst, W, H)
+        torch.cuda.synchronize()
+        assert all_periods_equal_first(dst, n_per), mode
+        assert np.array_equal(dst[:P].cpu().numpy(), O.i16(mode, s16, W, P)), mode
+    f = src.to(torch.float32)
+    g = torch.empty_like(f)
+    M.fwd_f32(f, g, W, H)
+    torch.cuda.synchronize()
+    assert all_periods_equal_first(g, n_per)
+    assert np.array_equal(g[:P].cpu().numpy(), O.f32("fwd", s16.astype(np.float32), W, P))
