@@ -194,6 +194,15 @@ int mdct_fwd_i16_records(const int16_t *from, size_t pitch, const float *lut, si
  * >= 208 * (sizeX/8) + 8 (the worst case of F.1.2); sizeX/8 <= 65535. */
 int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t *counts, size_t sizeX, size_t sizeY,
                       size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, void *stream);
+/* The whole encoder front to back in ONE kernel: pixels (or an int16 plane) -> the row segments mdct_fwd_u8_records
+ * (mdct_fwd_i16_records) followed by mdct_huffman_rows would produce, byte for byte -- the records exist only in LDS,
+ * so 1 byte in and ~0.2 bytes out per pixel instead of 1 + 3 and 3 + 0.2.  Arguments as for those two calls
+ * (pitch: bytes for pixels, elements for the int16 plane, whose rows must be 16-byte aligned; lut may be NULL;
+ * seg_stride as above; sizeX/8 <= 65535). */
+int mdct_fwd_u8_huffman_rows(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY,
+                             size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, void *stream);
+int mdct_fwd_i16_huffman_rows(const int16_t *from, size_t pitch, const float *lut, size_t sizeX, size_t sizeY,
+                              size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, void *stream);
 /* smallest legal seg_stride for a plane sizeX wide: 208 * (sizeX/8) + 8 (host function) */
 size_t mdct_huffman_seg_stride(size_t sizeX);
 /* The row segments -> one contiguous scan, ready to follow an SOS header: every row byte-stuffed (B.1.1.5: a zero

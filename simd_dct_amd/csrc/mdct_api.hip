@@ -446,6 +446,60 @@ int mdct_fwd_i16_records(const int16_t *from, size_t pitch, const float *lut, si
   return run_u8_records(from, true, pitch, lut, 0, sizeX, sizeY, by0, by1, levels, runs, counts, stream);
 }
 
+extern "C" __attribute__((visibility("hidden"))) void mdct_huff_build(int which, uint32_t *tab, int ntab); // stages.hip
+
+static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride,
+                          uint32_t *seg_bytes, void *stream)
+{
+  const uint8_t *px = static_cast<const uint8_t *>(px_);
+  if (px == nullptr || out == nullptr || seg_bytes == nullptr)
+    return fail(MDCT_INVALID_PARAMETER, "null pointer");
+  if (sizeX == 0 || sizeX % 8 != 0 || sizeY % 8 != 0)
+    return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu is not a multiple of 8x8", sizeX, sizeY);
+  const size_t bpr = sizeX / 8;
+  if (pitch_px < sizeX || by0 > by1 || by1 > sizeY / 8 || bpr > 0xFFFF)
+    return fail(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows, or more than 65535 blocks per row (a restart interval)", by0, by1, sizeY / 8);
+  if (seg_stride < bpr * 208 + 8 || seg_stride % 4 != 0 || ((uintptr_t)out & 3))
+    return fail(MDCT_INVALID_PARAMETER, "seg_stride must be a multiple of 4 and >= 208 * blocks per row + 8 = %zu (worst case of F.1.2); out 4-byte aligned", bpr * 208 + 8);
+  if (i16_in && (((uintptr_t)px | (pitch_px * sizeof(int16_t))) & 15))
+    return fail(MDCT_INVALID_PARAMETER, "rows of the int16 plane must be 16-byte aligned");
+  if (by1 - by0 > 0x7FFFFFFFull)
+    return fail(MDCT_NOT_SUPPORTED, "too many block rows for one call");
+  const mdct_device_info *di;
+  int r = current(&di);
+  if (r)
+    return r;
+  mdct::PxHuffArgs a;
+  memset(&a, 0, sizeof(a));
+  a.consts = mdct::DctConsts();
+  a.px = px;
+  a.out = out;
+  a.seg_bytes = seg_bytes;
+  a.seg_stride = seg_stride;
+  a.pitch_px = pitch_px;
+  a.bpr = (uint32_t)bpr;
+  a.by0 = (uint32_t)by0;
+  if ((r = make_own_tables(lut, a.tb, /*pair_order=*/true)))
+    return r;
+  a.dc_shift = level_shift ? 64.0f * 128.0f : 0.0f;
+  mdct_huff_build(chroma ? 2 : 0, a.dc, 12);
+  mdct_huff_build(chroma ? 3 : 1, a.ac, 256);
+  const hipError_t e = mdct::launch_px_huffman(a, i16_in, (uint32_t)(by1 - by0), (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "pixels -> Huffman rows kernel launch");
+}
+
+int mdct_fwd_u8_huffman_rows(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride,
+                             uint32_t *seg_bytes, void *stream)
+{
+  return run_px_huffman(px, false, pitch, lut, level_shift, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, stream);
+}
+
+int mdct_fwd_i16_huffman_rows(const int16_t *from, size_t pitch, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes,
+                              void *stream)
+{
+  return run_px_huffman(from, true, pitch, lut, 0, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, stream);
+}
+
 int mdct_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
 {
   return run_u8_i16(mdct::MODE_FWD, from, to, const_cast<uint8_t *>(from), to, pitch_in, pitch_out, lut, level_shift, sizeX, sizeY, by0, by1, stream);

@@ -121,6 +121,21 @@ struct U8RecArgs
   float dc_shift;  // 64*128 when level-shifting, else 0
 };
 
+struct PxHuffArgs
+{ // pixels -> quantised coefficients -> baseline Huffman rows in one pass (k_px_huffman_rows); records exist only in LDS
+  const uint8_t *px; // 8-bit pixels, or an int16 plane (k_px_huffman_rows<true, ..>)
+  uint8_t *out;      // row segments, seg_stride apart
+  uint32_t *seg_bytes;
+  size_t seg_stride;
+  size_t pitch_px;   // bytes (int16 plane: elements)
+  OwnTables tb;      // qf in the pair order of the column pass (as U8RecArgs)
+  DctConsts consts;
+  uint32_t bpr, by0;
+  float dc_shift;    // 64*128 when level-shifting, else 0
+  uint32_t dc[12];   // size << 16 | code per DC category
+  uint32_t ac[256];  // size << 16 | code per RRRRSSSS
+};
+
 struct F32Args
 {
   const float *from;
@@ -150,6 +165,7 @@ hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s);
 hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s);
 hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s);
 hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s);
+hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, uint32_t n_rows, hipStream_t s);
 hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s);
 hipError_t launch_stream_copy(const void *from, void *to, size_t bytes, int cus, hipStream_t s);
 

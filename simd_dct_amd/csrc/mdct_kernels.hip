@@ -16,9 +16,11 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
+#include "huffman_rows.h"
 #include "mdct_kernels.h"
 #include "scan_records.h"
 
@@ -1640,6 +1642,133 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
   scan_emit<true>(val, lv, rn, lane, nvalid, valid, (size_t)a.by0 * a.bpr + wave_t0, a.levels, a.runs, a.counts);
 }
 
+// ---------------------------------------------------------------------------------------
+// Pixels (or an int16 plane) -> baseline Huffman rows in ONE kernel: the front half of
+// k_u8_records (forward transform + quantiser on packed fp32), the zig-zag run/level compaction straight into the
+// workgroup's LDS -- one dword per pair (run << 16 | level), 65 dwords per block, a lane writes and later reads only its own
+// row -- and the chunk coder of k_huffman_rows (huffman_rows.h).  The 3 B/px of records that k_u8_records writes and
+// k_huffman_rows reads back (two thirds of them padding) never exist: 1 B/px in, ~0.2 B/px out.  One workgroup of WAVES
+// waves per block row (= restart interval); the next chunk's pixel rows are loaded while the current one is coded.
+// A wave's first block needs the previous wave's last DC as predictor, which is computed in the same pass: LATE_DC.
+// Byte for byte the segments of mdct_fwd_u8_records + mdct_huffman_rows.
+// ---------------------------------------------------------------------------------------
+constexpr int kFusedRec = 65; // dwords per block: 64 pairs + the slot that takes the zero coefficients' writes
+template <bool I16_IN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
+{
+  __shared__ uint32_t ac[256], dc[12];
+  __shared__ uint32_t rec_all[WAVES][64 * kFusedRec];
+  __shared__ uint32_t ring[kHuffRing];
+  __shared__ uint32_t tot[2][WAVES];
+  __shared__ int dcx[2][2][WAVES];
+  constexpr uint32_t kChunk = 64 * WAVES;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t row = a.by0 + blockIdx.x;
+  for (uint32_t i = tid; i < 256; i += kChunk)
+    ac[i] = a.ac[i];
+  if (tid < 12)
+    dc[tid] = a.dc[tid];
+  for (uint32_t w = tid; w < kHuffRing; w += kChunk)
+    ring[w] = 0;
+  HuffRowCoder<WAVES, 64, false, true> coder;
+  coder.ac = ac;
+  coder.dc = dc;
+  coder.ring = ring;
+  coder.tot = tot;
+  coder.dcx = dcx;
+  coder.out_w = reinterpret_cast<uint32_t *>(a.out + (size_t)row * a.seg_stride);
+  coder.zrl = a.ac[0xF0];
+  coder.eob = a.ac[0x00];
+  coder.bpr = a.bpr;
+  const DctConsts &C = a.consts;
+  const AanPk &K = reinterpret_cast<const AanPk &>(C);
+  uint32_t *rec = rec_all[wave] + lane * kFusedRec;
+  const uint32_t last_blk = a.bpr - 1;
+
+  typedef typename std::conditional<I16_IN, uint4, uint2>::type row_t;
+  row_t rows[8];
+  auto fetch = [&](uint32_t bx) { // the 8 rows of block min(bx, last) of this block row (lanes past the row's end redo the last block)
+    const uint32_t blk = min(bx, last_blk);
+    if constexpr (I16_IN)
+    {
+      const int16_t *src = reinterpret_cast<const int16_t *>(a.px) + (size_t)row * 8 * a.pitch_px + (size_t)blk * 8;
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+        rows[r] = ld_stream16(src + (size_t)r * a.pitch_px);
+    }
+    else
+    {
+      const uint8_t *src = a.px + (size_t)row * 8 * a.pitch_px + (size_t)blk * 8;
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+        rows[r] = load8(src + (size_t)r * a.pitch_px);
+    }
+  };
+  fetch(wave * 64 + lane);
+  __syncthreads(); // tables and the cleared ring
+  for (uint32_t c0 = 0; c0 < a.bpr; c0 += kChunk)
+  {
+    const uint32_t bx = c0 + wave * 64 + lane;
+    const bool live = bx < a.bpr;
+    // ---- forward transform and quantiser (as k_u8_records)
+    f32x2 P[4][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      f32x2 a01, a23, a45, a67;
+      if constexpr (I16_IN)
+      {
+        a01 = f32x2{(float)(int16_t)(rows[r].x & 0xFFFF), (float)(int16_t)(rows[r].x >> 16)};
+        a23 = f32x2{(float)(int16_t)(rows[r].y & 0xFFFF), (float)(int16_t)(rows[r].y >> 16)};
+        a45 = f32x2{(float)(int16_t)(rows[r].z & 0xFFFF), (float)(int16_t)(rows[r].z >> 16)};
+        a67 = f32x2{(float)(int16_t)(rows[r].w & 0xFFFF), (float)(int16_t)(rows[r].w >> 16)};
+      }
+      else
+      {
+        a01 = f32x2{ubyte_to_float<0>(rows[r].x), ubyte_to_float<1>(rows[r].x)};
+        a23 = f32x2{ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
+        a45 = f32x2{ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)};
+        a67 = f32x2{ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
+      }
+      aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
+    }
+    int val[64];
+    constexpr int kA[4] = {0, 2, 5, 1}, kB[4] = {4, 6, 3, 7};
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      aan_fwd_v(K, P[j]);
+      if (j == 0)
+        P[0][0].x = P[0][0].x - a.dc_shift; // the level shift is exactly "raw DC minus 64 * 128"
+#pragma unroll
+      for (int v = 0; v < 8; v++)
+      {
+        f32x2 m;
+        MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[v * 4 + j], MDCT_K_LH);
+        val[v * 8 + kA[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.x) & 0xFFFFu);
+        val[v * 8 + kB[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.y) & 0xFFFFu);
+      }
+    }
+    // ---- zig-zag order, run/level pairs compacted to the front of the lane's LDS row (zeros write into slot 64)
+    uint32_t pos = 0, run = 0;
+#pragma unroll
+    for (int k = 0; k < 64; k++)
+    {
+      const int c = val[kZigZag[k]];
+      const bool nz = c != 0;
+      rec[nz ? pos : 64u] = (run << 16) | ((uint32_t)c & 0xFFFFu);
+      pos += nz ? 1u : 0u;
+      run = nz ? 0u : run + 1u;
+    }
+    if (c0 + kChunk < a.bpr)
+      fetch(bx + kChunk); // in flight while this chunk is coded
+    coder.chunk(c0, rec, live ? (int)pos : 0, live, 0, nullptr, nullptr);
+  }
+  __syncthreads();
+  if (tid == 0)
+    a.seg_bytes[row] = coder.finish();
+}
+
 // Several planes (each with its own table) in one launch: linear block index over the
 // concatenation of the planes; prefix[] is the exclusive scan of per-plane block counts.
 // LUTMODE: 0 no plane has a table, 1 every plane has one, 2 mixed (branch per wave)
@@ -2018,6 +2147,30 @@ hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s)
     hipLaunchKernelGGL(k_u8_records<true>, dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a);
   else
     hipLaunchKernelGGL(k_u8_records<false>, dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+// waves per workgroup (= per block row): 4 by default; MDCT_FUSED_HUFF_WAVES=2 in the environment selects the 2-wave build
+// (chunks of 128 blocks, half the LDS per workgroup) for A/B runs
+hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, uint32_t n_rows, hipStream_t s)
+{
+  if (n_rows == 0)
+    return hipSuccess;
+  static const int waves = [] {
+    const char *e = getenv("MDCT_FUSED_HUFF_WAVES");
+    return e && atoi(e) == 2 ? 2 : 4;
+  }();
+  if (waves == 2)
+  {
+    if (i16_in)
+      hipLaunchKernelGGL((k_px_huffman_rows<true, 2>), dim3(n_rows), dim3(128), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_px_huffman_rows<false, 2>), dim3(n_rows), dim3(128), 0, s, a);
+  }
+  else if (i16_in)
+    hipLaunchKernelGGL((k_px_huffman_rows<true, 4>), dim3(n_rows), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_px_huffman_rows<false, 4>), dim3(n_rows), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

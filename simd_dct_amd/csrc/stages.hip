@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "huffman_rows.h"
 #include "mdct.h"
 #include "scan_records.h"
 
@@ -201,51 +202,11 @@ __global__ __launch_bounds__(kWG) void k_split420(SplitArgs a)
 // The ring holds kHuffRing words (4 bit/px over a chunk); a chunk with more bits than that is emitted
 // in several windows (walk 4 repeated, each time keeping only the words of one window).
 // ---------------------------------------------------------------------------------------
-struct HuffArgs
-{
-  const int16_t *levels;
-  const uint8_t *runs, *counts;
-  uint8_t *out;
-  uint32_t *seg_bytes;
-  size_t seg_stride;
-  uint32_t bpr, by0;
-  uint32_t dc[12];  // size << 16 | code per DC category
-  uint32_t ac[256]; // size << 16 | code per RRRRSSSS
-};
-
 constexpr int kHuffWaves = 4;
 constexpr int kHuffChunk = 64 * kHuffWaves; // blocks per chunk = lanes of the workgroup
-constexpr uint32_t kHuffRing = 2048;        // words of bit stream held in LDS (power of two)
 constexpr int kHuffStage = 28;              // pairs per block parked in LDS, one dword each (a multiple of 4)
 constexpr int kRecSkew = kHuffStage + 1;    // dwords per block in LDS (odd: entry i of 64 blocks = 64 banks)
 constexpr int kHuffPieces = kHuffStage / 4; // a block's parked head in pieces of 4 pairs (8 B of levels + 4 B of runs)
-
-// A parked pair is  run << 16 | (uint16_t)level  (top 10 bits zero).  The counting walk replaces it by
-// its token  length << 27 | Huffman code and amplitude bits  (length >= 2: top 5 bits non-zero); pairs
-// that need ZRL codes first (rare) stay as they are and are coded again by the emitting walk.
-struct HuffTok
-{
-  uint32_t bits, len;
-};
-
-__device__ __forceinline__ HuffTok huff_dc_token(int diff, const uint32_t *dc)
-{
-  diff = diff > 2047 ? 2047 : (diff < -2047 ? -2047 : diff);                        // 8-bit baseline: categories 0..11 (F.1.2.1.1)
-  const int s = diff ? 32 - __builtin_clz((uint32_t)(diff < 0 ? -diff : diff)) : 0; // SSSS: bits of |DIFF|
-  const uint32_t e = dc[s];
-  return {((e & 0xFFFFu) << s) | ((uint32_t)(diff < 0 ? diff - 1 : diff) & ((1u << s) - 1u)), (e >> 16) + (uint32_t)s};
-}
-
-__device__ __forceinline__ HuffTok huff_ac_token(int r, int l, const uint32_t *ac)
-{                                                 // r: 0..15 zeros before the coefficient
-  l = l > 1023 ? 1023 : (l < -1023 ? -1023 : l); // categories 1..10 (F.1.2.2.1)
-  const int amp = l + (l >> 31);                 // F.1.2.2.1: a negative value is coded as value - 1, low SSSS bits
-  int lead; // leading bits equal to the sign bit
-  asm("v_ffbh_i32 %0, %1" : "=v"(lead) : "v"(amp));
-  const int s = 32 - lead; // SSSS = bits of |l| = significant bits of amp (l != 0)
-  const uint32_t e = ac[(r << 4) | s];
-  return {((e & 0xFFFFu) << s) | ((uint32_t)amp & ((1u << s) - 1u)), (e >> 16) + (uint32_t)s}; // <= 16 + 10 bits
-}
 
 __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
 {
@@ -260,12 +221,21 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
     dc[tid] = a.dc[tid];
   for (uint32_t w = tid; w < kHuffRing; w += kHuffChunk)
     ring[w] = 0;
-  uint32_t *out_w = reinterpret_cast<uint32_t *>(a.out + (size_t)row * a.seg_stride);
   const size_t row_blk0 = (size_t)row * a.bpr;
   const uint8_t *g_lv = reinterpret_cast<const uint8_t *>(a.levels) + row_blk0 * 128;
   const uint8_t *g_rn = a.runs + row_blk0 * 64;
   const uint8_t *g_ct = a.counts + row_blk0;
   uint32_t *rec_lds = rec_all[wave];
+  HuffRowCoder<kHuffWaves, kHuffStage, true, false> coder;
+  coder.ac = ac;
+  coder.dc = dc;
+  coder.ring = ring;
+  coder.tot = tot;
+  coder.dcx = nullptr;
+  coder.out_w = reinterpret_cast<uint32_t *>(a.out + (size_t)row * a.seg_stride);
+  coder.zrl = a.ac[0xF0]; // size << 16 | code (kernel arguments: scalar registers)
+  coder.eob = a.ac[0x00];
+  coder.bpr = a.bpr;
 
   // the head of the wave's 64 records: kHuffPieces pieces per block, kHuffPieces per lane
   u32x2 plv[kHuffPieces];
@@ -306,13 +276,10 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  const uint32_t zrl = a.ac[0xF0], eob = a.ac[0x00]; // size << 16 | code (kernel arguments: scalar registers)
 
-  uint32_t base_bits = 0; // bits of the row produced by earlier chunks
-  uint32_t par = 0;
   fetch(wave * 64);
   __syncthreads(); // tables and the cleared ring
-  for (uint32_t c0 = 0; c0 < a.bpr; c0 += kHuffChunk, par ^= 1)
+  for (uint32_t c0 = 0; c0 < a.bpr; c0 += kHuffChunk)
   {
     const uint32_t c0w = c0 + wave * 64, bx = c0w + lane;
     const bool live = bx < a.bpr;
@@ -321,160 +288,11 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
     if (c0 + kHuffChunk < a.bpr)
       fetch(c0w + kHuffChunk); // in flight while this chunk is coded
     wave_sync();
-    uint32_t *rec = rec_lds + lane * kRecSkew;
-    const int16_t *lv_g = reinterpret_cast<const int16_t *>(g_lv + (live ? bx : 0u) * 128u);
-    const uint8_t *rn_g = g_rn + (live ? bx : 0u) * 64u;
-    const int nl = n < kHuffStage ? n : kHuffStage; // pairs of this block that sit in LDS
-    // 1. DC of this block and of its predecessor
-    const uint32_t e0 = rec[0];
-    const bool has_dc = n > 0 && (e0 >> 16) == 0; // the first pair sits at scan position 0: it is the DC coefficient
-    const int my_dc = has_dc ? (int)(int16_t)e0 : 0;
-    const int up = __shfl_up(my_dc, 1, 64);
-    const HuffTok dct = huff_dc_token(my_dc - (lane == 0 ? prev_dc : up), dc);
-    // 2. bits of this block; the parked pairs become tokens
-    uint32_t bits = 0;
-    bool need_eob = false;
-    const int first_ac = has_dc ? 1 : 0;
-    int ac_end = n; // pairs [first_ac, ac_end) are coded
-    if (live)
-    {
-      bits = dct.len;
-      int pos = has_dc ? 0 : -1; // scan position of the last coded coefficient
-      uint32_t lmin = 0xFFFFu;   // smallest AC level seen, as a 16-bit pattern: 0 only for a zero level
-      auto count = [&](uint32_t e, int run, int l) -> uint32_t { // the pair's token, or e itself if ZRL codes precede it
-        const int r = run + (pos >> 31); // zeros before it among the AC positions (position 0 is the DC's)
-        pos += run + 1;
-        lmin = min(lmin, (uint32_t)l & 0xFFFFu);
-        const HuffTok t = huff_ac_token(r & 15, l, ac);
-        bits += t.len + (uint32_t)(r >> 4) * (zrl >> 16);
-        return r > 15 ? e : t.len << 27 | t.bits;
-      };
-      int i = first_ac;
-      for (; i + 1 < nl; i += 2)
-      { // two pairs per trip: their LDS reads and table lookups overlap
-        const uint32_t ea = rec[i], eb = rec[i + 1];
-        const uint32_t ta = count(ea, (int)(ea >> 16), (int)(int16_t)ea), tb = count(eb, (int)(eb >> 16), (int)(int16_t)eb);
-        rec[i] = ta;
-        rec[i + 1] = tb;
-      }
-      if (i < nl)
-      {
-        const uint32_t e = rec[i];
-        rec[i] = count(e, (int)(e >> 16), (int)(int16_t)e);
-        i++;
-      }
-      for (; i < n; i++)
-        count(0u, (int)rn_g[i], (int)lv_g[i]);
-      if (pos > 63 || lmin == 0)
-      { // not a block (positions past 63, or a zero level): coded as its DC coefficient alone -- keeps the worst case of F.1.2
-        ac_end = first_ac;
-        bits = dct.len;
-        pos = 0;
-      }
-      need_eob = pos < 63;
-      if (need_eob)
-        bits += eob >> 16;
-    }
-    // 3. exclusive scan: inside the wave, then over the 4 waves
-    uint32_t incl = bits;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1)
-    {
-      const uint32_t v = __shfl_up(incl, d, 64);
-      if (lane >= (uint32_t)d)
-        incl += v;
-    }
-    if (lane == 63)
-      tot[par][wave] = incl;
-    __syncthreads(); // also: every wave has flushed (and cleared) the previous chunk's words
-    uint32_t wave_start = 0, chunk_bits = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < kHuffWaves; w++)
-    {
-      const uint32_t t = tot[par][w];
-      wave_start += w < wave ? t : 0;
-      chunk_bits += t;
-    }
-    const uint32_t end_bits = base_bits + chunk_bits;
-    const uint32_t w_first = base_bits >> 5, w_end = end_bits >> 5; // complete words of the row after this chunk: [.., w_end)
-    // 4. + 5. emit and flush, one window of the ring at a time (one window unless the chunk exceeds 4 bit/px)
-    for (uint32_t win = w_first; win <= w_end; win += kHuffRing)
-    {
-      if (win != w_first)
-        __syncthreads(); // the previous window's slots are cleared
-      if (live)
-      {
-        const uint32_t cur = base_bits + wave_start + (incl - bits); // bit position in the row
-        uint32_t widx = cur >> 5;
-        uint32_t acc = 0;         // the bits not yet written: acc < 2^nacc
-        uint32_t nacc = cur & 31; // pretend that many zero bits precede: OR leaves the neighbour's bits alone
-        auto put = [&](uint32_t tok, uint32_t len) { // 1 <= len <= 27, tok < 2^len
-          const uint32_t total = nacc + len;
-          if (total < 32)
-          {
-            acc = (acc << len) | tok;
-            nacc = total;
-          }
-          else
-          { // the word is complete: the pending bits and the head of the token
-            const uint32_t over = total - 32;
-            if (widx - win < kHuffRing)
-              atomicOr(&ring[widx & (kHuffRing - 1)], (acc << ((32 - nacc) & 31)) | (tok >> over));
-            widx++;
-            acc = tok & ((1u << over) - 1u);
-            nacc = over;
-          }
-        };
-        auto put_pair = [&](int r, int l) {
-          for (; r > 15; r -= 16)
-            put(zrl & 0xFFFFu, zrl >> 16);
-          const HuffTok t = huff_ac_token(r, l, ac);
-          put(t.bits, t.len);
-        };
-        put(dct.bits, dct.len);
-        int i = first_ac;
-        const int nl2 = ac_end < nl ? ac_end : nl;
-        uint32_t e_next = rec[i]; // one token ahead (the row's skew dword makes rec[nl] readable)
-        for (; i < nl2; i++)
-        {
-          const uint32_t e = e_next;
-          e_next = rec[i + 1];
-          if (e >> 27)
-            put(e & 0x7FFFFFFu, e >> 27);
-          else
-            put_pair((int)(e >> 16) - (i == 0 ? 1 : 0), (int)(int16_t)e);
-        }
-        for (; i < ac_end; i++)
-          put_pair((int)rn_g[i] - (i == 0 ? 1 : 0), (int)lv_g[i]);
-        if (need_eob)
-          put(eob & 0xFFFFu, eob >> 16);
-        if (nacc && widx - win < kHuffRing)
-          atomicOr(&ring[widx & (kHuffRing - 1)], acc << (32 - nacc));
-      }
-      __syncthreads();
-      const uint32_t stop = min(w_end, win + kHuffRing);
-      for (uint32_t w = win + tid; w < stop; w += kHuffChunk)
-      {
-        out_w[w] = __builtin_bswap32(ring[w & (kHuffRing - 1)]);
-        ring[w & (kHuffRing - 1)] = 0;
-      }
-    }
-    base_bits = end_bits;
+    coder.chunk(c0, rec_lds + lane * kRecSkew, n, live, prev_dc, reinterpret_cast<const int16_t *>(g_lv + (live ? bx : 0u) * 128u), g_rn + (live ? bx : 0u) * 64u);
   }
   __syncthreads();
   if (tid == 0)
-  { // F.1.2.3: pad the last byte with 1-bits; the segment's length in bytes
-    const uint32_t rem = base_bits & 31;
-    if (rem)
-    {
-      const uint32_t pad = (8 - (rem & 7)) & 7;
-      uint32_t w = ring[(base_bits >> 5) & (kHuffRing - 1)];
-      if (pad)
-        w |= ((1u << pad) - 1u) << (32 - rem - pad);
-      out_w[base_bits >> 5] = __builtin_bswap32(w);
-    }
-    a.seg_bytes[row] = (base_bits + 7) / 8;
-  }
+    a.seg_bytes[row] = coder.finish();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -670,6 +488,12 @@ void huff_build(int which, uint32_t *tab, int ntab)
     code <<= 1;
   }
 }
+
+} // namespace
+// for the fused pixels -> Huffman rows entry points (mdct_api.hip)
+extern "C" __attribute__((visibility("hidden"))) void mdct_huff_build(int which, uint32_t *tab, int ntab) { huff_build(which, tab, ntab); }
+namespace
+{
 
 int scan_launch(int src, const void *coef, size_t pitch, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int16_t *levels, uint8_t *runs, uint8_t *counts, void *stream)
 {

@@ -185,6 +185,78 @@ def test_huffman_kernel_equals_the_checker():
 
 
 @pytest.mark.gpu
+def test_fused_pixels_to_huffman_rows_equals_the_staged_path_and_the_checker():
+    """mdct_fwd_u8_huffman_rows / mdct_fwd_i16_huffman_rows (one kernel, records only in LDS): byte for byte the row segments of
+    mdct_fwd_u8_records + mdct_huffman_rows on the GPU AND of the checker's composition -- one lane ... several 256-block
+    chunks with ragged tails, photo at the Annex K tables, noise at quantiser 1 (64 pairs per block, ZRL, several ring
+    windows), flat planes (DC only: the late DC predictor across waves and chunks), chroma tables, no level shift, sub-ranges"""
+    api.init(0)
+    for (W, H) in ((8, 8), (64, 16), (264, 24), (520, 8), (2048, 64), (4104, 16), (8192, 32)):
+        for kind, q, shift in (("photo", K1_LUMA, True), ("noise", np.ones(64, dtype=np.float32), True), ("photo", K2_CHROMA, True), ("flat", K1_LUMA, False), ("photo", None, True)):
+            if kind == "flat":  # a ramp of constant blocks: every block is its DC alone, every DC difference is non-zero
+                img = (np.arange(W // 8, dtype=np.int64)[None, :] * 37 + np.arange(H // 8, dtype=np.int64)[:, None] * 11) % 256
+                img = np.ascontiguousarray(np.kron(img, np.ones((8, 8), dtype=np.int64)).astype(np.uint8))
+            else:
+                img = synth.plane_u8_np(W, H, kind, seed=W + H)
+            chroma = q is K2_CHROMA
+            stride = api.huffman_seg_stride(W)
+            nblk = (W // 8) * (H // 8)
+            d_img = _dev(img)
+            # staged on the GPU
+            lv = torch.zeros((nblk, 64), dtype=torch.int16, device="cuda")
+            rn = torch.zeros((nblk, 64), dtype=torch.uint8, device="cuda")
+            ct = torch.zeros((nblk,), dtype=torch.uint8, device="cuda")
+            api.fwd_u8_records(d_img, W, H, lv, rn, ct, lut=q, level_shift=shift)
+            seg_a = torch.full(((H // 8) * stride,), 0x5A, dtype=torch.uint8, device="cuda")
+            nb_a = torch.zeros((H // 8,), dtype=torch.int32, device="cuda")
+            api.huffman_rows(lv, rn, ct, W, H, seg_a, nb_a, chroma=chroma)
+            # fused
+            seg_b = torch.full(((H // 8) * stride + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+            nb_b = torch.full((H // 8,), -1, dtype=torch.int32, device="cuda")
+            api.fwd_u8_huffman_rows(d_img, W, H, seg_b, nb_b, lut=q, level_shift=shift, chroma=chroma)
+            torch.cuda.synchronize()
+            na, nbb = nb_a.cpu().numpy(), nb_b.cpu().numpy()
+            assert np.array_equal(na, nbb), (W, H, kind)
+            ga, gb = seg_a.cpu().numpy(), seg_b.cpu().numpy()
+            for r in range(H // 8):
+                assert np.array_equal(ga[r * stride:r * stride + na[r]], gb[r * stride:r * stride + na[r]]), (W, H, kind, r)
+            assert (gb[(H // 8) * stride:] == 0x5A).all()
+            # the checker's composition (CPU), on the smaller cases
+            if W * H <= 2048 * 64:
+                lvh, rnh, cth = O.u8_records(img, W, H, lut=q, level_shift=shift)
+                want_seg, want_nb, _ = O.huffman_rows(lvh, rnh, cth, W, H, chroma=chroma)
+                assert np.array_equal(nbb.astype(np.uint32), want_nb), (W, H, kind)
+                for r in range(H // 8):
+                    assert np.array_equal(gb[r * stride:r * stride + want_nb[r]], want_seg[r * stride:r * stride + want_nb[r]]), (W, H, kind, r)
+    # an int16 plane as input (the chroma planes of mdct_split420_u8), a pitched plane, a sub-range that leaves the other rows alone
+    W, H, pitch = 1032, 48, 1040
+    s16 = np.zeros((H, pitch), dtype=np.int16)
+    s16[:, :W] = synth.plane_i16_np(W, H, "photo", seed=9)
+    d16 = _dev(s16)
+    nblk = (W // 8) * (H // 8)
+    stride = api.huffman_seg_stride(W)
+    lv = torch.zeros((nblk, 64), dtype=torch.int16, device="cuda")
+    rn = torch.zeros((nblk, 64), dtype=torch.uint8, device="cuda")
+    ct = torch.zeros((nblk,), dtype=torch.uint8, device="cuda")
+    api.fwd_i16_records(d16, W, H, lv, rn, ct, lut=K2_CHROMA, pitch=pitch)
+    seg_a = torch.full(((H // 8) * stride,), 0x5A, dtype=torch.uint8, device="cuda")
+    nb_a = torch.full((H // 8,), -1, dtype=torch.int32, device="cuda")
+    api.huffman_rows(lv, rn, ct, W, H, seg_a, nb_a, chroma=True, by0=2, by1=5)
+    seg_b = torch.full(((H // 8) * stride,), 0x5A, dtype=torch.uint8, device="cuda")
+    nb_b = torch.full((H // 8,), -1, dtype=torch.int32, device="cuda")
+    api.fwd_i16_huffman_rows(d16, W, H, seg_b, nb_b, lut=K2_CHROMA, chroma=True, by0=2, by1=5, pitch=pitch)
+    torch.cuda.synchronize()
+    assert torch.equal(nb_a, nb_b) and (nb_b[:2] == -1).all() and (nb_b[5:] == -1).all()
+    ga, gb, na = seg_a.cpu().numpy(), seg_b.cpu().numpy(), nb_a.cpu().numpy()
+    for r in range(2, 5):
+        assert np.array_equal(ga[r * stride:r * stride + na[r]], gb[r * stride:r * stride + na[r]]), r
+    assert (gb[:2 * stride] == 0x5A).all() and (gb[5 * stride:] == 0x5A).all()
+    # argument checks
+    assert api.fwd_u8_huffman_rows(d16, W + 4, H, seg_b, nb_b, check=False) == 2
+    assert api.fwd_u8_huffman_rows(d16, W, H, seg_b, nb_b, seg_stride=stride - 4, check=False) == 1
+
+
+@pytest.mark.gpu
 def test_gpu_pipeline_writes_jpegs_libjpeg_opens():
     """pixels -> mdct_fwd_u8_i16 (Annex K tables) -> mdct_zigzag_rle_i16 -> mdct_huffman_rows -> JFIF: decoded by libjpeg, the
     picture equals our own inverse transform within 1 grey level; grey at 4096x2160 and 4:2:0 colour through mdct_split420_u8"""

@@ -79,6 +79,7 @@ for i in range(2):
     M.zigzag_rle_i16(o16[i], W, H, lvk[i], rnk[i], ctk[i])
 torch.cuda.synchronize()
 print(f"records: {float(ct[0].float().mean()):.1f} pairs per block (quality-60 table), {float(ctk[0].float().mean()):.1f} (Annex K.1 table)")
+Q60 = (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32)
 hstride = M.huffman_seg_stride(W)
 hseg = [torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda") for _ in range(2)]
 hnb = [torch.empty((H // 8,), dtype=torch.int32, device="cuda") for _ in range(2)]
@@ -97,6 +98,9 @@ cases += [
     ("zig-zag + run/level, encq blocks (1+3)", 4.016, W * H, [lambda i=i: M.zigzag_rle_u8(bl8[i % 2], M.LAYOUT_BLOCK, W, H, lv[i % 2], rn[i % 2], ct[i % 2]) for i in range(2)]),
     ("u8 px -> records, fused (1+3 B/px)", 4.016, W * H, [lambda i=i: M.fwd_u8_records(u8[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2], lut=K1) for i in range(NS)]),
     ("i16 plane -> records, fused (2+3 B/px)", 5.016, W * H, [lambda i=i: M.fwd_i16_records(i16[i], W, H, lv[i % 2], rn[i % 2], ct[i % 2], lut=K1) for i in range(NS)]),
+    ("u8 px -> Huffman rows, ONE kernel, q60 table (1+0.2 B/px)", 1.22, W * H, [lambda i=i: M.fwd_u8_huffman_rows(u8[i], W, H, hseg[i % 2], hnb[i % 2], lut=Q60) for i in range(NS)]),
+    ("u8 px -> Huffman rows, ONE kernel, Annex K.1 table", 1.15, W * H, [lambda i=i: M.fwd_u8_huffman_rows(u8[i], W, H, hseg[i % 2], hnb[i % 2], lut=K1) for i in range(NS)]),
+    ("i16 plane -> Huffman rows, ONE kernel, Annex K.1 table", 2.15, W * H, [lambda i=i: M.fwd_i16_huffman_rows(i16[i], W, H, hseg[i % 2], hnb[i % 2], lut=K1) for i in range(NS)]),
     ("4:2:0 split (3+3 B/px)", 6, W * H, [lambda i=i: M.split420_u8(ycc[i], W, H, sy[i], scb[i], scr[i]) for i in range(2)]),
 ]
 # config 4 on one GPU: 256 independent 4096x4096 int16 planes, forward only.  Blocks are
