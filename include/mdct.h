@@ -198,11 +198,15 @@ int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t 
  * (mdct_fwd_i16_records) followed by mdct_huffman_rows would produce, byte for byte -- the records exist only in LDS,
  * so 1 byte in and ~0.2 bytes out per pixel instead of 1 + 3 and 3 + 0.2.  Arguments as for those two calls
  * (pitch: bytes for pixels, elements for the int16 plane, whose rows must be 16-byte aligned; lut may be NULL;
- * seg_stride as above; sizeX/8 <= 65535). */
+ * seg_stride as above; sizeX/8 <= 65535).  ff_counts (may be NULL): ff_counts[by] = number of 0xFF bytes in row by's
+ * segment, counted while the segment is written -- hand it to mdct_jpeg_pack_rows_counted and the packing needs no
+ * counting pass of its own. */
 int mdct_fwd_u8_huffman_rows(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY,
-                             size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, void *stream);
+                             size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, uint32_t *ff_counts,
+                             void *stream);
 int mdct_fwd_i16_huffman_rows(const int16_t *from, size_t pitch, const float *lut, size_t sizeX, size_t sizeY,
-                              size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, void *stream);
+                              size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes, uint32_t *ff_counts,
+                              void *stream);
 /* smallest legal seg_stride for a plane sizeX wide: 208 * (sizeX/8) + 8 (host function) */
 size_t mdct_huffman_seg_stride(size_t sizeX);
 /* The row segments -> one contiguous scan, ready to follow an SOS header: every row byte-stuffed (B.1.1.5: a zero
@@ -213,6 +217,9 @@ size_t mdct_huffman_seg_stride(size_t sizeX);
  * (n_rows * seg_stride * 2 always suffices; in practice the total is ~0.2 bytes per pixel.) */
 int mdct_jpeg_pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, size_t seg_stride, size_t n_rows, int first_rst,
                         uint8_t *out, size_t out_capacity, uint64_t *row_offsets, void *stream);
+/* the same when the producer of the segments has counted their 0xFF bytes (ff_counts[r], mdct_fwd_*_huffman_rows): two launches instead of three */
+int mdct_jpeg_pack_rows_counted(const uint8_t *segments, const uint32_t *seg_bytes, const uint32_t *ff_counts, size_t seg_stride, size_t n_rows,
+                                int first_rst, uint8_t *out, size_t out_capacity, uint64_t *row_offsets, void *stream);
 /* BITS (16 counts) and HUFFVAL of the table as a DHT marker segment carries them (host function).
  * which: 0 DC luminance (K.3), 1 AC luminance (K.5), 2 DC chrominance (K.4), 3 AC chrominance (K.6). */
 int mdct_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals);

@@ -68,8 +68,9 @@ SIGNATURES = {
     "mdct_zigzag_rle_q32": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdct_zigzag_rle_u8": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdct_huffman_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
-    "mdct_fwd_u8_huffman_rows": (c_int, [c_void_p, c_size_t, f32p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
-    "mdct_fwd_i16_huffman_rows": (c_int, [c_void_p, c_size_t, f32p, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mdct_fwd_u8_huffman_rows": (c_int, [c_void_p, c_size_t, f32p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mdct_fwd_i16_huffman_rows": (c_int, [c_void_p, c_size_t, f32p, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mdct_jpeg_pack_rows_counted": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mdct_jpeg_pack_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mdct_huffman_seg_stride": (c_size_t, [c_size_t]),
     "mdct_huffman_spec": (c_int, [c_int, c_void_p, c_void_p, ctypes.POINTER(c_int)]),

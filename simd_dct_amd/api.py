@@ -282,30 +282,34 @@ def huffman_rows(levels, runs, counts, sizeX, sizeY, out, seg_bytes, seg_stride=
     return rc
 
 
-def fwd_u8_huffman_rows(src, sizeX, sizeY, out, seg_bytes, lut=None, level_shift=True, seg_stride=None, chroma=False, by0=0, by1=None, pitch=None, stream=None, check=True):
+def fwd_u8_huffman_rows(src, sizeX, sizeY, out, seg_bytes, lut=None, level_shift=True, seg_stride=None, chroma=False, by0=0, by1=None, pitch=None, ff_counts=None, stream=None, check=True):
     """8-bit pixels -> Huffman row segments in one kernel (mdct_fwd_u8_huffman_rows): the bytes of fwd_u8_records + huffman_rows"""
     keep, lp = _lut_ptr(lut)
     rc = _lib.load().mdct_fwd_u8_huffman_rows(_ptr(src), sizeX if pitch is None else pitch, lp, int(bool(level_shift)), sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, int(bool(chroma)),
-                                              _ptr(out), huffman_seg_stride(sizeX) if seg_stride is None else seg_stride, _ptr(seg_bytes), _stream(stream))
+                                              _ptr(out), huffman_seg_stride(sizeX) if seg_stride is None else seg_stride, _ptr(seg_bytes), _ptr(ff_counts), _stream(stream))
     if check:
         _check(rc)
     return rc
 
 
-def fwd_i16_huffman_rows(src, sizeX, sizeY, out, seg_bytes, lut=None, seg_stride=None, chroma=False, by0=0, by1=None, pitch=None, stream=None, check=True):
+def fwd_i16_huffman_rows(src, sizeX, sizeY, out, seg_bytes, lut=None, seg_stride=None, chroma=False, by0=0, by1=None, pitch=None, ff_counts=None, stream=None, check=True):
     """int16 plane -> Huffman row segments in one kernel (mdct_fwd_i16_huffman_rows): the bytes of fwd_i16_records + huffman_rows"""
     keep, lp = _lut_ptr(lut)
     rc = _lib.load().mdct_fwd_i16_huffman_rows(_ptr(src), sizeX if pitch is None else pitch, lp, sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, int(bool(chroma)),
-                                               _ptr(out), huffman_seg_stride(sizeX) if seg_stride is None else seg_stride, _ptr(seg_bytes), _stream(stream))
+                                               _ptr(out), huffman_seg_stride(sizeX) if seg_stride is None else seg_stride, _ptr(seg_bytes), _ptr(ff_counts), _stream(stream))
     if check:
         _check(rc)
     return rc
 
 
-def jpeg_pack_rows(segments, seg_bytes, seg_stride, n_rows, out, row_offsets, first_rst=0, out_capacity=None, stream=None, check=True):
-    """row segments of huffman_rows -> one stuffed scan with RSTm between the rows (mdct_jpeg_pack_rows); row_offsets: n_rows + 1 int64"""
+def jpeg_pack_rows(segments, seg_bytes, seg_stride, n_rows, out, row_offsets, first_rst=0, out_capacity=None, ff_counts=None, stream=None, check=True):
+    """row segments of huffman_rows -> one stuffed scan with RSTm between the rows (mdct_jpeg_pack_rows); row_offsets: n_rows + 1 int64.
+    ff_counts (from fwd_*_huffman_rows): mdct_jpeg_pack_rows_counted, no counting pass"""
     cap = out.numel() * out.element_size() if out_capacity is None and hasattr(out, "numel") else (out.nbytes if out_capacity is None else out_capacity)
-    rc = _lib.load().mdct_jpeg_pack_rows(_ptr(segments), _ptr(seg_bytes), seg_stride, n_rows, first_rst, _ptr(out), cap, _ptr(row_offsets), _stream(stream))
+    if ff_counts is not None:
+        rc = _lib.load().mdct_jpeg_pack_rows_counted(_ptr(segments), _ptr(seg_bytes), _ptr(ff_counts), seg_stride, n_rows, first_rst, _ptr(out), cap, _ptr(row_offsets), _stream(stream))
+    else:
+        rc = _lib.load().mdct_jpeg_pack_rows(_ptr(segments), _ptr(seg_bytes), seg_stride, n_rows, first_rst, _ptr(out), cap, _ptr(row_offsets), _stream(stream))
     if check:
         _check(rc)
     return rc

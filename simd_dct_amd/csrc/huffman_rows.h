@@ -22,6 +22,13 @@ struct HuffArgs
 
 constexpr uint32_t kHuffRing = 2048; // words of bit stream held in LDS (power of two)
 
+// 0x80 in every byte of w that equals 0xFF (exact: no carries between bytes)
+__device__ __forceinline__ uint32_t ff_bytes(uint32_t w)
+{
+  const uint32_t t = ~w; // a zero byte of t is an 0xFF byte of w
+  return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
+}
+
 // A parked pair is  run << 16 | (uint16_t)level  (top 10 bits zero).  The counting walk replaces it by
 // its token  length << 27 | Huffman code and amplitude bits  (length >= 2: top 5 bits non-zero); pairs
 // that need ZRL codes first (rare) stay as they are and are coded again by the emitting walk.
@@ -250,6 +257,183 @@ struct HuffRowCoder
       if (pad)
         w |= ((1u << pad) - 1u) << (32 - rem - pad);
       out_w[base_bits >> 5] = __builtin_bswap32(w);
+    }
+    return (base_bits + 7) / 8;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// The same coder on COMPACT records (the fused pixels -> Huffman rows kernel): the DC value travels in a register and
+// the AC coefficients are 16-bit entries  run << 12 | (level & 0xFFF)  -- run 0..15, level within +-1023 (the range of
+// baseline AC categories 1..10, F.1.2.2.1; the quantiser saturates there, as huff_ac_token does) -- with 0xF000 for
+// "16 zeros" (ZRL, RRRRSSSS = 0xF0: an entry like any other).  A block's worst case is 63 entries = 126 bytes instead of
+// 64 dwords, which is what lets four workgroups share a CU's LDS.  Entries cannot hold their 26-bit tokens, so the
+// counting walk only sums lengths and the emitting walk looks the codes up again.
+// ---------------------------------------------------------------------------------------
+constexpr int kRec16Row = 66; // halfwords per block: 63 entries + the slot that takes the writes of zero coefficients, padded to an odd dword count
+
+__device__ __forceinline__ HuffTok huff_ac_token12(uint32_t e, const uint32_t *ac)
+{
+  int l;
+  asm("v_bfe_i32 %0, %1, 0, 12" : "=v"(l) : "v"(e));
+  const int amp = l + (l >> 31); // F.1.2.2.1: a negative value is coded as value - 1, low SSSS bits
+  int lead;
+  asm("v_ffbh_i32 %0, %1" : "=v"(lead) : "v"(amp));
+  const int s = l ? 32 - lead : 0; // SSSS; 0 for the ZRL entry
+  const uint32_t c = ac[((e >> 12) << 4) | (uint32_t)s];
+  return {((c & 0xFFFFu) << s) | ((uint32_t)amp & ((1u << s) - 1u)), (c >> 16) + (uint32_t)s};
+}
+
+template <int WAVES, uint32_t RING>
+struct HuffRowCoder16
+{
+  const uint32_t *ac, *dc; // LDS copies of the tables
+  uint32_t *ring;          // [RING], zeroed
+  uint32_t (*tot)[WAVES];  // [2][WAVES]
+  int (*dcx)[2][WAVES];    // [2][first / last][WAVES]
+  uint32_t *out_w;         // the row's segment
+  uint32_t eob;            // size << 16 | code
+  uint32_t bpr;
+  uint32_t base_bits = 0;
+  uint32_t par = 0;
+  int carry_dc = 0; // DC of the previous chunk's last block
+  uint32_t ff = 0;  // 0xFF bytes among the words this thread has flushed (the bytes mdct_jpeg_pack_rows will stuff)
+
+  // blocks c0 + 64 * wave + lane of the row; the lane's block: DC value, n AC entries in rec[], EOB needed unless position 63 is coded
+  __device__ __forceinline__ void chunk(uint32_t c0, const uint16_t *rec, int n, bool live, int my_dc, bool need_eob)
+  {
+    constexpr uint32_t kChunk = 64 * WAVES;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *rec2 = reinterpret_cast<const uint32_t *>(rec); // two entries per LDS read
+    if (!live)
+    {
+      my_dc = 0;
+      n = 0;
+    }
+    const int up = __shfl_up(my_dc, 1, 64);
+    HuffTok dct = huff_dc_token(my_dc - up, dc); // lane 0: replaced after the barrier
+    if (lane == 0)
+      dcx[par][0][wave] = my_dc;
+    if (lane == 63)
+      dcx[par][1][wave] = my_dc;
+    // bits of this block
+    uint32_t bits = 0;
+    if (live)
+    {
+      bits = lane ? dct.len : 0u;
+      for (int i = 0; i < n; i += 2)
+      {
+        const uint32_t w = rec2[i >> 1];
+        bits += huff_ac_token12(w & 0xFFFFu, ac).len;
+        if (i + 1 < n)
+          bits += huff_ac_token12(w >> 16, ac).len;
+      }
+      if (need_eob)
+        bits += eob >> 16;
+    }
+    uint32_t incl = bits;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1)
+    {
+      const uint32_t v = __shfl_up(incl, d, 64);
+      if (lane >= (uint32_t)d)
+        incl += v;
+    }
+    if (lane == 63)
+      tot[par][wave] = incl;
+    __syncthreads(); // also: every wave has flushed (and cleared) the previous chunk's words
+    uint32_t wave_start = 0, chunk_bits = 0, lane0_len = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < (uint32_t)WAVES; w++)
+    { // the DC token of wave w's first block: predictor = the last block of wave w - 1 (of the previous chunk for w == 0)
+      const int pred = w == 0 ? (c0 == 0 ? 0 : carry_dc) : dcx[par][1][w - 1];
+      const HuffTok t0 = huff_dc_token(dcx[par][0][w] - pred, dc);
+      const uint32_t l0 = c0 + 64 * w < bpr ? t0.len : 0u;
+      const uint32_t t = tot[par][w] + l0;
+      if (w == wave)
+      {
+        lane0_len = l0;
+        if (lane == 0)
+          dct = t0;
+      }
+      wave_start += w < wave ? t : 0;
+      chunk_bits += t;
+    }
+    carry_dc = dcx[par][1][WAVES - 1];
+    const uint32_t end_bits = base_bits + chunk_bits;
+    const uint32_t w_first = base_bits >> 5, w_end = end_bits >> 5;
+    for (uint32_t win = w_first; win <= w_end; win += RING)
+    {
+      if (win != w_first)
+        __syncthreads(); // the previous window's slots are cleared
+      if (live)
+      {
+        const uint32_t cur = base_bits + wave_start + (incl - bits) + (lane ? lane0_len : 0u);
+        uint32_t widx = cur >> 5;
+        uint32_t acc = 0;
+        uint32_t nacc = cur & 31;
+        auto put = [&](uint32_t tok, uint32_t len) { // 1 <= len <= 27, tok < 2^len
+          const uint32_t total = nacc + len;
+          if (total < 32)
+          {
+            acc = (acc << len) | tok;
+            nacc = total;
+          }
+          else
+          {
+            const uint32_t over = total - 32;
+            if (widx - win < RING)
+              atomicOr(&ring[widx & (RING - 1)], (acc << ((32 - nacc) & 31)) | (tok >> over));
+            widx++;
+            acc = tok & ((1u << over) - 1u);
+            nacc = over;
+          }
+        };
+        put(dct.bits, dct.len);
+        for (int i = 0; i < n; i += 2)
+        {
+          const uint32_t w = rec2[i >> 1];
+          const HuffTok ta = huff_ac_token12(w & 0xFFFFu, ac);
+          put(ta.bits, ta.len);
+          if (i + 1 < n)
+          {
+            const HuffTok tb = huff_ac_token12(w >> 16, ac);
+            put(tb.bits, tb.len);
+          }
+        }
+        if (need_eob)
+          put(eob & 0xFFFFu, eob >> 16);
+        if (nacc && widx - win < RING)
+          atomicOr(&ring[widx & (RING - 1)], acc << (32 - nacc));
+      }
+      __syncthreads();
+      const uint32_t stop = min(w_end, win + RING);
+      for (uint32_t w = win + tid; w < stop; w += kChunk)
+      {
+        const uint32_t v = ring[w & (RING - 1)];
+        ff += (uint32_t)__builtin_popcount(ff_bytes(v));
+        out_w[w] = __builtin_bswap32(v);
+        ring[w & (RING - 1)] = 0;
+      }
+    }
+    base_bits = end_bits;
+    par ^= 1;
+  }
+
+  // one thread, after the last chunk (behind a workgroup barrier); *ff_last = 0xFF bytes in the padded last word
+  __device__ __forceinline__ uint32_t finish(uint32_t *ff_last)
+  {
+    const uint32_t rem = base_bits & 31;
+    *ff_last = 0;
+    if (rem)
+    {
+      const uint32_t pad = (8 - (rem & 7)) & 7;
+      uint32_t w = ring[(base_bits >> 5) & (RING - 1)];
+      if (pad)
+        w |= ((1u << pad) - 1u) << (32 - rem - pad);
+      out_w[base_bits >> 5] = __builtin_bswap32(w);
+      const uint32_t nbytes = (rem + 7) / 8; // the stream is MSB first: its bytes are the word's top ones
+      *ff_last = (uint32_t)__builtin_popcount(ff_bytes(w) & (0xFFFFFFFFu << (8 * (4 - nbytes))));
     }
     return (base_bits + 7) / 8;
   }

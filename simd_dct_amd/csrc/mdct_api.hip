@@ -449,7 +449,7 @@ int mdct_fwd_i16_records(const int16_t *from, size_t pitch, const float *lut, si
 extern "C" __attribute__((visibility("hidden"))) void mdct_huff_build(int which, uint32_t *tab, int ntab); // stages.hip
 
 static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride,
-                          uint32_t *seg_bytes, void *stream)
+                          uint32_t *seg_bytes, uint32_t *ff_counts, void *stream)
 {
   const uint8_t *px = static_cast<const uint8_t *>(px_);
   if (px == nullptr || out == nullptr || seg_bytes == nullptr)
@@ -475,6 +475,7 @@ static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const f
   a.px = px;
   a.out = out;
   a.seg_bytes = seg_bytes;
+  a.ff_counts = ff_counts;
   a.seg_stride = seg_stride;
   a.pitch_px = pitch_px;
   a.bpr = (uint32_t)bpr;
@@ -489,15 +490,15 @@ static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const f
 }
 
 int mdct_fwd_u8_huffman_rows(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride,
-                             uint32_t *seg_bytes, void *stream)
+                             uint32_t *seg_bytes, uint32_t *ff_counts, void *stream)
 {
-  return run_px_huffman(px, false, pitch, lut, level_shift, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, stream);
+  return run_px_huffman(px, false, pitch, lut, level_shift, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, ff_counts, stream);
 }
 
 int mdct_fwd_i16_huffman_rows(const int16_t *from, size_t pitch, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes,
-                              void *stream)
+                              uint32_t *ff_counts, void *stream)
 {
-  return run_px_huffman(from, true, pitch, lut, 0, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, stream);
+  return run_px_huffman(from, true, pitch, lut, 0, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, ff_counts, stream);
 }
 
 int mdct_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)

@@ -126,6 +126,7 @@ struct PxHuffArgs
   const uint8_t *px; // 8-bit pixels, or an int16 plane (k_px_huffman_rows<true, ..>)
   uint8_t *out;      // row segments, seg_stride apart
   uint32_t *seg_bytes;
+  uint32_t *ff_counts; // nullable: 0xFF bytes per row segment (what mdct_jpeg_pack_rows_counted needs instead of a counting pass)
   size_t seg_stride;
   size_t pitch_px;   // bytes (int16 plane: elements)
   OwnTables tb;      // qf in the pair order of the column pass (as U8RecArgs)

@@ -1645,22 +1645,24 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
 // ---------------------------------------------------------------------------------------
 // Pixels (or an int16 plane) -> baseline Huffman rows in ONE kernel: the front half of
 // k_u8_records (forward transform + quantiser on packed fp32), the zig-zag run/level compaction straight into the
-// workgroup's LDS -- one dword per pair (run << 16 | level), 65 dwords per block, a lane writes and later reads only its own
-// row -- and the chunk coder of k_huffman_rows (huffman_rows.h).  The 3 B/px of records that k_u8_records writes and
+// workgroup's LDS -- 16-bit entries run << 12 | level, 132 bytes per block (HuffRowCoder16, huffman_rows.h: the first version
+// kept k_huffman_rows' dword pairs, 260 bytes per block = 2 waves/SIMD, and was slower than the two stages it replaces), a lane
+// writes and later reads only its own row -- and the chunk coder of k_huffman_rows.  The 3 B/px of records that k_u8_records writes and
 // k_huffman_rows reads back (two thirds of them padding) never exist: 1 B/px in, ~0.2 B/px out.  One workgroup of WAVES
 // waves per block row (= restart interval); the next chunk's pixel rows are loaded while the current one is coded.
 // A wave's first block needs the previous wave's last DC as predictor, which is computed in the same pass: LATE_DC.
 // Byte for byte the segments of mdct_fwd_u8_records + mdct_huffman_rows.
 // ---------------------------------------------------------------------------------------
-constexpr int kFusedRec = 65; // dwords per block: 64 pairs + the slot that takes the zero coefficients' writes
+constexpr uint32_t kFusedRing = 1024; // words of bit stream held in LDS (2 bit/px over a 256-block chunk; denser chunks take several windows)
 template <bool I16_IN, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
 {
   __shared__ uint32_t ac[256], dc[12];
-  __shared__ uint32_t rec_all[WAVES][64 * kFusedRec];
-  __shared__ uint32_t ring[kHuffRing];
+  __shared__ __attribute__((aligned(4))) uint16_t rec_all[WAVES][64 * kRec16Row];
+  __shared__ uint32_t ring[kFusedRing];
   __shared__ uint32_t tot[2][WAVES];
   __shared__ int dcx[2][2][WAVES];
+  __shared__ uint32_t ff_total;
   constexpr uint32_t kChunk = 64 * WAVES;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t row = a.by0 + blockIdx.x;
@@ -1668,21 +1670,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
     ac[i] = a.ac[i];
   if (tid < 12)
     dc[tid] = a.dc[tid];
-  for (uint32_t w = tid; w < kHuffRing; w += kChunk)
+  if (tid == 0)
+    ff_total = 0;
+  for (uint32_t w = tid; w < kFusedRing; w += kChunk)
     ring[w] = 0;
-  HuffRowCoder<WAVES, 64, false, true> coder;
+  HuffRowCoder16<WAVES, kFusedRing> coder;
   coder.ac = ac;
   coder.dc = dc;
   coder.ring = ring;
   coder.tot = tot;
   coder.dcx = dcx;
   coder.out_w = reinterpret_cast<uint32_t *>(a.out + (size_t)row * a.seg_stride);
-  coder.zrl = a.ac[0xF0];
   coder.eob = a.ac[0x00];
   coder.bpr = a.bpr;
   const DctConsts &C = a.consts;
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
-  uint32_t *rec = rec_all[wave] + lane * kFusedRec;
+  uint16_t *rec = rec_all[wave] + lane * kRec16Row;
   const uint32_t last_blk = a.bpr - 1;
 
   typedef typename std::conditional<I16_IN, uint4, uint2>::type row_t;
@@ -1732,7 +1735,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
       }
       aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
     }
-    int val[64];
+    // quantised levels as the low 16 bits of val[]: the DC like the int16 plane would hold it (sat_i16), the AC coefficients
+    // saturated to the +-1023 of baseline categories 1..10 -- exactly what the staged coder does to an int16 record at token time
+    uint32_t val[64];
     constexpr int kA[4] = {0, 2, 5, 1}, kB[4] = {4, 6, 3, 7};
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -1745,28 +1750,42 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
       {
         f32x2 m;
         MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[v * 4 + j], MDCT_K_LH);
-        val[v * 8 + kA[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.x) & 0xFFFFu);
-        val[v * 8 + kB[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.y) & 0xFFFFu);
+        const bool is_dc = j == 0 && v == 0;
+        val[v * 8 + kA[j]] = __float_as_uint(__builtin_amdgcn_fmed3f(m.x, is_dc ? -32768.0f : -1023.0f, is_dc ? 32767.0f : 1023.0f) + C.magic23);
+        val[v * 8 + kB[j]] = __float_as_uint(__builtin_amdgcn_fmed3f(m.y, -1023.0f, 1023.0f) + C.magic23);
       }
     }
-    // ---- zig-zag order, run/level pairs compacted to the front of the lane's LDS row (zeros write into slot 64)
-    uint32_t pos = 0, run = 0;
+    // ---- zig-zag order; AC entries run << 12 | level compacted to the front of the lane's LDS row, a ZRL entry for every
+    // 16 zeros in a row (those after the last coefficient are dropped: n counts up to the last real one).  Zeros that
+    // need no entry write into slot 64.
+    uint32_t pos = 0, n = 0, run = 0;
 #pragma unroll
-    for (int k = 0; k < 64; k++)
+    for (int k = 1; k < 64; k++)
     {
-      const int c = val[kZigZag[k]];
-      const bool nz = c != 0;
-      rec[nz ? pos : 64u] = (run << 16) | ((uint32_t)c & 0xFFFFu);
-      pos += nz ? 1u : 0u;
-      run = nz ? 0u : run + 1u;
+      const uint32_t l12 = val[kZigZag[k]] & 0xFFFu;
+      const bool nz = (val[kZigZag[k]] & 0xFFFFu) != 0;
+      const bool wr = nz || run == 15;
+      rec[wr ? pos : 64u] = (uint16_t)(nz ? (run << 12) | l12 : 0xF000u);
+      pos += wr ? 1u : 0u;
+      n = nz ? pos : n;
+      run = wr ? 0u : run + 1u;
     }
+    const int my_dc = (int)(int16_t)(val[0] & 0xFFFFu);
+    const bool need_eob = (val[kZigZag[63]] & 0xFFFFu) == 0;
     if (c0 + kChunk < a.bpr)
       fetch(bx + kChunk); // in flight while this chunk is coded
-    coder.chunk(c0, rec, live ? (int)pos : 0, live, 0, nullptr, nullptr);
+    coder.chunk(c0, rec, (int)n, live, my_dc, need_eob);
   }
+  if (a.ff_counts && coder.ff)
+    atomicAdd(&ff_total, coder.ff);
   __syncthreads();
   if (tid == 0)
-    a.seg_bytes[row] = coder.finish();
+  {
+    uint32_t ff_last;
+    a.seg_bytes[row] = coder.finish(&ff_last);
+    if (a.ff_counts)
+      a.ff_counts[row] = ff_total + ff_last;
+  }
 }
 
 // Several planes (each with its own table) in one launch: linear block index over the

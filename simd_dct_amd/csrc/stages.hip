@@ -308,15 +308,9 @@ struct PackArgs
   uint8_t *out;
   unsigned long long capacity;
   unsigned long long *row_off; // [n_rows + 1]: k_pack_count leaves the lengths here, k_pack_scan turns them into offsets
+  const uint32_t *ff_counts;   // not null: 0xFF bytes per row, counted by the producer of the segments (no k_pack_count pass)
   uint32_t n_rows, first_rst;
 };
-
-// 0x80 in every byte of w that equals 0xFF (exact: no carries between bytes)
-__device__ __forceinline__ uint32_t ff_bytes(uint32_t w)
-{
-  const uint32_t t = ~w; // a zero byte of t is an 0xFF byte of w
-  return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);
-}
 
 // sum over the 256 threads of the workgroup (returned to all) and the exclusive prefix of this thread
 __device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t *wave_tot /* LDS [4] */, uint32_t &total)
@@ -373,7 +367,9 @@ __global__ __launch_bounds__(256) void k_pack_scan(PackArgs a)
   for (uint32_t c0 = 0; c0 < a.n_rows; c0 += 256)
   {
     const uint32_t i = c0 + threadIdx.x;
-    const unsigned long long v = i < a.n_rows ? a.row_off[i] : 0ull;
+    unsigned long long v = 0;
+    if (i < a.n_rows)
+      v = a.ff_counts ? (unsigned long long)min((size_t)a.seg_bytes[i], a.seg_stride) + a.ff_counts[i] + (i + 1 < a.n_rows ? 2u : 0u) : a.row_off[i];
     unsigned long long incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1)
@@ -621,8 +617,25 @@ int mdct_huffman_rows(const int16_t *levels, const uint8_t *runs, const uint8_t 
   return e == hipSuccess ? MDCT_SUCCESS : mdct_set_error(MDCT_NOT_SUPPORTED, "huffman kernel launch: %s", hipGetErrorString(e));
 }
 
+static int pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, const uint32_t *ff_counts, size_t seg_stride, size_t n_rows, int first_rst, uint8_t *out, size_t out_capacity,
+                     uint64_t *row_offsets, void *stream);
+
 int mdct_jpeg_pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, size_t seg_stride, size_t n_rows, int first_rst, uint8_t *out, size_t out_capacity, uint64_t *row_offsets,
                         void *stream)
+{
+  return pack_rows(segments, seg_bytes, nullptr, seg_stride, n_rows, first_rst, out, out_capacity, row_offsets, stream);
+}
+
+int mdct_jpeg_pack_rows_counted(const uint8_t *segments, const uint32_t *seg_bytes, const uint32_t *ff_counts, size_t seg_stride, size_t n_rows, int first_rst, uint8_t *out,
+                                size_t out_capacity, uint64_t *row_offsets, void *stream)
+{
+  if (!ff_counts)
+    return mdct_set_error(MDCT_INVALID_PARAMETER, "null pointer");
+  return pack_rows(segments, seg_bytes, ff_counts, seg_stride, n_rows, first_rst, out, out_capacity, row_offsets, stream);
+}
+
+static int pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, const uint32_t *ff_counts, size_t seg_stride, size_t n_rows, int first_rst, uint8_t *out, size_t out_capacity,
+                     uint64_t *row_offsets, void *stream)
 {
   if (!segments || !seg_bytes || !out || !row_offsets)
     return mdct_set_error(MDCT_INVALID_PARAMETER, "null pointer");
@@ -639,8 +652,9 @@ int mdct_jpeg_pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, size
   a.row_off = reinterpret_cast<unsigned long long *>(row_offsets);
   a.n_rows = (uint32_t)n_rows;
   a.first_rst = (uint32_t)first_rst;
+  a.ff_counts = ff_counts;
   hipStream_t s = (hipStream_t)stream;
-  if (n_rows)
+  if (n_rows && !ff_counts)
     hipLaunchKernelGGL(mdct::k_pack_count, dim3(a.n_rows), dim3(256), 0, s, a);
   hipLaunchKernelGGL(mdct::k_pack_scan, dim3(1), dim3(256), 0, s, a);
   if (n_rows)

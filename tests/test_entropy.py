@@ -213,7 +213,8 @@ def test_fused_pixels_to_huffman_rows_equals_the_staged_path_and_the_checker():
             # fused
             seg_b = torch.full(((H // 8) * stride + 64,), 0x5A, dtype=torch.uint8, device="cuda")
             nb_b = torch.full((H // 8,), -1, dtype=torch.int32, device="cuda")
-            api.fwd_u8_huffman_rows(d_img, W, H, seg_b, nb_b, lut=q, level_shift=shift, chroma=chroma)
+            ff_b = torch.full((H // 8,), -1, dtype=torch.int32, device="cuda")
+            api.fwd_u8_huffman_rows(d_img, W, H, seg_b, nb_b, lut=q, level_shift=shift, chroma=chroma, ff_counts=ff_b)
             torch.cuda.synchronize()
             na, nbb = nb_a.cpu().numpy(), nb_b.cpu().numpy()
             assert np.array_equal(na, nbb), (W, H, kind)
@@ -221,6 +222,18 @@ def test_fused_pixels_to_huffman_rows_equals_the_staged_path_and_the_checker():
             for r in range(H // 8):
                 assert np.array_equal(ga[r * stride:r * stride + na[r]], gb[r * stride:r * stride + na[r]]), (W, H, kind, r)
             assert (gb[(H // 8) * stride:] == 0x5A).all()
+            # the 0xFF bytes counted on the way out, and the packing that uses them instead of its own counting pass
+            ffh = ff_b.cpu().numpy()
+            assert [int((gb[r * stride:r * stride + na[r]] == 0xFF).sum()) for r in range(H // 8)] == ffh.tolist(), (W, H, kind)
+            cap = int(na.sum()) * 2 + 2 * (H // 8) + 16
+            scan_a = torch.full((cap,), 0x33, dtype=torch.uint8, device="cuda")
+            scan_b = torch.full((cap,), 0x33, dtype=torch.uint8, device="cuda")
+            off_a = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
+            off_b = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
+            api.jpeg_pack_rows(seg_a, nb_a, stride, H // 8, scan_a, off_a, first_rst=3)
+            api.jpeg_pack_rows(seg_b[:(H // 8) * stride], nb_b, stride, H // 8, scan_b, off_b, first_rst=3, ff_counts=ff_b)
+            torch.cuda.synchronize()
+            assert torch.equal(off_a, off_b) and torch.equal(scan_a, scan_b), (W, H, kind)
             # the checker's composition (CPU), on the smaller cases
             if W * H <= 2048 * 64:
                 lvh, rnh, cth = O.u8_records(img, W, H, lut=q, level_shift=shift)
