@@ -440,6 +440,42 @@ __global__ __launch_bounds__(64, MINW) void v_q32_tile_prio(U8Args a)
   }
 }
 
+// stereo / SSE tier with a WAVE-private reorder: one workgroup = one wave = 64 consecutive blocks of one (block row, eye) row = 64
+// contiguous bytes of each of the 64 coefficient planes (simd_dct.cpp:1061-1099).  Staged as [coef][lane] like q32, then every store
+// instruction writes 64-byte pieces of 16 planes.  No workgroup barrier, 4.5 KiB of LDS per wave -- against the product's
+// 256-block workgroups with 256-byte pieces behind __syncthreads().
+template <int MINW>
+__global__ __launch_bounds__(64, MINW) void v_stereo_wave(U8Args a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t wl[64 * kQ32RowStride];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tile = blockIdx.x, row = blockIdx.y; // row = (block row, eye)
+  const uint32_t by = a.by0 + (row >> 1), eye = row & 1;
+  uint32_t q[64];
+  {
+    uint2 rows[8];
+    load_block_rows_g(a.from + (size_t)by * 8 * a.pitch + (size_t)eye * a.eye_offset + (size_t)tile * 512, a.pitch, lane * 8, rows);
+    encode_block_pk<MDCT_PROFILE_REF_SSE, MDCT_LAYOUT_STEREO, false>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, nullptr, q);
+  }
+#pragma unroll
+  for (int c = 0; c < 64; c++)
+    wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // store k, lane l: plane c = 16 k + (l >> 2), bytes [16 (l & 3), +16) of the wave's 64
+  const size_t pos0 = ((size_t)a.by0 * 2 + row) * a.bpr + (size_t)tile * 64;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+  {
+    const uint32_t c = 16 * k + (lane >> 2), part = lane & 3;
+    const uint4 v = *reinterpret_cast<const uint4 *>(wl + c * kQ32RowStride + part * 16);
+    typedef unsigned int u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+    const u32x4_unaligned w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4_unaligned *>(a.to + a.plane_stride * c + pos0 + part * 16));
+  }
+}
+
 int main(int argc, char **argv)
 {
   const char *mode = argc > 1 ? argv[1] : "ab";
@@ -500,6 +536,59 @@ int main(int argc, char **argv)
     return 0;
   }
 
+  if (!strcmp(mode, "ab_stereo"))
+  {
+    U8Args st = a;
+    for (int i = 0; i < 64; i++) q[i] = 255.0f / ((0.1f + 0.01f * i) * 8 * 0.95f);
+    for (int m = 0; m < 8; m++)
+      for (int j = 0; j < 4; j++)
+      { // stereo: columns first, pair (m, j) = coefficients (kPairA[j], m) / (kPairB[j], m) stored at first*8 + second
+        st.qt.q[(m * 4 + j) * 2] = q[kPairA[j] * 8 + m];
+        st.qt.q[(m * 4 + j) * 2 + 1] = q[kPairB[j] * 8 + m];
+      }
+    st.pk = PkConstsArg{{a.consts.a, a.consts.f}, {a.consts.c, a.consts.d}, {a.consts.b, a.consts.e}, {a.consts.n, a.consts.magic23},
+                        {a.consts.d, a.consts.a}, {a.consts.f, a.consts.d}, {a.consts.f, a.consts.c}, {a.consts.c, a.consts.a}, {1.f / (float)0xFF, 127.0f}};
+    st.eye_offset = W * (H / 2);
+    st.plane_stride = W * H / 64;
+    st.nblocks = (uint32_t)(W / 8 * H / 8);
+    auto sargs = [&](int s) { U8Args x = st; x.from = A[s]; x.to = B[s]; return x; };
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    struct V { const char *name; std::function<void(int)> f; std::vector<float> t; };
+    std::vector<V> vs;
+    const dim3 g64((unsigned)(W / 512), (unsigned)(H / 8));
+    vs.push_back({"stereo/SSE product (256-block workgroups)", [&](int s) { launch_fwd_quant_u8(sargs(s), MDCT_LAYOUT_STEREO, MDCT_PROFILE_REF_SSE, false, 0); }, {}});
+    vs.push_back({"stereo/SSE wave-private reorder 6w", [&](int s) { hipLaunchKernelGGL((v_stereo_wave<6>), g64, dim3(64), 0, 0, sargs(s)); }, {}});
+    vs.push_back({"stereo/SSE wave-private reorder 5w", [&](int s) { hipLaunchKernelGGL((v_stereo_wave<5>), g64, dim3(64), 0, 0, sargs(s)); }, {}});
+    std::vector<uint8_t> ref(bytes), got(bytes);
+    vs[0].f(0); hipMemcpy(ref.data(), B[0], bytes, hipMemcpyDeviceToHost);
+    for (size_t i = 1; i < vs.size(); i++)
+    {
+      hipMemset(B[0], 0x55, bytes);
+      vs[i].f(0);
+      hipMemcpy(got.data(), B[0], bytes, hipMemcpyDeviceToHost);
+      printf("%-44s %s\n", vs[i].name, memcmp(ref.data(), got.data(), bytes) ? "!! MISMATCH" : "bit-exact");
+    }
+    for (auto &v : vs) for (int i = 0; i < 300; i++) v.f(i % NS);
+    hipDeviceSynchronize();
+    for (int round = 0; round < 11; round++)
+      for (auto &v : vs)
+      {
+        for (int i = 0; i < 40; i++) v.f(i % NS);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 40; i++) v.f(i % NS);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        v.t.push_back(ms / 40);
+      }
+    for (auto &v : vs)
+    {
+      std::sort(v.t.begin(), v.t.end());
+      printf("%-44s median %7.2f us  min %7.2f us\n", v.name, v.t[v.t.size() / 2] * 1e3, v.t[0] * 1e3);
+    }
+    return 0;
+  }
   if (!strcmp(mode, "ab_f32"))
   {
     const size_t b32 = W * H * 4;
