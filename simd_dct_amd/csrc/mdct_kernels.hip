@@ -1487,8 +1487,9 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
 // time with 2 of 3 waves resident -- a freed slot waits until the other three waves of its workgroup are done too.
 // scheduling steered per mode like k_i16 (measured, profiles/r03_exp_i16_tile_and_priorities.log): forward 42.7 us with 2
 // (44.1 with 3, 45.1 with 4; k_i16<FWD> 43.7; the copy kernel 43.4), inverse 43.2 with 2 (45.1 with 4; k_i16<INV> 45.4),
-// fused round trip 45.4-45.7 with 3 or 4 (47.5 with 2; k_i16<ROUNDTRIP> 47.1-48.0); with a table the round trip needs 160 registers
-constexpr int i16_tile_waves(int mode, bool has_lut) { return mode == MODE_ROUNDTRIP ? 3 : 2; }
+// fused round trip with phase priorities 44.3 with 2, 44.7 with 3, 45.9 with 4 (without priorities 48.4 / 45.8 / 46.0;
+// k_i16<ROUNDTRIP> 47.1-48.6)
+constexpr int i16_tile_waves(int, bool) { return 2; }
 template <int MODE, bool HAS_LUT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(i16_tile_waves(MODE, HAS_LUT), i16_tile_waves(MODE, HAS_LUT)))) void k_i16_tile(I16Args a)
 {
@@ -2169,15 +2170,16 @@ hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s)
   return hipGetLastError();
 }
 
-// waves per workgroup (= per block row): 4 by default; MDCT_FUSED_HUFF_WAVES=2 in the environment selects the 2-wave build
-// (chunks of 128 blocks, half the LDS per workgroup) for A/B runs
+// waves per workgroup (= per block row): 4 by default; MDCT_FUSED_HUFF_WAVES=2 / 8 in the environment selects the 2- / 8-wave
+// builds (chunks of 128 / 512 blocks) for A/B runs
 hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, uint32_t n_rows, hipStream_t s)
 {
   if (n_rows == 0)
     return hipSuccess;
   static const int waves = [] {
     const char *e = getenv("MDCT_FUSED_HUFF_WAVES");
-    return e && atoi(e) == 2 ? 2 : 4;
+    const int w = e ? atoi(e) : 4;
+    return w == 2 || w == 8 ? w : 4;
   }();
   if (waves == 2)
   {
@@ -2185,6 +2187,13 @@ hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, uint32_t n_rows, 
       hipLaunchKernelGGL((k_px_huffman_rows<true, 2>), dim3(n_rows), dim3(128), 0, s, a);
     else
       hipLaunchKernelGGL((k_px_huffman_rows<false, 2>), dim3(n_rows), dim3(128), 0, s, a);
+  }
+  else if (waves == 8)
+  {
+    if (i16_in)
+      hipLaunchKernelGGL((k_px_huffman_rows<true, 8>), dim3(n_rows), dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_px_huffman_rows<false, 8>), dim3(n_rows), dim3(512), 0, s, a);
   }
   else if (i16_in)
     hipLaunchKernelGGL((k_px_huffman_rows<true, 4>), dim3(n_rows), dim3(256), 0, s, a);

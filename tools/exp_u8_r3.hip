@@ -681,6 +681,7 @@ int main(int argc, char **argv)
       vs.push_back({"tile 64 thr, 4 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile<4>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
       vs.push_back({"tile 64 thr, 5 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile<5>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
       vs.push_back({"tile 64 thr, 6 waves", [&](int s) { hipLaunchKernelGGL((v_i16_tile<6>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
+      vs.push_back({"tile 64 thr, 2 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_i16_tile_prio<2>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
       vs.push_back({"tile 64 thr, 3 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_i16_tile_prio<3>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
       vs.push_back({"tile 64 thr, 4 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_i16_tile_prio<4>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
       vs.push_back({"tile 64 thr, 6 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_i16_tile_prio<6>), g64, dim3(64), 0, 0, iargs(s)); }, {}});
