@@ -220,6 +220,22 @@ int mdct_jpeg_pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, size
 /* the same when the producer of the segments has counted their 0xFF bytes (ff_counts[r], mdct_fwd_*_huffman_rows): two launches instead of three */
 int mdct_jpeg_pack_rows_counted(const uint8_t *segments, const uint32_t *seg_bytes, const uint32_t *ff_counts, size_t seg_stride, size_t n_rows,
                                 int first_rst, uint8_t *out, size_t out_capacity, uint64_t *row_offsets, void *stream);
+/* Pixels (or an int16 plane) -> the finished scan in ONE launch: mdct_fwd_*_huffman_rows and mdct_jpeg_pack_rows_counted in a single
+ * kernel.  A row's workgroup codes its segment into seg_work (scratch, addressed like `out` of mdct_fwd_u8_huffman_rows:
+ * row by at seg_work + by * seg_stride, so by1 * seg_stride bytes), publishes its stuffed length, waits for the rows before it and copies
+ * the segment -- still in L2 -- to its place in `out`.  out / out_capacity / row_offsets (by1 - by0 + 1 entries) / first_rst as for
+ * mdct_jpeg_pack_rows; by0 < by1.
+ * row_work: by1 - by0 + 2 device uint64 that the CALLER ZEROES ONCE (hipMemset) before the first call; every call leaves them ready
+ * for the next one, also for replays of a captured launch and for another number of rows.  Calls that share a row_work must
+ * not overlap (same stream, or ordered by events); concurrent calls take one row_work each.
+ * Should a row not hear from its predecessors within ~1 s (cannot happen while rows are dispatched in order), it writes
+ * UINT64_MAX to its row_offsets entry instead of a scan. */
+int mdct_fwd_u8_jpeg_scan(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
+                          int chroma, uint8_t *seg_work, size_t seg_stride, uint64_t *row_work, int first_rst, uint8_t *out, size_t out_capacity,
+                          uint64_t *row_offsets, void *stream);
+int mdct_fwd_i16_jpeg_scan(const int16_t *from, size_t pitch, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma,
+                           uint8_t *seg_work, size_t seg_stride, uint64_t *row_work, int first_rst, uint8_t *out, size_t out_capacity,
+                           uint64_t *row_offsets, void *stream);
 /* BITS (16 counts) and HUFFVAL of the table as a DHT marker segment carries them (host function).
  * which: 0 DC luminance (K.3), 1 AC luminance (K.5), 2 DC chrominance (K.4), 3 AC chrominance (K.6). */
 int mdct_huffman_spec(int which, uint8_t *bits16, uint8_t *vals, int *nvals);

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mdct_huffman_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mdct_fwd_u8_huffman_rows": (c_int, [c_void_p, c_size_t, f32p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "mdct_fwd_i16_huffman_rows": (c_int, [c_void_p, c_size_t, f32p, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mdct_fwd_u8_jpeg_scan": (c_int, [c_void_p, c_size_t, f32p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mdct_fwd_i16_jpeg_scan": (c_int, [c_void_p, c_size_t, f32p, c_size_t, c_size_t, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mdct_jpeg_pack_rows_counted": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mdct_jpeg_pack_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mdct_huffman_seg_stride": (c_size_t, [c_size_t]),

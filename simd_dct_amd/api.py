@@ -302,6 +302,37 @@ def fwd_i16_huffman_rows(src, sizeX, sizeY, out, seg_bytes, lut=None, seg_stride
     return rc
 
 
+def _scan_cap(out, out_capacity):
+    if out_capacity is not None:
+        return out_capacity
+    return out.numel() * out.element_size() if hasattr(out, "numel") else out.nbytes
+
+
+def fwd_u8_jpeg_scan(src, sizeX, sizeY, seg_work, row_work, out, row_offsets, lut=None, level_shift=True, seg_stride=None, chroma=False, by0=0, by1=None, pitch=None, first_rst=0,
+                     out_capacity=None, stream=None, check=True):
+    """8-bit pixels -> finished, stuffed scan with RSTm between the block rows in ONE launch (mdct_fwd_u8_jpeg_scan).
+    seg_work: by1 * seg_stride bytes of scratch; row_work: by1 - by0 + 2 int64 zeroed once by the caller; row_offsets: by1 - by0 + 1 int64"""
+    keep, lp = _lut_ptr(lut)
+    rc = _lib.load().mdct_fwd_u8_jpeg_scan(_ptr(src), sizeX if pitch is None else pitch, lp, int(bool(level_shift)), sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, int(bool(chroma)),
+                                           _ptr(seg_work), huffman_seg_stride(sizeX) if seg_stride is None else seg_stride, _ptr(row_work), first_rst, _ptr(out), _scan_cap(out, out_capacity),
+                                           _ptr(row_offsets), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+def fwd_i16_jpeg_scan(src, sizeX, sizeY, seg_work, row_work, out, row_offsets, lut=None, seg_stride=None, chroma=False, by0=0, by1=None, pitch=None, first_rst=0, out_capacity=None,
+                      stream=None, check=True):
+    """int16 plane -> finished scan in ONE launch (mdct_fwd_i16_jpeg_scan); arguments as fwd_u8_jpeg_scan"""
+    keep, lp = _lut_ptr(lut)
+    rc = _lib.load().mdct_fwd_i16_jpeg_scan(_ptr(src), sizeX if pitch is None else pitch, lp, sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, int(bool(chroma)),
+                                            _ptr(seg_work), huffman_seg_stride(sizeX) if seg_stride is None else seg_stride, _ptr(row_work), first_rst, _ptr(out), _scan_cap(out, out_capacity),
+                                            _ptr(row_offsets), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
 def jpeg_pack_rows(segments, seg_bytes, seg_stride, n_rows, out, row_offsets, first_rst=0, out_capacity=None, ff_counts=None, stream=None, check=True):
     """row segments of huffman_rows -> one stuffed scan with RSTm between the rows (mdct_jpeg_pack_rows); row_offsets: n_rows + 1 int64.
     ff_counts (from fwd_*_huffman_rows): mdct_jpeg_pack_rows_counted, no counting pass"""

@@ -448,12 +448,25 @@ int mdct_fwd_i16_records(const int16_t *from, size_t pitch, const float *lut, si
 
 extern "C" __attribute__((visibility("hidden"))) void mdct_huff_build(int which, uint32_t *tab, int ntab); // stages.hip
 
+struct PxScanOut
+{ // the one-launch form: the rows go on into a contiguous scan (mdct_fwd_*_jpeg_scan)
+  uint64_t *row_work;
+  int first_rst;
+  uint8_t *scan;
+  size_t capacity;
+  uint64_t *row_offsets;
+};
+
 static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride,
-                          uint32_t *seg_bytes, uint32_t *ff_counts, void *stream)
+                          uint32_t *seg_bytes, uint32_t *ff_counts, const PxScanOut *pack, void *stream)
 {
   const uint8_t *px = static_cast<const uint8_t *>(px_);
-  if (px == nullptr || out == nullptr || seg_bytes == nullptr)
+  if (px == nullptr || out == nullptr || (seg_bytes == nullptr && !pack))
     return fail(MDCT_INVALID_PARAMETER, "null pointer");
+  if (pack && (pack->row_work == nullptr || pack->scan == nullptr || pack->row_offsets == nullptr))
+    return fail(MDCT_INVALID_PARAMETER, "null pointer");
+  if (pack && ((((uintptr_t)pack->row_work | (uintptr_t)pack->row_offsets) & 7) || pack->first_rst < 0 || pack->first_rst > 7))
+    return fail(MDCT_INVALID_PARAMETER, "row_work and row_offsets 8-byte aligned; first_rst in 0..7");
   if (sizeX == 0 || sizeX % 8 != 0 || sizeY % 8 != 0)
     return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu is not a multiple of 8x8", sizeX, sizeY);
   const size_t bpr = sizeX / 8;
@@ -465,6 +478,8 @@ static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const f
     return fail(MDCT_INVALID_PARAMETER, "rows of the int16 plane must be 16-byte aligned");
   if (by1 - by0 > 0x7FFFFFFFull)
     return fail(MDCT_NOT_SUPPORTED, "too many block rows for one call");
+  if (pack && by0 == by1)
+    return fail(MDCT_INVALID_PARAMETER, "an empty block-row range has no scan");
   const mdct_device_info *di;
   int r = current(&di);
   if (r)
@@ -480,25 +495,48 @@ static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const f
   a.pitch_px = pitch_px;
   a.bpr = (uint32_t)bpr;
   a.by0 = (uint32_t)by0;
+  if (pack)
+  {
+    a.scan = pack->scan;
+    a.capacity = pack->capacity;
+    a.row_off = reinterpret_cast<unsigned long long *>(pack->row_offsets);
+    a.work = reinterpret_cast<unsigned long long *>(pack->row_work);
+    a.n_rows = (uint32_t)(by1 - by0);
+    a.first_rst = (uint32_t)pack->first_rst;
+  }
   if ((r = make_own_tables(lut, a.tb, /*pair_order=*/true)))
     return r;
   a.dc_shift = level_shift ? 64.0f * 128.0f : 0.0f;
   mdct_huff_build(chroma ? 2 : 0, a.dc, 12);
   mdct_huff_build(chroma ? 3 : 1, a.ac, 256);
-  const hipError_t e = mdct::launch_px_huffman(a, i16_in, (uint32_t)(by1 - by0), (hipStream_t)stream);
+  const hipError_t e = mdct::launch_px_huffman(a, i16_in, pack != nullptr, (uint32_t)(by1 - by0), (hipStream_t)stream);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "pixels -> Huffman rows kernel launch");
 }
 
 int mdct_fwd_u8_huffman_rows(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride,
                              uint32_t *seg_bytes, uint32_t *ff_counts, void *stream)
 {
-  return run_px_huffman(px, false, pitch, lut, level_shift, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, ff_counts, stream);
+  return run_px_huffman(px, false, pitch, lut, level_shift, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, ff_counts, nullptr, stream);
 }
 
 int mdct_fwd_i16_huffman_rows(const int16_t *from, size_t pitch, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride, uint32_t *seg_bytes,
                               uint32_t *ff_counts, void *stream)
 {
-  return run_px_huffman(from, true, pitch, lut, 0, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, ff_counts, stream);
+  return run_px_huffman(from, true, pitch, lut, 0, sizeX, sizeY, by0, by1, chroma, out, seg_stride, seg_bytes, ff_counts, nullptr, stream);
+}
+
+int mdct_fwd_u8_jpeg_scan(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *seg_work, size_t seg_stride,
+                          uint64_t *row_work, int first_rst, uint8_t *out, size_t out_capacity, uint64_t *row_offsets, void *stream)
+{
+  const PxScanOut pack = {row_work, first_rst, out, out_capacity, row_offsets};
+  return run_px_huffman(px, false, pitch, lut, level_shift, sizeX, sizeY, by0, by1, chroma, seg_work, seg_stride, nullptr, nullptr, &pack, stream);
+}
+
+int mdct_fwd_i16_jpeg_scan(const int16_t *from, size_t pitch, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *seg_work, size_t seg_stride, uint64_t *row_work,
+                           int first_rst, uint8_t *out, size_t out_capacity, uint64_t *row_offsets, void *stream)
+{
+  const PxScanOut pack = {row_work, first_rst, out, out_capacity, row_offsets};
+  return run_px_huffman(from, true, pitch, lut, 0, sizeX, sizeY, by0, by1, chroma, seg_work, seg_stride, nullptr, nullptr, &pack, stream);
 }
 
 int mdct_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)

@@ -135,6 +135,12 @@ struct PxHuffArgs
   float dc_shift;    // 64*128 when level-shifting, else 0
   uint32_t dc[12];   // size << 16 | code per DC category
   uint32_t ac[256];  // size << 16 | code per RRRRSSSS
+  // k_px_huffman_rows<.., PACK> only: the row goes on into the contiguous scan in the same launch (pack_rows.h)
+  uint8_t *scan;
+  unsigned long long capacity;
+  unsigned long long *row_off; // [n_rows + 1]
+  unsigned long long *work;    // [n_rows + 2], zeroed once by the caller
+  uint32_t n_rows, first_rst;
 };
 
 struct F32Args
@@ -166,7 +172,7 @@ hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s);
 hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s);
 hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s);
 hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s);
-hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, uint32_t n_rows, hipStream_t s);
+hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, uint32_t n_rows, hipStream_t s);
 hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s);
 hipError_t launch_stream_copy(const void *from, void *to, size_t bytes, int cus, hipStream_t s);
 

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "huffman_rows.h"
+#include "pack_rows.h"
 #include "mdct_kernels.h"
 #include "scan_records.h"
 
@@ -1655,11 +1656,16 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
 // Byte for byte the segments of mdct_fwd_u8_records + mdct_huffman_rows.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kFusedRing = 1024; // words of bit stream held in LDS (2 bit/px over a 256-block chunk; denser chunks take several windows)
-template <bool I16_IN, int WAVES>
+// PACK (4 waves): the finished row goes on into the contiguous scan in the same launch -- it publishes its stuffed length,
+// waits until the rows before it have published theirs (pack_rows.h: chain_*), and copies its own segment (still in L2)
+// to its place, stuffed and followed by its restart marker: pixels -> decodable scan, one kernel.
+template <bool I16_IN, int WAVES, bool PACK = false>
 __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
 {
+  static_assert(!PACK || WAVES == 4, "the packing tail is written for 256 threads");
   __shared__ uint32_t ac[256], dc[12];
-  __shared__ __attribute__((aligned(4))) uint16_t rec_all[WAVES][64 * kRec16Row];
+  __shared__ __attribute__((aligned(16))) uint16_t rec_all[WAVES][64 * kRec16Row]; // PACK: later the staging buffer of the copy
+  static_assert(!PACK || sizeof(rec_all) >= kPackStageWords * 4, "the packing tail stages a window in the record rows");
   __shared__ uint32_t ring[kFusedRing];
   __shared__ uint32_t tot[2][WAVES];
   __shared__ int dcx[2][2][WAVES];
@@ -1667,6 +1673,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
   constexpr uint32_t kChunk = 64 * WAVES;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t row = a.by0 + blockIdx.x;
+  uint32_t tag = 0; // PACK: the chain's epoch, read now so that nobody waits for it later
+  if constexpr (PACK)
+    tag = __builtin_amdgcn_readfirstlane(chain_epoch_tag(a.work));
   for (uint32_t i = tid; i < 256; i += kChunk)
     ac[i] = a.ac[i];
   if (tid < 12)
@@ -1777,15 +1786,57 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
       fetch(bx + kChunk); // in flight while this chunk is coded
     coder.chunk(c0, rec, (int)n, live, my_dc, need_eob);
   }
-  if (a.ff_counts && coder.ff)
+  if ((PACK || a.ff_counts) && coder.ff)
     atomicAdd(&ff_total, coder.ff);
   __syncthreads();
-  if (tid == 0)
+  if constexpr (!PACK)
   {
-    uint32_t ff_last;
-    a.seg_bytes[row] = coder.finish(&ff_last);
-    if (a.ff_counts)
-      a.ff_counts[row] = ff_total + ff_last;
+    if (tid == 0)
+    {
+      uint32_t ff_last;
+      a.seg_bytes[row] = coder.finish(&ff_last);
+      if (a.ff_counts)
+        a.ff_counts[row] = ff_total + ff_last;
+    }
+  }
+  else
+  {
+    __shared__ uint32_t row_info[2]; // bytes, 0xFF bytes
+    __shared__ uint32_t wave_tot[4];
+    __shared__ unsigned long long wave_sum[4];
+    const uint32_t r = blockIdx.x;
+    const bool marker = r + 1 < a.n_rows;
+    if (tid == 0)
+    {
+      uint32_t ff_last;
+      const uint32_t nbytes = coder.finish(&ff_last), ff = ff_total + ff_last;
+      if (a.seg_bytes)
+        a.seg_bytes[row] = nbytes;
+      if (a.ff_counts)
+        a.ff_counts[row] = ff;
+      chain_publish(a.work, r, tag, nbytes + ff + (marker ? 2u : 0u));
+      row_info[0] = nbytes;
+      row_info[1] = ff;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores of the segment have reached L2 ...
+    __syncthreads();                                  // ... and so have everybody's: the copy below reads them back from there
+    const uint32_t nbytes = row_info[0];
+    PackRow<true> prow;
+    prow.begin(a.out + (size_t)row * a.seg_stride, a.seg_stride, nbytes); // on its way while the chain is consulted
+    const unsigned long long len = (unsigned long long)nbytes + row_info[1] + (marker ? 2u : 0u);
+    bool ok;
+    const unsigned long long base = chain_base(a.work, r, tag, wave_sum, ok);
+    if (tid == 0)
+    {
+      a.row_off[r] = ok ? base : ~0ull;
+      if (!marker)
+      {
+        chain_next_epoch(a.work, tag);
+        a.row_off[a.n_rows] = ok ? base + len : ~0ull;
+      }
+    }
+    if (ok && base + len <= a.capacity) // a row that does not fit is not written: the caller sees row_off[n_rows] > capacity
+      prow.finish(a.scan + base, marker, (a.first_rst + r) & 7, reinterpret_cast<uint32_t *>(&rec_all[0][0]), wave_tot);
   }
 }
 
@@ -2172,7 +2223,7 @@ hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s)
 
 // waves per workgroup (= per block row): 4 by default; MDCT_FUSED_HUFF_WAVES=2 / 8 in the environment selects the 2- / 8-wave
 // builds (chunks of 128 / 512 blocks) for A/B runs
-hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, uint32_t n_rows, hipStream_t s)
+hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, uint32_t n_rows, hipStream_t s)
 {
   if (n_rows == 0)
     return hipSuccess;
@@ -2181,7 +2232,14 @@ hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, uint32_t n_rows, 
     const int w = e ? atoi(e) : 4;
     return w == 2 || w == 8 ? w : 4;
   }();
-  if (waves == 2)
+  if (pack)
+  {
+    if (i16_in)
+      hipLaunchKernelGGL((k_px_huffman_rows<true, 4, true>), dim3(n_rows), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_px_huffman_rows<false, 4, true>), dim3(n_rows), dim3(256), 0, s, a);
+  }
+  else if (waves == 2)
   {
     if (i16_in)
       hipLaunchKernelGGL((k_px_huffman_rows<true, 2>), dim3(n_rows), dim3(128), 0, s, a);

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "huffman_rows.h"
+#include "pack_rows.h"
 #include "mdct.h"
 #include "scan_records.h"
 
@@ -312,34 +313,6 @@ struct PackArgs
   uint32_t n_rows, first_rst;
 };
 
-// sum over the 256 threads of the workgroup (returned to all) and the exclusive prefix of this thread
-__device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t *wave_tot /* LDS [4] */, uint32_t &total)
-{
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t incl = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1)
-  {
-    const uint32_t u = __shfl_up(incl, d, 64);
-    if (lane >= (uint32_t)d)
-      incl += u;
-  }
-  __syncthreads(); // the previous use of wave_tot is over
-  if (lane == 63)
-    wave_tot[wave] = incl;
-  __syncthreads();
-  uint32_t before = 0;
-  total = 0;
-#pragma unroll
-  for (uint32_t w = 0; w < 4; w++)
-  {
-    const uint32_t t = wave_tot[w];
-    before += w < wave ? t : 0;
-    total += t;
-  }
-  return before + incl - v;
-}
-
 __global__ __launch_bounds__(256) void k_pack_count(PackArgs a)
 {
   __shared__ uint32_t wave_tot[4];
@@ -398,45 +371,53 @@ __global__ __launch_bounds__(256) void k_pack_scan(PackArgs a)
     a.row_off[a.n_rows] = carry;
 }
 
+// stuffed length of row i in the scan, restart marker included (counted mode: the producer has counted the 0xFF bytes)
+__device__ __forceinline__ unsigned long long pack_row_len(const PackArgs &a, uint32_t i)
+{
+  return (unsigned long long)min((size_t)a.seg_bytes[i], a.seg_stride) + a.ff_counts[i] + (i + 1 < a.n_rows ? 2u : 0u);
+}
+
+// One workgroup per row; the copy itself is pack_write_row (pack_rows.h).
+// OWN_BASE (counted mode, few rows): the workgroup sums the lengths of the rows before it itself, so that no
+// k_pack_scan launch stands between the coder and the copy; it also writes row_off[].
+template <bool OWN_BASE>
 __global__ __launch_bounds__(256) void k_pack_write(PackArgs a)
 {
   __shared__ uint32_t wave_tot[4];
+  __shared__ unsigned long long wave_sum[4];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[kPackStageWords];
   const uint32_t r = blockIdx.x, nb = (uint32_t)min((size_t)a.seg_bytes[r], a.seg_stride); // a length beyond the stride is not a row
-  const unsigned long long base = a.row_off[r], end = a.row_off[r + 1];
+  PackRow<false> row;
+  row.begin(a.seg + (size_t)r * a.seg_stride, a.seg_stride, nb); // on its way while the row's place is worked out
+  unsigned long long base, end;
+  if (OWN_BASE)
+  {
+    unsigned long long s = 0;
+    for (uint32_t i0 = threadIdx.x; i0 < r; i0 += 4 * 256)
+    { // four rows per thread and step: eight independent loads in flight
+      unsigned long long l[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+        l[k] = i0 + 256 * k < r ? pack_row_len(a, i0 + 256 * k) : 0ull;
+      s += (l[0] + l[1]) + (l[2] + l[3]);
+    }
+    base = wg_sum256(s, wave_sum);
+    end = base + pack_row_len(a, r);
+    if (threadIdx.x == 0)
+    {
+      a.row_off[r] = base;
+      if (r + 1 == a.n_rows)
+        a.row_off[a.n_rows] = end;
+    }
+  }
+  else
+  {
+    base = a.row_off[r];
+    end = a.row_off[r + 1];
+  }
   if (end > a.capacity)
     return; // does not fit: the caller sees row_off[n_rows] > capacity
-  const uint32_t *p = reinterpret_cast<const uint32_t *>(a.seg + (size_t)r * a.seg_stride);
-  uint8_t *out = a.out + base;
-  uint32_t done = 0; // bytes of this row already written
-  for (uint32_t c0 = 0; c0 < nb; c0 += 1024)
-  {
-    const uint32_t i = c0 + threadIdx.x * 4;
-    uint32_t w = 0, nvalid = 0;
-    if (i < nb)
-    {
-      w = p[i >> 2];
-      nvalid = min(4u, nb - i);
-    }
-    uint32_t m = ff_bytes(w);
-    if (nvalid < 4)
-      m &= (1u << (8 * nvalid)) - 1u;
-    const uint32_t mine = nvalid + (uint32_t)__builtin_popcount(m);
-    uint32_t total;
-    uint32_t pos = done + wg_scan256(mine, wave_tot, total);
-    for (uint32_t k = 0; k < nvalid; k++)
-    {
-      const uint32_t b = (w >> (8 * k)) & 0xFFu;
-      out[pos++] = (uint8_t)b;
-      if (b == 0xFFu)
-        out[pos++] = 0;
-    }
-    done += total;
-  }
-  if (threadIdx.x == 0 && r + 1 < a.n_rows)
-  {
-    out[done] = 0xFF;
-    out[done + 1] = (uint8_t)(0xD0 + ((a.first_rst + r) & 7));
-  }
+  row.finish(a.out + base, r + 1 < a.n_rows, (a.first_rst + r) & 7, stage, wave_tot);
 }
 
 } // namespace mdct
@@ -654,11 +635,18 @@ static int pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, const u
   a.first_rst = (uint32_t)first_rst;
   a.ff_counts = ff_counts;
   hipStream_t s = (hipStream_t)stream;
-  if (n_rows && !ff_counts)
-    hipLaunchKernelGGL(mdct::k_pack_count, dim3(a.n_rows), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(mdct::k_pack_scan, dim3(1), dim3(256), 0, s, a);
-  if (n_rows)
-    hipLaunchKernelGGL(mdct::k_pack_write, dim3(a.n_rows), dim3(256), 0, s, a);
+  // counted rows, and few enough of them that every workgroup can sum the lengths before its own: one launch
+  static const bool never_own = getenv("MDCT_PACK_SCAN_KERNEL") != nullptr;
+  if (n_rows && ff_counts && n_rows <= 16384 && !never_own)
+    hipLaunchKernelGGL(mdct::k_pack_write<true>, dim3(a.n_rows), dim3(256), 0, s, a);
+  else
+  {
+    if (n_rows && !ff_counts)
+      hipLaunchKernelGGL(mdct::k_pack_count, dim3(a.n_rows), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mdct::k_pack_scan, dim3(1), dim3(256), 0, s, a);
+    if (n_rows)
+      hipLaunchKernelGGL(mdct::k_pack_write<false>, dim3(a.n_rows), dim3(256), 0, s, a);
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? MDCT_SUCCESS : mdct_set_error(MDCT_NOT_SUPPORTED, "pack kernel launch: %s", hipGetErrorString(e));
 }

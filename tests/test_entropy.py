@@ -353,6 +353,108 @@ def test_encoder_stages_replay_from_one_hip_graph():
         assert np.abs(dec.astype(int) - pic.astype(int)).mean() < 16  # and it is this picture (whose +-24 noise K.1 quantises away)
 
 
+@pytest.mark.gpu
+def test_one_launch_pixels_to_scan_equals_the_two_launch_path():
+    """mdct_fwd_u8_jpeg_scan / mdct_fwd_i16_jpeg_scan (the fused kernel with the packing as its tail: rows chained through row_work):
+    scan and row offsets byte for byte those of mdct_fwd_*_huffman_rows + mdct_jpeg_pack_rows_counted -- and of the checker's packing of
+    the same segments; the SAME row_work over many calls, other row counts, a replayed hipGraph, scans at odd addresses, a capacity that
+    cuts the scan, sub-ranges, more rows than are resident at once"""
+    api.init(0)
+    work = torch.zeros((4096 + 2,), dtype=torch.int64, device="cuda")  # zeroed ONCE; every call below reuses it
+    cases = [(8, 8, "photo"), (64, 16, "noise"), (264, 24, "photo"), (2048, 64, "noise"), (4104, 16, "photo"), (1000, 72, "flat"), (8192, 32, "photo"), (64, 32768, "photo"), (8, 8, "noise")]
+    for n_case, (W, H, kind) in enumerate(cases):
+        q = np.ones(64, dtype=np.float32) if kind == "noise" else K1_LUMA
+        if kind == "flat":
+            img = (np.arange(W // 8, dtype=np.int64)[None, :] * 37 + np.arange(H // 8, dtype=np.int64)[:, None] * 11) % 256
+            img = np.ascontiguousarray(np.kron(img, np.ones((8, 8), dtype=np.int64)).astype(np.uint8))
+        else:
+            img = synth.plane_u8_np(W, H, kind, seed=W + H)
+        n = H // 8
+        stride = api.huffman_seg_stride(W)
+        d_img = _dev(img)
+        seg = torch.full((n * stride,), 0x5A, dtype=torch.uint8, device="cuda")
+        nb = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        ff = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        api.fwd_u8_huffman_rows(d_img, W, H, seg, nb, lut=q, ff_counts=ff)
+        total = int(nb.sum().item()) + int(ff.sum().item()) + 2 * (n - 1)
+        want = torch.full((total + 24,), 0x33, dtype=torch.uint8, device="cuda")
+        woff = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
+        rst = n_case % 8
+        api.jpeg_pack_rows(seg, nb, stride, n, want[:total], woff, first_rst=rst, ff_counts=ff)
+        assert int(woff[-1].item()) == total
+        if W * H <= 2048 * 64:  # and the checker's packing of those segments
+            cw, coff = O.jpeg_pack_rows(seg.cpu().numpy(), nb.cpu().numpy().astype(np.uint32), stride, first_rst=rst)
+            assert np.array_equal(coff.astype(np.int64), woff.cpu().numpy()) and np.array_equal(cw[:total], want[:total].cpu().numpy())
+        seg_w = torch.empty((n * stride,), dtype=torch.uint8, device="cuda")
+        for shift in ((0, 1, 3) if n <= 64 else (2,)):
+            got = torch.full((total + 24,), 0x33, dtype=torch.uint8, device="cuda")
+            off = torch.full((n + 1,), -7, dtype=torch.int64, device="cuda")
+            api.fwd_u8_jpeg_scan(d_img, W, H, seg_w, work, got[shift:], off, lut=q, first_rst=rst, out_capacity=total)
+            torch.cuda.synchronize()
+            assert torch.equal(off, woff), (W, H, kind, shift)
+            assert torch.equal(got[shift: shift + total], want[:total]) and (got[:shift] == 0x33).all() and (got[shift + total:] == 0x33).all(), (W, H, kind, shift)
+        if n > 3:  # a capacity that ends inside row 2: rows 0 and 1 arrive, nothing else is touched, the offsets still tell the whole length
+            cut = int(woff[2].item()) + 1
+            got = torch.full((total + 24,), 0x33, dtype=torch.uint8, device="cuda")
+            api.fwd_u8_jpeg_scan(d_img, W, H, seg_w, work, got, off, lut=q, first_rst=rst, out_capacity=cut)
+            torch.cuda.synchronize()
+            assert torch.equal(off, woff) and torch.equal(got[: int(woff[2].item())], want[: int(woff[2].item())]) and (got[int(woff[2].item()):] == 0x33).all(), (W, H, kind)
+    # the same launch captured once and replayed: the epoch of the chain lives in row_work, not in the kernel arguments
+    W, H = 2048, 512
+    n, stride = H // 8, api.huffman_seg_stride(W)
+    imgs = [synth.plane_u8_torch(W, H, "photo", seed=40 + i) for i in range(3)]
+    cur = torch.empty_like(imgs[0])
+    seg_w = torch.empty((n * stride,), dtype=torch.uint8, device="cuda")
+    got = torch.zeros((W * H,), dtype=torch.uint8, device="cuda")
+    off = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        api.fwd_u8_jpeg_scan(cur, W, H, seg_w, work, got, off, lut=K1_LUMA)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        api.fwd_u8_jpeg_scan(cur, W, H, seg_w, work, got, off, lut=K1_LUMA)
+    seg = torch.empty((n * stride,), dtype=torch.uint8, device="cuda")
+    nb = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    ff = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    want = torch.zeros((W * H,), dtype=torch.uint8, device="cuda")
+    woff = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
+    for rep in range(6):
+        cur.copy_(imgs[rep % 3])
+        got.zero_()
+        g.replay()
+        api.fwd_u8_huffman_rows(cur, W, H, seg, nb, lut=K1_LUMA, ff_counts=ff)
+        want.zero_()
+        api.jpeg_pack_rows(seg, nb, stride, n, want, woff, ff_counts=ff)
+        torch.cuda.synchronize()
+        assert torch.equal(off, woff) and torch.equal(got, want), rep
+    # an int16 plane, pitched, chroma tables, a sub-range of the block rows (row offsets count from the sub-range's first row)
+    W, H, pitch = 1032, 48, 1040
+    s16 = np.zeros((H, pitch), dtype=np.int16)
+    s16[:, :W] = synth.plane_i16_np(W, H, "photo", seed=9)
+    d16 = _dev(s16)
+    stride = api.huffman_seg_stride(W)
+    seg = torch.empty(((H // 8) * stride,), dtype=torch.uint8, device="cuda")
+    nb = torch.zeros((H // 8,), dtype=torch.int32, device="cuda")
+    ff = torch.zeros((H // 8,), dtype=torch.int32, device="cuda")
+    api.fwd_i16_huffman_rows(d16, W, H, seg, nb, lut=K2_CHROMA, chroma=True, by0=2, by1=5, pitch=pitch, ff_counts=ff)
+    want = torch.full((W * H,), 0x33, dtype=torch.uint8, device="cuda")
+    woff = torch.zeros((4,), dtype=torch.int64, device="cuda")
+    api.jpeg_pack_rows(seg[2 * stride:], nb[2:], stride, 3, want, woff, first_rst=2, ff_counts=ff[2:])
+    got = torch.full((W * H,), 0x33, dtype=torch.uint8, device="cuda")
+    off = torch.zeros((4,), dtype=torch.int64, device="cuda")
+    seg_w = torch.empty(((H // 8) * stride,), dtype=torch.uint8, device="cuda")
+    api.fwd_i16_jpeg_scan(d16, W, H, seg_w, work, got, off, lut=K2_CHROMA, chroma=True, by0=2, by1=5, pitch=pitch, first_rst=2)
+    torch.cuda.synchronize()
+    assert torch.equal(off, woff) and torch.equal(got, want)
+    # argument checks
+    assert api.fwd_u8_jpeg_scan(d_img, 8, 8, seg_w, None, got, off, check=False) == 1
+    assert api.fwd_u8_jpeg_scan(d_img, 8, 8, seg_w, work, got, off, by0=1, by1=1, check=False) == 1
+    assert api.fwd_u8_jpeg_scan(d_img, 8, 8, seg_w, work, got, off, first_rst=8, check=False) == 1
+    assert api.fwd_u8_jpeg_scan(d_img, 8, 8, seg_w, work[1:].view(torch.uint8)[4:], got, off, check=False) == 1
+
+
 def test_pack_checker_equals_the_host_writer():
     """orc_jpeg_pack_rows == jfif.scan_bytes (numpy) on segments full of 0xFF bytes, empty rows, a capacity that cuts the scan short"""
     rng = np.random.default_rng(9)
@@ -378,7 +480,7 @@ def test_device_packed_scan_is_the_file_libjpeg_opens():
     JPEG whose scan was stuffed and joined on the device decodes like the one stuffed on the host"""
     api.init(0)
     rng = np.random.default_rng(10)
-    for (stride, n) in ((16, 1), (408, 13), (4104, 300), (213000, 40)):
+    for (stride, n) in ((16, 1), (408, 13), (412, 21), (4104, 300), (213000, 40), (16, 20000)):  # the last: more rows than the one-launch form takes
         nb = rng.integers(0, stride - 8, n).astype(np.uint32)
         nb[0] = stride - 8
         if n > 3:
@@ -394,6 +496,15 @@ def test_device_packed_scan_is_the_file_libjpeg_opens():
         assert np.array_equal(off.cpu().numpy().astype(np.uint64), woff), (stride, n)
         g = out.cpu().numpy()
         assert np.array_equal(g[: len(want)], want) and (g[len(want):] == 0x77).all(), (stride, n)
+        # the counted form (one launch: every workgroup sums the lengths before its own row), into a scan that starts at any byte address
+        ff = np.array([int((seg[r * stride:r * stride + nb[r]] == 0xFF).sum()) for r in range(n)], dtype=np.int32)
+        for shift in (0, 1, 2, 3):
+            out2 = torch.full((len(want) + 16,), 0x77, dtype=torch.uint8, device="cuda")
+            off.zero_()
+            api.jpeg_pack_rows(_dev(seg), _dev(nb.view(np.int32)), stride, n, out2[shift:], off, first_rst=n % 8, out_capacity=len(want), ff_counts=_dev(ff))
+            assert np.array_equal(off.cpu().numpy().astype(np.uint64), woff), (stride, n, shift)
+            g = out2.cpu().numpy()
+            assert (g[:shift] == 0x77).all() and np.array_equal(g[shift: shift + len(want)], want) and (g[shift + len(want):] == 0x77).all(), (stride, n, shift)
         if n > 8:  # a capacity that ends inside row 7: rows 0..6 arrive, nothing else is touched
             cut = int(woff[7]) + 3
             out.fill_(0x77)

@@ -1,7 +1,9 @@
 """Example: a baseline JPEG written by the engine's stages (tools/ = not part of the product path).
     python3 tools/gpu_jpeg.py out.jpg [synthetic | synthetic-color | raw_grey_file] [X Y]
-Default (round 3): the transform, the records and the Huffman rows are ONE kernel per plane (mdct_fwd_u8_huffman_rows /
-mdct_fwd_i16_huffman_rows), then mdct_jpeg_pack_rows.  MDCT_JPEG_STAGED=1 selects the staged path of round 2:
+Default (round 3), grey: ONE launch, pixels -> finished scan (mdct_fwd_u8_jpeg_scan).  Colour: per plane the fused pixels -> Huffman rows
+kernel (mdct_fwd_i16_huffman_rows), then mdct_jpeg_pack_rows_counted -- three one-launch encoders side by side on three streams wait on each
+other's rows and measure 2 % slower (MDCT_JPEG_ONE_LAUNCH=1 selects them anyway; MDCT_JPEG_TWO_LAUNCH=1 the two launches for grey too).
+MDCT_JPEG_STAGED=1 selects the staged path of round 2:
 grey:   pixels -> mdct_fwd_u8_records (Annex K.1 table; = mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 in one pass) -> mdct_huffman_rows
         -> mdct_jpeg_pack_rows (stuffing + RSTm, one contiguous scan) -> simd_dct_amd.jfif.write_jpeg (the marker segments)
 colour: interleaved 8-bit YCbCr -> mdct_split420_u8 -> per plane mdct_fwd_i16_records (K.1 / K.2) -> mdct_huffman_rows -> mdct_jpeg_pack_rows;
@@ -16,6 +18,8 @@ K1 = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 1
                18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
 K2 = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.float32)
 STAGED = os.environ.get("MDCT_JPEG_STAGED") == "1"
+COLOUR = len(sys.argv) > 2 and sys.argv[2] == "synthetic-color"
+TWO = os.environ.get("MDCT_JPEG_TWO_LAUNCH") == "1" or (COLOUR and os.environ.get("MDCT_JPEG_ONE_LAUNCH") != "1")
 out = sys.argv[1] if len(sys.argv) > 1 else "out.jpg"
 src = sys.argv[2] if len(sys.argv) > 2 else "synthetic"
 W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (4096, 2160 - 2160 % 16)
@@ -38,6 +42,7 @@ class Plane:
         self.ff = None if STAGED else torch.empty((h // 8,), dtype=torch.int32, device="cuda")  # 0xFF bytes per row, counted by the fused kernel
         self.scan = torch.empty((w * h // 2,), dtype=torch.uint8, device="cuda")
         self.off = torch.zeros((h // 8 + 1,), dtype=torch.int64, device="cuda")
+        self.work = torch.zeros((h // 8 + 2,), dtype=torch.int64, device="cuda")  # the one-launch form's chain between the rows: zeroed once
 
     def entropy(self, stream=None):
         M.huffman_rows(self.lv, self.rn, self.ct, self.w, self.h, self.seg, self.nb, chroma=self.chroma, stream=stream)
@@ -72,12 +77,14 @@ if src == "synthetic-color":
             if STAGED:
                 M.fwd_i16_records(s, p.w, p.h, p.lv, p.rn, p.ct, lut=p.q, stream=st.cuda_stream)
                 p.entropy(stream=st.cuda_stream)
-            else:
+            elif TWO:
                 M.fwd_i16_huffman_rows(s, p.w, p.h, p.seg, p.nb, lut=p.q, chroma=p.chroma, ff_counts=p.ff, stream=st.cuda_stream)
                 p.pack(stream=st.cuda_stream)
+            else:
+                M.fwd_i16_jpeg_scan(s, p.w, p.h, p.seg, p.work, p.scan, p.off, lut=p.q, chroma=p.chroma, stream=st.cuda_stream)
         for st in side_streams:
             cur.wait_stream(st)
-    what = "4:2:0 colour, 10 launches on 3 streams (staged)" if STAGED else "4:2:0 colour, split + 3 x (fused kernel + pack) on 3 streams"
+    what = "4:2:0 colour, 10 launches on 3 streams (staged)" if STAGED else ("4:2:0 colour, split + 3 x (fused kernel + pack) on 3 streams" if TWO else "4:2:0 colour, split + 3 x one launch on 3 streams")
 else:
     img = synth.plane_u8_torch(W, H, "photo") if src == "synthetic" else torch.from_numpy(np.fromfile(src, dtype=np.uint8)[: W * H].reshape(H, W)).cuda()
     planes = [Plane(W, H, K1, False)]
@@ -87,10 +94,12 @@ else:
         if STAGED:
             M.fwd_u8_records(img, W, H, p.lv, p.rn, p.ct, lut=K1)
             p.entropy()
-        else:
+        elif TWO:
             M.fwd_u8_huffman_rows(img, W, H, p.seg, p.nb, lut=K1, ff_counts=p.ff)
             p.pack()
-    what = "grey, 3 stages" if STAGED else "grey, fused kernel + pack"
+        else:
+            M.fwd_u8_jpeg_scan(img, W, H, p.seg, p.work, p.scan, p.off, lut=K1)
+    what = "grey, 3 stages" if STAGED else ("grey, fused kernel + pack" if TWO else "grey, one launch")
 
 for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -7,7 +7,7 @@ O=$R/gpurun_out/r03prof
 mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/trace -o bench --output-format csv -- python3 $R/bench.py --steps 2000 --warmup 200 --no-cpu-baseline > $O/bench_under_trace.log 2> $O/bench_under_trace.err
 echo "trace rc=$?"
-for k in q32 stereo_sse encq_sse stereo_scalar encq_scalar scan_q32 u8_records roundtrip; do
+for k in q32 stereo_sse encq_sse stereo_scalar encq_scalar scan_q32 u8_records px_huffman roundtrip; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c -d $O/pmc_${k}_$c -o run --output-format csv -- python3 $R/tools/run_kernel.py $k 12 > $O/pmc_${k}_$c.log 2>&1
     echo "pmc $k $c rc=$?"

@@ -1,5 +1,5 @@
 """Launch ONE engine kernel repeatedly on the bench workload (for rocprofv3 --pmc passes):
-    python3 tools/run_kernel.py {roundtrip|fwd|inv|q32|stereo_sse|encq_sse|stereo_scalar|encq_scalar|scan_q32|u8_records|copy|huffman|huffman_k1} [launches]"""
+    python3 tools/run_kernel.py {roundtrip|fwd|inv|q32|stereo_sse|encq_sse|stereo_scalar|encq_scalar|scan_q32|u8_records|copy|huffman|huffman_k1|px_huffman|px_huffman_k1} [launches]"""
 import os
 import sys
 
@@ -38,6 +38,14 @@ if which.startswith("huffman"):
     hnb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     print("pairs per block", float(recs[0][2].float().mean()))
+K1 = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+               18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+if which.startswith("px_huffman"):  # the fused pixels -> Huffman rows kernel: dense quality-60 table, or Annex K.1
+    pq = K1 if which.endswith("_k1") else (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32)
+    hstride = M.huffman_seg_stride(W)
+    hseg = torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda")
+    hnb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
+    hff = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
 lut8 = (M.QUANTIZE_BASE * np.float32(8)).astype(np.float32)
 U8 = {"stereo_sse": (M.LAYOUT_STEREO, M.PROFILE_REF_SSE, H // 16), "encq_sse": (M.LAYOUT_BLOCK_SSE, M.PROFILE_REF_SSE, H // 8),
       "stereo_scalar": (M.LAYOUT_STEREO, M.PROFILE_REF_SCALAR, H // 16), "encq_scalar": (M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, H // 8)}
@@ -66,6 +74,8 @@ for i in range(n):
         M.zigzag_rle_q32(u8d[s], W, H, lv, rn, ct)
     elif which == "u8_records":
         M.fwd_u8_records(u8s[s], W, H, lv, rn, ct, lut=q60)
+    elif which.startswith("px_huffman"):
+        M.fwd_u8_huffman_rows(u8s[s], W, H, hseg, hnb, lut=pq, ff_counts=hff)
     elif which.startswith("huffman"):
         M.huffman_rows(*recs[i % 2], W, H, hseg, hnb)
     elif which == "copy":

@@ -1,5 +1,5 @@
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import simd_dct_amd as M
 from simd_dct_amd import synth
 W = H = 8192
@@ -25,3 +25,19 @@ for name, q in (("q60", Q60), ("K.1", K1)):
         best.append(t.elapsed_ms() / 40)
     best.sort()
     print(f"waves {os.environ.get('MDCT_FUSED_HUFF_WAVES', '4')}: fused px -> Huffman rows, {name}: {best[2] * 1e3:.1f} us")
+# the packing of the K.1 rows just written: counted (one launch unless MDCT_PACK_SCAN_KERNEL is set) and uncounted (three launches)
+scan = torch.empty((W * H // 2,), dtype=torch.uint8, device="cuda")
+off = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
+for name, kw in (("counted", True), ("uncounted", False)):
+    f = (lambda i: M.jpeg_pack_rows(seg[i % 2], nb[i % 2], st, H // 8, scan, off, ff_counts=ff[i % 2])) if kw else (lambda i: M.jpeg_pack_rows(seg[i % 2], nb[i % 2], st, H // 8, scan, off))
+    for i in range(100):
+        f(i)
+    best = []
+    for r in range(5):
+        t.start()
+        for i in range(40):
+            f(i)
+        t.stop()
+        best.append(t.elapsed_ms() / 40)
+    best.sort()
+    print(f"pack {name} (scan kernel forced: {os.environ.get('MDCT_PACK_SCAN_KERNEL') is not None}): {best[2] * 1e3:.1f} us, {int(off[-1].item())} bytes")
