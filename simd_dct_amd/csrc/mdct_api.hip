@@ -156,7 +156,7 @@ void aan_tables(float *fwd, float *inv)
 
 // forward multiplier = (1/lut) * scale, inverse multiplier = lut * scale, each one float op
 // pair_order: the fused round trip runs on packed fp32 and wants both tables in the register-pair order of its
-// column pass, (v*4 + j)*2 + {0,1} = (v, kAanPairA[j]) / (v, kAanPairB[j])  (mdct_kernels.hip: i16_roundtrip_pk)
+// column pass, j-major: (j*8 + v)*2 + {0,1} = (v, kAanPairA[j]) / (v, kAanPairB[j])  (mdct_kernels.hip: i16_roundtrip_rows)
 int make_own_tables(const float *lut, mdct::OwnTables &tb, bool pair_order = false)
 {
   float ft[64], it[64];
@@ -175,10 +175,10 @@ int make_own_tables(const float *lut, mdct::OwnTables &tb, bool pair_order = fal
     for (int v = 0; v < 8; v++)
       for (int j = 0; j < 4; j++)
       {
-        tb.qf[(v * 4 + j) * 2] = t.qf[v * 8 + pa[j]];
-        tb.qf[(v * 4 + j) * 2 + 1] = t.qf[v * 8 + pb[j]];
-        tb.dq[(v * 4 + j) * 2] = t.dq[v * 8 + pa[j]];
-        tb.dq[(v * 4 + j) * 2 + 1] = t.dq[v * 8 + pb[j]];
+        tb.qf[(j * 8 + v) * 2] = t.qf[v * 8 + pa[j]];
+        tb.qf[(j * 8 + v) * 2 + 1] = t.qf[v * 8 + pb[j]];
+        tb.dq[(j * 8 + v) * 2] = t.dq[v * 8 + pa[j]];
+        tb.dq[(j * 8 + v) * 2 + 1] = t.dq[v * 8 + pb[j]];
       }
   }
   return MDCT_SUCCESS;

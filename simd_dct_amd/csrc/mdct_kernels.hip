@@ -1381,21 +1381,32 @@ __device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, 
 
 // Fused round trip on packed fp32: forward rows (h), forward columns (v), [quantise -> dequantise], inverse columns (v),
 // inverse rows (h).  With a table, `tb` holds the multipliers in the pair order of the column pass,
-// (v*4 + j)*2 + {0,1} = coefficient (v, A[j]) / (v, B[j]) with A = {0,2,5,1}, B = {4,6,3,7}: the pairs aan_fwd_h
+// j-major, (j*8 + v)*2 + {0,1} = coefficient (v, A[j]) / (v, B[j]) with A = {0,2,5,1}, B = {4,6,3,7}: the pairs aan_fwd_h
 // produces and aan_inv_h consumes (mdct_api.hip: make_own_tables).
 // PRIO: the wave raises its issue priority as it advances (forward rows 1, columns 2, inverse rows + stores 3), so that of
 // the waves sharing a SIMD the one closest to its stores goes first (shortest remaining work first)
 template <bool HAS_LUT, class Rows, bool PRIO = false>
-__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, const OwnTables &tb);
+__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, size_t tb_off);
 
+// tb_off: where the plane's OwnTables lie in the kernel's argument segment
 template <bool HAS_LUT>
-__device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16_t *src, int16_t *dst, size_t pitch_in, size_t pitch_out, const OwnTables &tb)
+__device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16_t *src, int16_t *dst, size_t pitch_in, size_t pitch_out, size_t tb_off)
 {
-  i16_roundtrip_rows<HAS_LUT>(C, RowsLinear{src, dst, pitch_in, pitch_out}, tb);
+  i16_roundtrip_rows<HAS_LUT>(C, RowsLinear{src, dst, pitch_in, pitch_out}, tb_off);
+}
+
+// The two tables are 128 multiplier pairs = 256 SGPRs if the compiler is left to fetch them when it likes -- it fetches
+// them all at the top and spills (252 v_readlane + 124 v_writelane per wave, 1451 vector instructions instead of ~1000).
+// So the pairs of column pair j are read from the argument segment through a pointer the compiler cannot see through,
+// right where they are used: two s_load_dwordx16 per j, 32 SGPRs live (mdct_api.hip lays the tables out j-major for this).
+typedef const __attribute__((address_space(4))) f32x2 *karg_pairs_t;
+__device__ __forceinline__ karg_pairs_t karg_pairs(size_t byte_off)
+{
+  return (karg_pairs_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + byte_off);
 }
 
 template <bool HAS_LUT, class Rows, bool PRIO>
-__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, const OwnTables &tb)
+__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, size_t tb_off)
 {
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
   uint4 in[8];
@@ -1420,10 +1431,12 @@ __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Row
     aan_fwd_v(K, P[j]);
     if constexpr (HAS_LUT)
     { // c = sat_i16(rne(y * qf)); z = c * dq  (rne_i16_float), on both halves
+      karg_pairs_t tq = karg_pairs(tb_off + offsetof(OwnTables, qf)) + j * 8, td = karg_pairs(tb_off + offsetof(OwnTables, dq)) + j * 8;
+      asm volatile("" : "+s"(tq), "+s"(td));
 #pragma unroll
       for (int v = 0; v < 8; v++)
       {
-        const f32x2 qf = reinterpret_cast<const f32x2 *>(tb.qf)[v * 4 + j], dq = reinterpret_cast<const f32x2 *>(tb.dq)[v * 4 + j];
+        const f32x2 qf = tq[v], dq = td[v];
         f32x2 m;
         MDCT_PKM(m, P[j][v], qf, MDCT_K_LH);
         m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
@@ -1477,7 +1490,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
   const int16_t *src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
   int16_t *dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
   if constexpr (MODE == MODE_ROUNDTRIP)
-    i16_roundtrip_pk<HAS_LUT>(a.consts, src, dst, a.pitch_in, a.pitch_out, a.tb);
+    i16_roundtrip_pk<HAS_LUT>(a.consts, src, dst, a.pitch_in, a.pitch_out, offsetof(I16Args, tb));
   else
     i16_block<MODE, HAS_LUT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, a.tb);
 }
@@ -1497,7 +1510,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(i16_tile_wav
   const size_t by = a.by0 + blockIdx.y;
   const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
   if constexpr (MODE == MODE_ROUNDTRIP)
-    i16_roundtrip_rows<HAS_LUT, RowsTiled, true>(a.consts, rows, a.tb); // with phase priorities
+    i16_roundtrip_rows<HAS_LUT, RowsTiled, true>(a.consts, rows, offsetof(I16Args, tb)); // with phase priorities
   else
     i16_block<MODE, HAS_LUT>(a.consts, rows, a.tb);
 }
@@ -1590,7 +1603,7 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
   const uint32_t row = t / a.bpr, bx = t - row * a.bpr;
   const DctConsts &C = a.consts;
   // the forward transform on packed fp32 (aan_fwd_h / aan_fwd_v: the same individually rounded operations as raw_fwd);
-  // a.tb.qf is in the pair order of the column pass, (v*4 + j)*2 + {0,1} = coefficient (v, A[j]) / (v, B[j]).
+  // a.tb.qf is in the pair order of the column pass, (j*8 + v)*2 + {0,1} = coefficient (v, A[j]) / (v, B[j]).
   // Rows are converted as they are consumed: the raw rows (16 / 32 registers) stay live, not 64 floats.
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
   f32x2 P[4][8];
@@ -1636,7 +1649,7 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
     for (int v = 0; v < 8; v++)
     { // the int16 the plane would have held (store_i16x8<0>), sign-extended
       f32x2 m;
-      MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[v * 4 + j], MDCT_K_LH);
+      MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[j * 8 + v], MDCT_K_LH);
       val[v * 8 + kA[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.x) & 0xFFFFu);
       val[v * 8 + kB[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.y) & 0xFFFFu);
     }
@@ -1759,7 +1772,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
       for (int v = 0; v < 8; v++)
       {
         f32x2 m;
-        MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[v * 4 + j], MDCT_K_LH);
+        MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[j * 8 + v], MDCT_K_LH);
         const bool is_dc = j == 0 && v == 0;
         val[v * 8 + kA[j]] = __float_as_uint(__builtin_amdgcn_fmed3f(m.x, is_dc ? -32768.0f : -1023.0f, is_dc ? 32767.0f : 1023.0f) + C.magic23);
         val[v * 8 + kB[j]] = __float_as_uint(__builtin_amdgcn_fmed3f(m.y, -1023.0f, 1023.0f) + C.magic23);
@@ -1846,10 +1859,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
 #ifndef MDCT_PLANES_WAVES
 #define MDCT_PLANES_WAVES 3
 #endif
-template <int LUTMODE>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_PLANES_WAVES, MDCT_PLANES_WAVES))) void k_i16_planes(PlaneBatchArgs a)
+template <int LUTMODE, int WG = kWG, int WAVES = MDCT_PLANES_WAVES, bool PRIO = false>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_i16_planes(PlaneBatchArgs a)
 {
-  const uint32_t t = wg_index() * kWG + threadIdx.x;
+  const uint32_t t = blockIdx.x * WG + threadIdx.x;
   // plane index from the wave's first block: wave-uniform, so the table reads stay scalar
   const uint32_t tw = __builtin_amdgcn_readfirstlane(t - (threadIdx.x & 63));
   if (tw >= a.prefix[a.n])
@@ -1874,14 +1887,14 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_PLANES
     // s_load_dwordx2 with a wait each (41.6-45 us instead of 36-38 on the 4:2:0 frame, profiles/r02_planes_waves.log).
     switch (p)
     {
-    case 0: i16_roundtrip_pk<true>(a.consts, src, dst, pin, pout, a.tb[0]); break;
-    case 1: i16_roundtrip_pk<true>(a.consts, src, dst, pin, pout, a.tb[1]); break;
-    case 2: i16_roundtrip_pk<true>(a.consts, src, dst, pin, pout, a.tb[2]); break;
-    default: i16_roundtrip_pk<true>(a.consts, src, dst, pin, pout, a.tb[3]); break;
+    case 0: i16_roundtrip_rows<true, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 0 * sizeof(OwnTables)); break;
+    case 1: i16_roundtrip_rows<true, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 1 * sizeof(OwnTables)); break;
+    case 2: i16_roundtrip_rows<true, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 2 * sizeof(OwnTables)); break;
+    default: i16_roundtrip_rows<true, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 3 * sizeof(OwnTables)); break;
     }
   }
   else
-    i16_roundtrip_pk<false>(a.consts, src, dst, pin, pout, a.tb[0]);
+    i16_roundtrip_rows<false, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, 0);
 }
 
 // float32 rows are 32 B per block: if every lane fetched its own 2 x 16 B, each wave load would
@@ -2182,6 +2195,18 @@ hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s)
   return hipErrorInvalidValue;
 }
 
+template <int WG, int WAVES, bool PRIO>
+static void launch_i16_planes_v(const PlaneBatchArgs &a, int with, uint32_t total, hipStream_t s)
+{
+  const dim3 grid((total + WG - 1) / WG), wg(WG);
+  if (with == 0)
+    hipLaunchKernelGGL((k_i16_planes<0, WG, WAVES, PRIO>), grid, wg, 0, s, a);
+  else if (with == a.n)
+    hipLaunchKernelGGL((k_i16_planes<1, WG, WAVES, PRIO>), grid, wg, 0, s, a);
+  else
+    hipLaunchKernelGGL((k_i16_planes<2, WG, WAVES, PRIO>), grid, wg, 0, s, a);
+}
+
 hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s)
 {
   const uint32_t total = a.prefix[a.n];
@@ -2190,12 +2215,9 @@ hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s)
   int with = 0;
   for (int i = 0; i < a.n; i++)
     with += a.has_lut[i] ? 1 : 0;
-  if (with == 0)
-    hipLaunchKernelGGL(k_i16_planes<0>, dim3(grid_for(total)), dim3(kWG), 0, s, a);
-  else if (with == a.n)
-    hipLaunchKernelGGL(k_i16_planes<1>, dim3(grid_for(total)), dim3(kWG), 0, s, a);
-  else
-    hipLaunchKernelGGL(k_i16_planes<2>, dim3(grid_for(total)), dim3(kWG), 0, s, a);
+  // one-wave workgroups, 3 waves per SIMD, no phase priorities: the best of seven combinations by 1-2 % on the single 8192^2
+  // plane and on the 8K 4:2:0 frame (64 / 256 threads x 2 / 3 waves x priorities on / off, profiles/r03_exp_planes_variants.log)
+  launch_i16_planes_v<64, 3, false>(a, with, total, s);
   return hipGetLastError();
 }
 

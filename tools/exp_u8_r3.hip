@@ -476,6 +476,93 @@ __global__ __launch_bounds__(64, MINW) void v_stereo_wave(U8Args a)
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The review's variant (i): a specialised LOADER wave per workgroup.  Workgroup = 1 loader wave + NC compute waves, one block
+// row (sizeX / 512 tiles) per workgroup in generations of NC tiles.  The loader issues global_load_lds_dwordx4 (64 lanes x 16 B
+// = two 512-byte pixel rows of a tile per instruction, straight into an LDS ring of two generations, no VGPRs), waits for the
+// generation the compute waves are about to read, and meets them at a workgroup barrier; a compute wave reads its block's rows by
+// ds_read_b64 (conflict-free), runs the product's encode_block_avx_pk and stages / stores its tile like k_q32_tile.
+// Two ring slots: generation g + 1 is issued right after barrier g (every compute wave is then through with generation g - 1,
+// the slot's previous tenant) and has the whole of generation g's arithmetic to land.
+// ---------------------------------------------------------------------------------------
+template <int NC, int MINW, int SPLIT>
+__global__ __launch_bounds__(64 * (NC + 1), MINW) void v_loader(U8Args a)
+{
+  // a slot holds a tile's 8 x 512 input bytes and, once its compute wave has them in registers, the same tile's output
+  // staged as [coef][lane] (64 x kQ32RowStride = 4608 bytes): 9 KiB of LDS per compute wave
+  __shared__ __attribute__((aligned(16))) uint8_t ring[2][NC][64 * kQ32RowStride];
+  const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t row = blockIdx.x / SPLIT, part = blockIdx.x % SPLIT;
+  const uint32_t tiles = a.bpr / 64 / SPLIT, gens = tiles / NC, tile0 = part * tiles;
+  const uint8_t *src_row = a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)tile0 * 512;
+  if (w == NC)
+  { // the loader
+    const uint32_t half = lane >> 5, l32 = lane & 31;
+    auto issue = [&](uint32_t g) {
+#pragma unroll
+      for (int t = 0; t < NC; t++)
+      {
+        const uint8_t *src16 = src_row + (size_t)half * a.pitch + (size_t)(g * NC + t) * 512 + l32 * 16;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src16 + (size_t)(2 * k) * a.pitch),
+                                           (__attribute__((address_space(3))) void *)(&ring[g & 1][t][k * 1024]), 16, 0, 0);
+      }
+    };
+    issue(0);
+    for (uint32_t g = 0; g < gens; g++)
+    {
+      __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): generation g has landed
+      __builtin_amdgcn_s_barrier();       // ... and every compute wave is through with generation g - 1, whose slot is free now
+      if (g + 1 < gens)
+        issue(g + 1); // in flight while the compute waves work on generation g
+    }
+    return;
+  }
+  for (uint32_t g = 0; g < gens; g++)
+  {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // read by inline asm: the compiler would put s_waitcnt vmcnt(0) -- i.e. a wait for this wave's own stores of the previous
+    // generation -- before every LDS read of a buffer that an LDS-DMA instruction anywhere in the kernel may write
+    uint8_t *wl = ring[g & 1][w];
+    const uint32_t slot_addr = (uint32_t)(uintptr_t)wl;
+    const uint32_t in_addr = slot_addr + lane * 8;
+    uint2 rows[8];
+    unsigned long long rr[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(rr[r]) : "v"(in_addr), "n"(r * 512) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]), "+v"(rr[4]), "+v"(rr[5]), "+v"(rr[6]), "+v"(rr[7])::"memory");
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      rows[r] = uint2{(uint32_t)rr[r], (uint32_t)(rr[r] >> 32)};
+    uint32_t q[64];
+    encode_block_avx_pk<false>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
+    // the output goes through the slot the input came from (asm again, for the same reason)
+    const uint32_t wr_addr = slot_addr + lane;
+#pragma unroll
+    for (int c = 0; c < 64; c++)
+      asm volatile("ds_write_b8 %0, %1 offset:%2" ::"v"(wr_addr), "v"(q[c]), "n"(c * kQ32RowStride) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t tile = tile0 + g * NC + w;
+    const gptr_t outw = sgpr_ptr(a.to + ((size_t)(a.by0 + row) * a.bpr + (size_t)tile * 64) * 64);
+    const uint32_t rd_addr = slot_addr + (lane & 31) * (2 * kQ32RowStride) + (lane >> 5) * 8;
+    unsigned long long lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo[k]) : "v"(rd_addr), "n"(k * 16) : "memory");
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi[k]) : "v"(rd_addr), "n"(k * 16 + kQ32RowStride) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])::"memory");
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      store16_g(outw + k * 1024 + lane * 16, ~u32x4_g{(uint32_t)lo[k], (uint32_t)(lo[k] >> 32), (uint32_t)hi[k], (uint32_t)(hi[k] >> 32)});
+  }
+}
+
 int main(int argc, char **argv)
 {
   const char *mode = argc > 1 ? argv[1] : "ab";
@@ -765,6 +852,11 @@ int main(int argc, char **argv)
   vs.push_back({"q32 tile (product kernel)", [&](int s) { hipLaunchKernelGGL(k_q32_tile, g64, dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"q32 tile, phase prio 6w", [&](int s) { hipLaunchKernelGGL((v_q32_tile_prio<6>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"q32 tile, phase prio 5w", [&](int s) { hipLaunchKernelGGL((v_q32_tile_prio<5>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"loader + 4 compute, 1 WG/row, 5w", [&](int s) { hipLaunchKernelGGL((v_loader<4, 5, 1>), dim3((unsigned)(H / 8)), dim3(320), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"loader + 4 compute, 2 WG/row, 5w", [&](int s) { hipLaunchKernelGGL((v_loader<4, 5, 2>), dim3((unsigned)(H / 8) * 2), dim3(320), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"loader + 2 compute, 2 WG/row, 6w", [&](int s) { hipLaunchKernelGGL((v_loader<2, 6, 2>), dim3((unsigned)(H / 8) * 2), dim3(192), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"loader + 2 compute, 4 WG/row, 6w", [&](int s) { hipLaunchKernelGGL((v_loader<2, 6, 4>), dim3((unsigned)(H / 8) * 4), dim3(192), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"loader + 1 compute, 4 WG/row, 6w", [&](int s) { hipLaunchKernelGGL((v_loader<1, 6, 4>), dim3((unsigned)(H / 8) * 4), dim3(128), 0, 0, args(s)); }, {}, true});
   vs.push_back({"tile: lds b8 (product)", [&](int s) { hipLaunchKernelGGL((v_ldscost<0>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"tile: no lds, 48 perm", [&](int s) { hipLaunchKernelGGL((v_ldscost<1>), g64, dim3(64), 0, 0, args(s)); }, {}, false});
   vs.push_back({"tile: no lds, no pack", [&](int s) { hipLaunchKernelGGL((v_ldscost<2>), g64, dim3(64), 0, 0, args(s)); }, {}, false});
