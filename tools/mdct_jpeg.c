@@ -3,7 +3,7 @@
  *
  *   mdct_jpeg out.jpg raw_grey_file X Y      X, Y multiples of 8
  *
- * pixels -> mdct_fwd_u8_records (Annex K.1 table) -> mdct_huffman_rows -> mdct_jpeg_pack_rows on the device; the host
+ * pixels -> mdct_fwd_u8_jpeg_scan (Annex K.1 table; ONE launch: transform, records, Huffman rows, stuffing, RSTm) on the device; the host
  * writes the marker segments (ITU-T T.81 B.2: SOI, APP0/JFIF, DQT, SOF0, DHT, DRI, SOS, EOI) around the packed scan.
  * Build: see the Makefile target `jpeg_example`. */
 #include <hip/hip_runtime_api.h>
@@ -73,19 +73,15 @@ int main(int argc, char **argv)
   fclose(in);
 
   MDCT_OK(mdct_init(0));
-  const size_t rows = H / 8, bpr = W / 8, nblk = rows * bpr, stride = mdct_huffman_seg_stride(W), cap = W * H / 2 + 4096;
-  uint8_t *d_px, *d_runs, *d_counts, *d_seg, *d_scan;
-  int16_t *d_levels;
-  uint32_t *d_seg_bytes;
-  uint64_t *d_off;
+  const size_t rows = H / 8, bpr = W / 8, stride = mdct_huffman_seg_stride(W), cap = W * H / 2 + 4096;
+  uint8_t *d_px, *d_seg, *d_scan;
+  uint64_t *d_off, *d_work;
   HIP_OK(hipMalloc((void **)&d_px, W * H));
-  HIP_OK(hipMalloc((void **)&d_levels, nblk * 128));
-  HIP_OK(hipMalloc((void **)&d_runs, nblk * 64));
-  HIP_OK(hipMalloc((void **)&d_counts, nblk));
-  HIP_OK(hipMalloc((void **)&d_seg, rows * stride));
-  HIP_OK(hipMalloc((void **)&d_seg_bytes, rows * sizeof(uint32_t)));
+  HIP_OK(hipMalloc((void **)&d_seg, rows * stride)); /* scratch: the rows' segments before they are stuffed and joined */
   HIP_OK(hipMalloc((void **)&d_scan, cap));
   HIP_OK(hipMalloc((void **)&d_off, (rows + 1) * sizeof(uint64_t)));
+  HIP_OK(hipMalloc((void **)&d_work, (rows + 2) * sizeof(uint64_t)));
+  HIP_OK(hipMemset(d_work, 0, (rows + 2) * sizeof(uint64_t))); /* once; every call leaves it ready for the next */
   HIP_OK(hipMemcpy(d_px, img, W * H, hipMemcpyHostToDevice));
 
   hipEvent_t t0, t1;
@@ -95,9 +91,7 @@ int main(int argc, char **argv)
   for (int rep = 0; rep < 3; rep++) /* the third pass is the one timed: the first pays the lazy module load */
   {
     HIP_OK(hipEventRecord(t0, 0));
-    MDCT_OK(mdct_fwd_u8_records(d_px, W, kLuma, /*level_shift*/ 1, W, H, 0, rows, d_levels, d_runs, d_counts, 0));
-    MDCT_OK(mdct_huffman_rows(d_levels, d_runs, d_counts, W, H, 0, rows, /*chroma*/ 0, d_seg, stride, d_seg_bytes, 0));
-    MDCT_OK(mdct_jpeg_pack_rows(d_seg, d_seg_bytes, stride, rows, 0, d_scan, cap, d_off, 0));
+    MDCT_OK(mdct_fwd_u8_jpeg_scan(d_px, W, kLuma, /*level_shift*/ 1, W, H, 0, rows, /*chroma*/ 0, d_seg, stride, d_work, /*first_rst*/ 0, d_scan, cap, d_off, 0));
     HIP_OK(hipEventRecord(t1, 0));
     HIP_OK(hipEventSynchronize(t1));
     HIP_OK(hipEventElapsedTime(&ms, t0, t1));
