@@ -396,7 +396,21 @@ def main():
             extras["huffman_rows"] = rate(lambda i: M.huffman_rows(lv, rn, ct, W, H, hseg, hnb), 3 * W * H + nblk, n=100, warm=200)
             extras["huffman_rows"]["pairs_per_block"] = round(float(ct.float().mean()), 1)
             extras["huffman_rows"]["bits_per_px"] = round(float(hnb.sum()) * 8 / (W * H), 3)
-            del lv, rn, ct, hseg, hnb
+            # pixels -> Huffman rows in ONE kernel (records only in LDS), and pixels -> finished scan (stuffed, RSTm) in one launch
+            hff = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
+            extras["px_to_huffman_rows_fused"] = rate(lambda i: M.fwd_u8_huffman_rows(u8s[i % NSETS], W, H, hseg, hnb, lut=q60, ff_counts=hff), W * H + int(hnb.sum()), n=100, warm=200)
+            extras["px_to_huffman_rows_fused"]["table"] = "QUANTIZE_BASE x 60 (the records above)"
+            k1 = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77,
+                           24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+            work = torch.zeros((H // 8 + 2,), dtype=torch.int64, device="cuda")
+            scan = torch.empty((W * H // 2,), dtype=torch.uint8, device="cuda")
+            off = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
+            M.fwd_u8_jpeg_scan(u8s[0], W, H, hseg, work, scan, off, lut=k1)
+            torch.cuda.synchronize()
+            nscan = int(off[-1].item())
+            extras["px_to_jpeg_scan_one_launch"] = rate(lambda i: M.fwd_u8_jpeg_scan(u8s[i % NSETS], W, H, hseg, work, scan, off, lut=k1), W * H + nscan, n=100, warm=200)
+            extras["px_to_jpeg_scan_one_launch"].update({"table": "ITU-T T.81 Annex K.1", "scan_bytes": nscan, "bits_per_px": round(nscan * 8 / (W * H), 3)})
+            del lv, rn, ct, hseg, hnb, hff, work, scan, off
         except Exception as e:
             extras["huffman_rows"] = {"error": str(e)[:120]}
 
@@ -445,10 +459,10 @@ def main():
                 line["roofline_u8"] = u8_block(extras["fwd_quant_u8_q32"], "k_q32_avx_bytes_per_launch")
             if "GBps" in extras.get("fwd_quant_u8_stereo_sse", {}):
                 line["roofline_stereo"] = u8_block(extras["fwd_quant_u8_stereo_sse"], "k_stereo_sse_bytes_per_launch")
-                line["roofline_stereo"]["scalar_tier"] = u8_block(extras.get("fwd_quant_u8_stereo_scalar"))
+                line["roofline_stereo"]["scalar_tier"] = u8_block(extras.get("fwd_quant_u8_stereo_scalar"), "k_stereo_scalar_bytes_per_launch")
             if "GBps" in extras.get("fwd_quant_u8_encq_sse", {}):
                 line["roofline_encq"] = u8_block(extras["fwd_quant_u8_encq_sse"], "k_encq_sse_bytes_per_launch")
-                line["roofline_encq"]["scalar_tier"] = u8_block(extras.get("fwd_quant_u8_encq_scalar"))
+                line["roofline_encq"]["scalar_tier"] = u8_block(extras.get("fwd_quant_u8_encq_scalar"), "k_encq_scalar_bytes_per_launch")
     # The optional whole-node leg runs AFTER the headline line is complete and under a watchdog: a collective that hangs
     # on some node must not cost the run its JSON line.  If the leg does not finish in time, rank 0 prints the line with
     # an error note in "allgather" and every rank exits.

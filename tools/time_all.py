@@ -85,6 +85,8 @@ hseg = [torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda") for
 hnb = [torch.empty((H // 8,), dtype=torch.int32, device="cuda") for _ in range(2)]
 pscan = torch.empty((W * H // 2,), dtype=torch.uint8, device="cuda")
 poff = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
+pwork = torch.zeros((H // 8 + 2,), dtype=torch.int64, device="cuda")  # the one-launch encoder's chain between the rows: zeroed once
+pff = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
 for i in range(2):
     M.huffman_rows(lv[i], rn[i], ct[i], W, H, hseg[i], hnb[i])
 cases += [
@@ -101,6 +103,8 @@ cases += [
     ("u8 px -> Huffman rows, ONE kernel, q60 table (1+0.2 B/px)", 1.22, W * H, [lambda i=i: M.fwd_u8_huffman_rows(u8[i], W, H, hseg[i % 2], hnb[i % 2], lut=Q60) for i in range(NS)]),
     ("u8 px -> Huffman rows, ONE kernel, Annex K.1 table", 1.15, W * H, [lambda i=i: M.fwd_u8_huffman_rows(u8[i], W, H, hseg[i % 2], hnb[i % 2], lut=K1) for i in range(NS)]),
     ("i16 plane -> Huffman rows, ONE kernel, Annex K.1 table", 2.15, W * H, [lambda i=i: M.fwd_i16_huffman_rows(i16[i], W, H, hseg[i % 2], hnb[i % 2], lut=K1) for i in range(NS)]),
+    ("u8 px -> finished JPEG scan, ONE launch, Annex K.1 table", 1.15, W * H, [lambda i=i: M.fwd_u8_jpeg_scan(u8[i], W, H, hseg[i % 2], pwork, pscan, poff, lut=K1) for i in range(NS)]),
+    ("  the same as two launches: fused kernel + counted pack", 1.15, W * H, [lambda i=i: (M.fwd_u8_huffman_rows(u8[i], W, H, hseg[i % 2], hnb[i % 2], lut=K1, ff_counts=pff), M.jpeg_pack_rows(hseg[i % 2], hnb[i % 2], hstride, H // 8, pscan, poff, ff_counts=pff)) for i in range(NS)]),
     ("4:2:0 split (3+3 B/px)", 6, W * H, [lambda i=i: M.split420_u8(ycc[i], W, H, sy[i], scb[i], scr[i]) for i in range(2)]),
 ]
 # config 4 on one GPU: 256 independent 4096x4096 int16 planes, forward only.  Blocks are
