@@ -1768,31 +1768,42 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
       aan_fwd_v(K, P[j]);
       if (j == 0)
         P[0][0].x = P[0][0].x - a.dc_shift; // the level shift is exactly "raw DC minus 64 * 128"
+      // the 8 multiplier pairs of column pair j, fetched here (all 64 multipliers held in SGPRs from the top of the kernel spilled)
+      karg_pairs_t tq = karg_pairs(offsetof(PxHuffArgs, tb) + offsetof(OwnTables, qf)) + j * 8;
+      asm volatile("" : "+s"(tq));
 #pragma unroll
       for (int v = 0; v < 8; v++)
       {
         f32x2 m;
-        MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[j * 8 + v], MDCT_K_LH);
+        MDCT_PKM(m, P[j][v], tq[v], MDCT_K_LH);
         const bool is_dc = j == 0 && v == 0;
-        val[v * 8 + kA[j]] = __float_as_uint(__builtin_amdgcn_fmed3f(m.x, is_dc ? -32768.0f : -1023.0f, is_dc ? 32767.0f : 1023.0f) + C.magic23);
-        val[v * 8 + kB[j]] = __float_as_uint(__builtin_amdgcn_fmed3f(m.y, -1023.0f, 1023.0f) + C.magic23);
+        f32x2 c = {__builtin_amdgcn_fmed3f(m.x, is_dc ? -32768.0f : -1023.0f, is_dc ? 32767.0f : 1023.0f), __builtin_amdgcn_fmed3f(m.y, -1023.0f, 1023.0f)};
+        MDCT_PKA(c, c, K.magic, MDCT_K_LL);
+        val[v * 8 + kA[j]] = __float_as_uint(c.x);
+        val[v * 8 + kB[j]] = __float_as_uint(c.y);
       }
     }
     // ---- zig-zag order; AC entries run << 12 | level compacted to the front of the lane's LDS row, a ZRL entry for every
-    // 16 zeros in a row (those after the last coefficient are dropped: n counts up to the last real one).  Zeros that
-    // need no entry write into slot 64.
-    uint32_t pos = 0, n = 0, run = 0;
+    // 16 zeros in a row.  EVERY coefficient writes run << 12 | level at the current position and only those that need an entry
+    // advance it: a zero's write is overwritten by the next entry -- unless it is the 16th zero in a row, and then what it
+    // wrote, 15 << 12 | 0, IS the ZRL entry.  (7 vector instructions per coefficient; selecting value and address per
+    // coefficient and tracking the last non-zero took 11.)
+    uint32_t pos = 0, r12 = 0;
 #pragma unroll
     for (int k = 1; k < 64; k++)
     {
-      const uint32_t l12 = val[kZigZag[k]] & 0xFFFu;
-      const bool nz = (val[kZigZag[k]] & 0xFFFFu) != 0;
-      const bool wr = nz || run == 15;
-      rec[wr ? pos : 64u] = (uint16_t)(nz ? (run << 12) | l12 : 0xF000u);
+      const uint32_t v = val[kZigZag[k]];
+      const bool nz = (v & 0xFFFFu) != 0;
+      const bool wr = nz || r12 == 0xF000u;
+      rec[pos] = (uint16_t)((v & 0xFFFu) | r12);
       pos += wr ? 1u : 0u;
-      n = nz ? pos : n;
-      run = wr ? 0u : run + 1u;
+      r12 = wr ? 0u : r12 + 0x1000u;
     }
+    // ZRL entries after the last coefficient are dropped (at most three: 62 zeros)
+    uint32_t n = pos;
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+      n -= (n > 0 && rec[n - 1] == 0xF000u) ? 1u : 0u;
     const int my_dc = (int)(int16_t)(val[0] & 0xFFFFu);
     const bool need_eob = (val[kZigZag[63]] & 0xFFFFu) == 0;
     if (c0 + kChunk < a.bpr)
