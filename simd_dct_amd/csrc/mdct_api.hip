@@ -509,7 +509,16 @@ static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const f
   a.dc_shift = level_shift ? 64.0f * 128.0f : 0.0f;
   mdct_huff_build(chroma ? 2 : 0, a.dc, 12);
   mdct_huff_build(chroma ? 3 : 1, a.ac, 256);
-  const hipError_t e = mdct::launch_px_huffman(a, i16_in, pack != nullptr, (uint32_t)(by1 - by0), (hipStream_t)stream);
+  // 8-bit pixels through a table with every entry >= 1.01: |AC level| <= 8 * 128 / 1.01 < 1023 and the DC fits int16 by far, the
+  // kernel's saturations can never fire (mdct_kernels.hip: CLAMP)
+  bool clamp = true;
+  if (!i16_in && lut)
+  {
+    clamp = false;
+    for (int i = 0; i < 64; i++)
+      clamp = clamp || !(fabsf(lut[i]) >= 1.01f);
+  }
+  const hipError_t e = mdct::launch_px_huffman(a, i16_in, pack != nullptr, clamp, (uint32_t)(by1 - by0), (hipStream_t)stream);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "pixels -> Huffman rows kernel launch");
 }
 

@@ -1672,9 +1672,12 @@ constexpr uint32_t kFusedRing = 1024; // words of bit stream held in LDS (2 bit/
 // PACK (4 waves): the finished row goes on into the contiguous scan in the same launch -- it publishes its stuffed length,
 // waits until the rows before it have published theirs (pack_rows.h: chain_*), and copies its own segment (still in L2)
 // to its place, stuffed and followed by its restart marker: pixels -> decodable scan, one kernel.
-template <bool I16_IN, int WAVES, bool PACK = false>
+// CLAMP = false (8-bit pixels and a table whose entries are all >= 1.01, decided on the host): no level can leave +-1023 -- an AC
+// coefficient of 8-bit pixels is at most 8 * 128 in magnitude, the DC 8 * 255 -- so the 64 saturations per block are left out.
+template <bool I16_IN, int WAVES, bool PACK = false, bool CLAMP = true>
 __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
 {
+  static_assert(CLAMP || !I16_IN, "an int16 plane can hold anything");
   static_assert(!PACK || WAVES == 4, "the packing tail is written for 256 threads");
   __shared__ uint32_t ac[256], dc[12];
   __shared__ __attribute__((aligned(16))) uint16_t rec_all[WAVES][64 * kRec16Row]; // PACK: later the staging buffer of the copy
@@ -1777,7 +1780,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
         f32x2 m;
         MDCT_PKM(m, P[j][v], tq[v], MDCT_K_LH);
         const bool is_dc = j == 0 && v == 0;
-        f32x2 c = {__builtin_amdgcn_fmed3f(m.x, is_dc ? -32768.0f : -1023.0f, is_dc ? 32767.0f : 1023.0f), __builtin_amdgcn_fmed3f(m.y, -1023.0f, 1023.0f)};
+        f32x2 c = m;
+        if constexpr (CLAMP)
+          c = f32x2{__builtin_amdgcn_fmed3f(m.x, is_dc ? -32768.0f : -1023.0f, is_dc ? 32767.0f : 1023.0f), __builtin_amdgcn_fmed3f(m.y, -1023.0f, 1023.0f)};
         MDCT_PKA(c, c, K.magic, MDCT_K_LL);
         val[v * 8 + kA[j]] = __float_as_uint(c.x);
         val[v * 8 + kB[j]] = __float_as_uint(c.y);
@@ -2254,42 +2259,34 @@ hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s)
   return hipGetLastError();
 }
 
-// waves per workgroup (= per block row): 4 by default; MDCT_FUSED_HUFF_WAVES=2 / 8 in the environment selects the 2- / 8-wave
-// builds (chunks of 128 / 512 blocks) for A/B runs
-hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, uint32_t n_rows, hipStream_t s)
+// 4 waves per workgroup (= per block row); 2- and 8-wave builds (chunks of 128 / 512 blocks) measured 125 / 126 us against 100
+// (profiles/r03_d_time_all_entry_points.log) and are not kept
+hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, bool clamp, uint32_t n_rows, hipStream_t s)
 {
   if (n_rows == 0)
     return hipSuccess;
-  static const int waves = [] {
-    const char *e = getenv("MDCT_FUSED_HUFF_WAVES");
-    const int w = e ? atoi(e) : 4;
-    return w == 2 || w == 8 ? w : 4;
-  }();
-  if (pack)
+  const dim3 grid(n_rows), wg(256);
+  if (i16_in)
   {
-    if (i16_in)
-      hipLaunchKernelGGL((k_px_huffman_rows<true, 4, true>), dim3(n_rows), dim3(256), 0, s, a);
+    if (pack)
+      hipLaunchKernelGGL((k_px_huffman_rows<true, 4, true>), grid, wg, 0, s, a);
     else
-      hipLaunchKernelGGL((k_px_huffman_rows<false, 4, true>), dim3(n_rows), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((k_px_huffman_rows<true, 4, false>), grid, wg, 0, s, a);
   }
-  else if (waves == 2)
+  else if (clamp)
   {
-    if (i16_in)
-      hipLaunchKernelGGL((k_px_huffman_rows<true, 2>), dim3(n_rows), dim3(128), 0, s, a);
+    if (pack)
+      hipLaunchKernelGGL((k_px_huffman_rows<false, 4, true>), grid, wg, 0, s, a);
     else
-      hipLaunchKernelGGL((k_px_huffman_rows<false, 2>), dim3(n_rows), dim3(128), 0, s, a);
+      hipLaunchKernelGGL((k_px_huffman_rows<false, 4, false>), grid, wg, 0, s, a);
   }
-  else if (waves == 8)
-  {
-    if (i16_in)
-      hipLaunchKernelGGL((k_px_huffman_rows<true, 8>), dim3(n_rows), dim3(512), 0, s, a);
-    else
-      hipLaunchKernelGGL((k_px_huffman_rows<false, 8>), dim3(n_rows), dim3(512), 0, s, a);
-  }
-  else if (i16_in)
-    hipLaunchKernelGGL((k_px_huffman_rows<true, 4>), dim3(n_rows), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((k_px_huffman_rows<false, 4>), dim3(n_rows), dim3(256), 0, s, a);
+  {
+    if (pack)
+      hipLaunchKernelGGL((k_px_huffman_rows<false, 4, true, false>), grid, wg, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_px_huffman_rows<false, 4, false, false>), grid, wg, 0, s, a);
+  }
   return hipGetLastError();
 }
 

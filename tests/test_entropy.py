@@ -241,6 +241,36 @@ def test_fused_pixels_to_huffman_rows_equals_the_staged_path_and_the_checker():
                 assert np.array_equal(nbb.astype(np.uint32), want_nb), (W, H, kind)
                 for r in range(H // 8):
                     assert np.array_equal(gb[r * stride:r * stride + want_nb[r]], want_seg[r * stride:r * stride + want_nb[r]]), (W, H, kind, r)
+    # the largest coefficients 8-bit pixels can produce -- block (u, v) is the sign pattern of basis function (u, v), 0 / 255 -- through the
+    # smallest table for which the fused kernel leaves its saturations out (every entry 1.01): still the staged path's bytes, with and
+    # without the level shift, and through a table just below the threshold (which keeps them)
+    xs = np.arange(8)
+    cosm = np.cos((2 * xs[None, :] + 1) * xs[:, None] * np.pi / 16)  # [u][x]
+    worst = np.zeros((16, 512), dtype=np.uint8)
+    for u in range(8):
+        for v in range(8):
+            blk = np.where(np.outer(cosm[v], cosm[u]) > 0, 255, 0).astype(np.uint8)  # [y][x]
+            worst[0:8, (u * 8 + v) * 8:(u * 8 + v) * 8 + 8] = blk
+            worst[8:16, (u * 8 + v) * 8:(u * 8 + v) * 8 + 8] = 255 - blk
+    W, H = 512, 16
+    stride = api.huffman_seg_stride(W)
+    nblk = (W // 8) * (H // 8)
+    d_w = _dev(worst)
+    for q, shift in ((np.full(64, 1.01, dtype=np.float32), True), (np.full(64, 1.01, dtype=np.float32), False), (np.full(64, 1.0, dtype=np.float32), True),
+                     (np.where(np.arange(64) == 37, 1.0, 1.01).astype(np.float32), True)):
+        lv = torch.zeros((nblk, 64), dtype=torch.int16, device="cuda")
+        rn = torch.zeros((nblk, 64), dtype=torch.uint8, device="cuda")
+        ct = torch.zeros((nblk,), dtype=torch.uint8, device="cuda")
+        api.fwd_u8_records(d_w, W, H, lv, rn, ct, lut=q, level_shift=shift)
+        assert int(lv[:, 1:].abs().max().item()) >= 1000  # the pattern does reach the edge of the AC range
+        seg_a = torch.full(((H // 8) * stride,), 0x5A, dtype=torch.uint8, device="cuda")
+        nb_a = torch.zeros((H // 8,), dtype=torch.int32, device="cuda")
+        api.huffman_rows(lv, rn, ct, W, H, seg_a, nb_a)
+        seg_b = torch.full(((H // 8) * stride,), 0x5A, dtype=torch.uint8, device="cuda")
+        nb_b = torch.zeros((H // 8,), dtype=torch.int32, device="cuda")
+        api.fwd_u8_huffman_rows(d_w, W, H, seg_b, nb_b, lut=q, level_shift=shift)
+        torch.cuda.synchronize()
+        assert torch.equal(nb_a, nb_b) and torch.equal(seg_a, seg_b), (float(q.min()), shift)
     # an int16 plane as input (the chroma planes of mdct_split420_u8), a pitched plane, a sub-range that leaves the other rows alone
     W, H, pitch = 1032, 48, 1040
     s16 = np.zeros((H, pitch), dtype=np.int16)

@@ -24,7 +24,7 @@ for name, q in (("q60", Q60), ("K.1", K1)):
         t.stop()
         best.append(t.elapsed_ms() / 40)
     best.sort()
-    print(f"waves {os.environ.get('MDCT_FUSED_HUFF_WAVES', '4')}: fused px -> Huffman rows, {name}: {best[2] * 1e3:.1f} us")
+    print(f"fused px -> Huffman rows, {name}: {best[2] * 1e3:.1f} us")
 # the packing of the K.1 rows just written: counted (one launch unless MDCT_PACK_SCAN_KERNEL is set) and uncounted (three launches)
 scan = torch.empty((W * H // 2,), dtype=torch.uint8, device="cuda")
 off = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
