@@ -184,6 +184,18 @@ int make_own_tables(const float *lut, mdct::OwnTables &tb, bool pair_order = fal
   return MDCT_SUCCESS;
 }
 
+// every entry >= 8.01 in magnitude: |orthonormal 8x8 DCT coefficient of int16 samples| <= 8 * 32768, so coefficient / entry stays inside
+// int16 with ~40 units to spare for the rounding of the float pipeline (mdct_kernels.hip: i16_roundtrip_rows<.., SAT = false>)
+static bool lut_bounded(const float *lut)
+{
+  if (!lut)
+    return false;
+  for (int i = 0; i < 64; i++)
+    if (!(fabsf(lut[i]) >= 8.01f))
+      return false;
+  return true;
+}
+
 int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
 {
   // arguments first (like the reference's dispatchers), device second
@@ -204,7 +216,7 @@ int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t 
     return r;
   if ((r = make_own_tables(lut, a.tb, mode == mdct::MODE_ROUNDTRIP)))
     return r;
-  const hipError_t e = mdct::launch_i16(a, mode, lut != nullptr, (hipStream_t)stream);
+  const hipError_t e = mdct::launch_i16(a, mode, lut != nullptr, (hipStream_t)stream, lut_bounded(lut));
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "i16 kernel launch");
 }
 
@@ -590,6 +602,7 @@ int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *
     a.consts = mdct::DctConsts();
     a.n = n_planes - base < mdct::kMaxPlanes ? n_planes - base : mdct::kMaxPlanes;
     uint64_t run = 0;
+    bool all_bounded = true; // every plane has a table whose entries are all >= 8.01
     for (int i = 0; i < a.n; i++)
     {
       const mdct_plane_i16 &p = planes[base + i];
@@ -605,11 +618,12 @@ int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *
       if (run > 0x7FFFFFFFull)
         return fail(MDCT_NOT_SUPPORTED, "plane batch exceeds the 2^31 block limit");
       a.has_lut[i] = p.lut != nullptr;
+      all_bounded = all_bounded && lut_bounded(p.lut);
       if ((r = make_own_tables(p.lut, a.tb[i], true)))
         return r;
     }
     a.prefix[a.n] = (uint32_t)run;
-    const hipError_t e = mdct::launch_i16_planes(a, (hipStream_t)stream);
+    const hipError_t e = mdct::launch_i16_planes(a, (hipStream_t)stream, all_bounded);
     if (e != hipSuccess)
       return hip_fail(e, "plane batch launch");
   }

@@ -168,8 +168,9 @@ struct PlaneBatchArgs
 };
 
 hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool safe, hipStream_t s);
-hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s);
-hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s);
+// lut_bounded / luts_bounded: every entry of every table >= 8.01 in magnitude (a quantised coefficient cannot leave int16)
+hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s, bool lut_bounded = false);
+hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s, bool luts_bounded = false);
 hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s);
 hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s);
 hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, bool clamp, uint32_t n_rows, hipStream_t s);

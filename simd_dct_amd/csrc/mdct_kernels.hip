@@ -1385,7 +1385,9 @@ __device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, 
 // produces and aan_inv_h consumes (mdct_api.hip: make_own_tables).
 // PRIO: the wave raises its issue priority as it advances (forward rows 1, columns 2, inverse rows + stores 3), so that of
 // the waves sharing a SIMD the one closest to its stores goes first (shortest remaining work first)
-template <bool HAS_LUT, class Rows, bool PRIO = false>
+// SAT = false (decided on the host: every table entry >= 8.01): a quantised coefficient cannot leave int16 -- an orthonormal 8x8
+// DCT coefficient of int16 samples is at most 8 * 32768 in magnitude -- so the two saturations per coefficient pair are left out.
+template <bool HAS_LUT, class Rows, bool PRIO = false, bool SAT = true>
 __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, size_t tb_off);
 
 // tb_off: where the plane's OwnTables lie in the kernel's argument segment
@@ -1405,7 +1407,7 @@ __device__ __forceinline__ karg_pairs_t karg_pairs(size_t byte_off)
   return (karg_pairs_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + byte_off);
 }
 
-template <bool HAS_LUT, class Rows, bool PRIO>
+template <bool HAS_LUT, class Rows, bool PRIO, bool SAT>
 __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, size_t tb_off)
 {
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
@@ -1439,8 +1441,11 @@ __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Row
         const f32x2 qf = tq[v], dq = td[v];
         f32x2 m;
         MDCT_PKM(m, P[j][v], qf, MDCT_K_LH);
-        m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
-        m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
+        if constexpr (SAT)
+        {
+          m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
+          m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
+        }
         MDCT_PKA(m, m, K.magic, MDCT_K_LL);
         MDCT_PKA(m, m, K.magic, MDCT_K_LL " " MDCT_NEG_B);
         MDCT_PKM(P[j][v], m, dq, MDCT_K_LH);
@@ -1478,7 +1483,7 @@ __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Row
 // 47.4 us with 3 (48.3 with 4, 51.5 with 2).  Left to itself the compiler sometimes serialises the eight row loads
 // behind the butterflies (58 vs 49 us on identical work, tools/time_planes.py).
 constexpr int i16_waves(int mode) { return mode == MODE_ROUNDTRIP ? 3 : (mode == MODE_FWD ? 2 : 4); }
-template <int MODE, bool HAS_LUT>
+template <int MODE, bool HAS_LUT, bool SAT = true>
 __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(MODE), i16_waves(MODE)))) void k_i16(I16Args a)
 {
   const uint32_t t = wg_index() * kWG + threadIdx.x;
@@ -1490,7 +1495,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
   const int16_t *src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
   int16_t *dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
   if constexpr (MODE == MODE_ROUNDTRIP)
-    i16_roundtrip_pk<HAS_LUT>(a.consts, src, dst, a.pitch_in, a.pitch_out, offsetof(I16Args, tb));
+    i16_roundtrip_rows<HAS_LUT, RowsLinear, false, SAT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, offsetof(I16Args, tb));
   else
     i16_block<MODE, HAS_LUT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, a.tb);
 }
@@ -1504,13 +1509,13 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
 // fused round trip with phase priorities 44.3 with 2, 44.7 with 3, 45.9 with 4 (without priorities 48.4 / 45.8 / 46.0;
 // k_i16<ROUNDTRIP> 47.1-48.6)
 constexpr int i16_tile_waves(int, bool) { return 2; }
-template <int MODE, bool HAS_LUT>
+template <int MODE, bool HAS_LUT, bool SAT = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(i16_tile_waves(MODE, HAS_LUT), i16_tile_waves(MODE, HAS_LUT)))) void k_i16_tile(I16Args a)
 {
   const size_t by = a.by0 + blockIdx.y;
   const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
   if constexpr (MODE == MODE_ROUNDTRIP)
-    i16_roundtrip_rows<HAS_LUT, RowsTiled, true>(a.consts, rows, offsetof(I16Args, tb)); // with phase priorities
+    i16_roundtrip_rows<HAS_LUT, RowsTiled, true, SAT>(a.consts, rows, offsetof(I16Args, tb)); // with phase priorities
   else
     i16_block<MODE, HAS_LUT>(a.consts, rows, a.tb);
 }
@@ -1875,7 +1880,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
 #ifndef MDCT_PLANES_WAVES
 #define MDCT_PLANES_WAVES 3
 #endif
-template <int LUTMODE, int WG = kWG, int WAVES = MDCT_PLANES_WAVES, bool PRIO = false>
+template <int LUTMODE, int WG = kWG, int WAVES = MDCT_PLANES_WAVES, bool PRIO = false, bool SAT = true>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_i16_planes(PlaneBatchArgs a)
 {
   const uint32_t t = blockIdx.x * WG + threadIdx.x;
@@ -1903,10 +1908,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     // s_load_dwordx2 with a wait each (41.6-45 us instead of 36-38 on the 4:2:0 frame, profiles/r02_planes_waves.log).
     switch (p)
     {
-    case 0: i16_roundtrip_rows<true, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 0 * sizeof(OwnTables)); break;
-    case 1: i16_roundtrip_rows<true, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 1 * sizeof(OwnTables)); break;
-    case 2: i16_roundtrip_rows<true, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 2 * sizeof(OwnTables)); break;
-    default: i16_roundtrip_rows<true, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 3 * sizeof(OwnTables)); break;
+    case 0: i16_roundtrip_rows<true, RowsLinear, PRIO, SAT>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 0 * sizeof(OwnTables)); break;
+    case 1: i16_roundtrip_rows<true, RowsLinear, PRIO, SAT>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 1 * sizeof(OwnTables)); break;
+    case 2: i16_roundtrip_rows<true, RowsLinear, PRIO, SAT>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 2 * sizeof(OwnTables)); break;
+    default: i16_roundtrip_rows<true, RowsLinear, PRIO, SAT>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 3 * sizeof(OwnTables)); break;
     }
   }
   else
@@ -2179,51 +2184,58 @@ hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool sa
 #define MDCT_I16_TILED 1
 #endif
 template <int MODE>
-static hipError_t launch_i16_m(const I16Args &a, bool has_lut, hipStream_t s)
+static hipError_t launch_i16_m(const I16Args &a, bool has_lut, bool lut_bounded, hipStream_t s)
 {
   const uint32_t launch_rows = a.nblocks / a.bpr;
+  constexpr bool RT = MODE == MODE_ROUNDTRIP; // the only mode with a build without saturations
   if (MDCT_I16_TILED && a.bpr % 64 == 0 && launch_rows <= 65535u)
   {
     const dim3 g(a.bpr / 64, launch_rows);
-    if (has_lut)
+    if (has_lut && RT && lut_bounded)
+      hipLaunchKernelGGL((k_i16_tile<MODE, true, !RT>), g, dim3(64), 0, s, a);
+    else if (has_lut)
       hipLaunchKernelGGL((k_i16_tile<MODE, true>), g, dim3(64), 0, s, a);
     else
       hipLaunchKernelGGL((k_i16_tile<MODE, false>), g, dim3(64), 0, s, a);
     return hipGetLastError();
   }
-  if (has_lut)
+  if (has_lut && RT && lut_bounded)
+    hipLaunchKernelGGL((k_i16<MODE, true, !RT>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
+  else if (has_lut)
     hipLaunchKernelGGL((k_i16<MODE, true>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
   else
     hipLaunchKernelGGL((k_i16<MODE, false>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s)
+hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s, bool lut_bounded)
 {
   if (a.nblocks == 0)
     return hipSuccess;
   switch (mode)
   {
-  case MODE_FWD: return launch_i16_m<MODE_FWD>(a, has_lut, s);
-  case MODE_INV: return launch_i16_m<MODE_INV>(a, has_lut, s);
-  case MODE_ROUNDTRIP: return launch_i16_m<MODE_ROUNDTRIP>(a, has_lut, s);
+  case MODE_FWD: return launch_i16_m<MODE_FWD>(a, has_lut, lut_bounded, s);
+  case MODE_INV: return launch_i16_m<MODE_INV>(a, has_lut, lut_bounded, s);
+  case MODE_ROUNDTRIP: return launch_i16_m<MODE_ROUNDTRIP>(a, has_lut, lut_bounded, s);
   }
   return hipErrorInvalidValue;
 }
 
 template <int WG, int WAVES, bool PRIO>
-static void launch_i16_planes_v(const PlaneBatchArgs &a, int with, uint32_t total, hipStream_t s)
+static void launch_i16_planes_v(const PlaneBatchArgs &a, int with, uint32_t total, bool luts_bounded, hipStream_t s)
 {
   const dim3 grid((total + WG - 1) / WG), wg(WG);
   if (with == 0)
     hipLaunchKernelGGL((k_i16_planes<0, WG, WAVES, PRIO>), grid, wg, 0, s, a);
+  else if (with == a.n && luts_bounded)
+    hipLaunchKernelGGL((k_i16_planes<1, WG, WAVES, PRIO, false>), grid, wg, 0, s, a);
   else if (with == a.n)
     hipLaunchKernelGGL((k_i16_planes<1, WG, WAVES, PRIO>), grid, wg, 0, s, a);
   else
     hipLaunchKernelGGL((k_i16_planes<2, WG, WAVES, PRIO>), grid, wg, 0, s, a);
 }
 
-hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s)
+hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s, bool luts_bounded)
 {
   const uint32_t total = a.prefix[a.n];
   if (total == 0)
@@ -2233,7 +2245,7 @@ hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s)
     with += a.has_lut[i] ? 1 : 0;
   // one-wave workgroups, 3 waves per SIMD, no phase priorities: the best of seven combinations by 1-2 % on the single 8192^2
   // plane and on the 8K 4:2:0 frame (64 / 256 threads x 2 / 3 waves x priorities on / off, profiles/r03_exp_planes_variants.log)
-  launch_i16_planes_v<64, 3, false>(a, with, total, s);
+  launch_i16_planes_v<64, 3, false>(a, with, total, luts_bounded, s);
   return hipGetLastError();
 }
 

@@ -205,6 +205,33 @@ def test_i16_saturation_pitch_and_ranges():
         assert np.array_equal(out.cpu().numpy(), want), mode
 
 
+def test_i16_roundtrip_without_saturations_at_the_edge_of_its_bound():
+    """Tables with every entry >= 8.01 take the round-trip build that leaves the int16 saturation of the quantised coefficient out (it
+    cannot fire: |coefficient| <= 8 * 32768).  The largest coefficients int16 samples can produce -- block (u, v) = the sign pattern of
+    basis function (u, v) at -32768 / 32767 -- through 8.01 (no saturations), 8.0 (keeps them) and a mixed table: the oracle's values,
+    in the tile kernel (512-wide), the linear kernel and the plane batch"""
+    xs = np.arange(8)
+    cosm = np.cos((2 * xs[None, :] + 1) * xs[:, None] * np.pi / 16)
+    worst = np.zeros((16, 512), dtype=np.int16)
+    for u in range(8):
+        for v in range(8):
+            blk = np.where(np.outer(cosm[v], cosm[u]) > 0, 32767, -32768).astype(np.int16)
+            worst[0:8, (u * 8 + v) * 8:(u * 8 + v) * 8 + 8] = blk
+            worst[8:16, (u * 8 + v) * 8:(u * 8 + v) * 8 + 8] = -1 - blk
+    for q in (np.full(64, 8.01, dtype=np.float32), np.full(64, 8.0, dtype=np.float32), np.where(np.arange(64) % 5 == 0, 7.9, 8.5).astype(np.float32), np.full(64, 100.0, dtype=np.float32)):
+        for W, src in ((512, worst), (256, np.ascontiguousarray(worst[:, :256])), (200, np.ascontiguousarray(worst[:, 56:256]))):
+            want = O.i16("roundtrip", src, W, 16, lut=q)
+            coef = O.i16("fwd", src, W, 16, lut=q)
+            if W == 512 and q[0] <= 8.01:
+                assert int(np.abs(coef.astype(np.int64)).max()) >= 32700  # the pattern does reach the edge of int16
+            out = torch.full((16, W), 77, dtype=torch.int16, device="cuda")
+            M.roundtrip_i16(dev(src), out, W, 16, lut=q)
+            assert np.array_equal(out.cpu().numpy(), want), (float(q.min()), W)
+            out2 = torch.full((16, W), 77, dtype=torch.int16, device="cuda")
+            M.roundtrip_i16_planes([(dev(src), out2, W, 16, q)])
+            assert np.array_equal(out2.cpu().numpy(), want), (float(q.min()), W, "planes")
+
+
 def test_f32_matches_oracle_and_double():
     # widths % 512 == 0 take the kernel's wide-load form (lane pairs swap half rows), the others the plain form
     for (W, H) in ((8, 8), (256, 64), (1000, 24), (512, 16), (1024, 40), (1536, 8)):
