@@ -594,8 +594,14 @@ __device__ __forceinline__ void load_block_rows(const uint8_t *src, size_t pitch
 // the stored byte is its complement.  The complement is applied to whole dwords after the LDS
 // reorder (4 v_not per lane instead of 64 integer adds).
 constexpr int kPairA[4] = {0, 2, 1, 5}, kPairB[4] = {4, 6, 3, 7};
-template <bool SAFE, bool PRIO = false>
-__device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uint2 (&rows)[8], const QuantTable &qt, uint32_t (&out)[64])
+struct NoHook
+{
+  __device__ __forceinline__ void operator()() const {}
+};
+// after_rows: called between the row pass and the column pass, when the 16 registers of `rows` are dead (a caller that works on
+// several tiles issues the next tile's loads there)
+template <bool SAFE, bool PRIO = false, class AfterRows = NoHook>
+__device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uint2 (&rows)[8], const QuantTable &qt, uint32_t (&out)[64], AfterRows after_rows = AfterRows())
 {
   MDCT_PHASE_PRIO(1);
   f32x2 col[4][8]; // col[j][r] = (B[r][kPairA[j]], B[r][kPairB[j]]) after the row pass
@@ -608,6 +614,7 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
     const f32x2 a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
     dct8_h<K_AVX>(K, a01, a23, a45, a67, col[0][r], col[1][r], col[2][r], col[3][r]);
   }
+  after_rows();
   MDCT_PHASE_PRIO(2);
 #pragma unroll
   for (int j = 0; j < 4; j++)

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const size_t by = a.by0 + row;
   const int16_t *src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
   int16_t *dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
-  i16_roundtrip_pk<false>(a.consts, src, dst, a.pitch_in, a.pitch_out, a.tb);
+  i16_roundtrip_pk<false>(a.consts, src, dst, a.pitch_in, a.pitch_out, 0);
   STAMP(3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   STAMP(4);
@@ -377,14 +377,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 {
   const size_t by = a.by0 + blockIdx.y;
   const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
-  i16_roundtrip_rows<false>(a.consts, rows, a.tb);
+  i16_roundtrip_rows<false>(a.consts, rows, 0);
 }
 template <int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void v_i16_tile_prio(I16Args a)
 {
   const size_t by = a.by0 + blockIdx.y;
   const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
-  i16_roundtrip_rows<false, RowsTiled, true>(a.consts, rows, a.tb);
+  i16_roundtrip_rows<false, RowsTiled, true>(a.consts, rows, 0);
 }
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void v_i16_tile_mode(I16Args a)
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
   const size_t by = a.by0 + blockIdx.y;
   const uint32_t tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)tile * 512, a.to + by * 8 * a.pitch_out + (size_t)tile * 512, a.pitch_in, a.pitch_out, (threadIdx.x & 63) * 16};
-  i16_roundtrip_rows<false>(a.consts, rows, a.tb);
+  i16_roundtrip_rows<false>(a.consts, rows, 0);
 }
 
 template <int MODE, int WAVES>
@@ -473,6 +473,51 @@ __global__ __launch_bounds__(64, MINW) void v_stereo_wave(U8Args a)
     typedef unsigned int u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
     const u32x4_unaligned w = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(w, reinterpret_cast<u32x4_unaligned *>(a.to + a.plane_stride * c + pos0 + part * 16));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// k_q32_tile over NT consecutive tiles of a block row per wave, the next tile's eight row loads issued between the row pass and
+// the column pass of the current one (the 16 registers of the raw rows are dead by then: no extra register pressure): every
+// wave after its first tile finds its rows waiting -- in-wave prefetch on top of the 6 waves per SIMD.
+// ---------------------------------------------------------------------------------------
+template <int NT, int MINW>
+__global__ __launch_bounds__(64, MINW) void v_tiles(U8Args a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t wl[64 * kQ32RowStride];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tile0 = blockIdx.x * NT, row = blockIdx.y;
+  const uint8_t *src = a.from + (size_t)(a.by0 + row) * 8 * a.pitch + (size_t)tile0 * 512;
+  uint2 rows[8], nxt[8];
+  load_block_rows_g(src, a.pitch, lane * 8, rows);
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+  {
+    uint32_t q[64];
+    if (t + 1 < NT)
+      encode_block_avx_pk<false>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q, [&]() { load_block_rows_g(src + (size_t)(t + 1) * 512, a.pitch, lane * 8, nxt); });
+    else
+      encode_block_avx_pk<false>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
+#pragma unroll
+    for (int c = 0; c < 64; c++)
+      wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const gptr_t outw = sgpr_ptr(a.to + ((size_t)(a.by0 + row) * a.bpr + (size_t)(tile0 + t) * 64) * 64);
+    const uint32_t rd = (lane & 31) * (2 * kQ32RowStride) + (lane >> 5) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+      const uint2 lo = *reinterpret_cast<const uint2 *>(wl + rd + k * 16);
+      const uint2 hi = *reinterpret_cast<const uint2 *>(wl + rd + k * 16 + kQ32RowStride);
+      store16_g(outw + k * 1024 + lane * 16, ~u32x4_g{lo.x, lo.y, hi.x, hi.y});
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier(); // the staging buffer is read before the next tile overwrites it
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      rows[r] = nxt[r];
   }
 }
 
@@ -852,6 +897,11 @@ int main(int argc, char **argv)
   vs.push_back({"q32 tile (product kernel)", [&](int s) { hipLaunchKernelGGL(k_q32_tile, g64, dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"q32 tile, phase prio 6w", [&](int s) { hipLaunchKernelGGL((v_q32_tile_prio<6>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"q32 tile, phase prio 5w", [&](int s) { hipLaunchKernelGGL((v_q32_tile_prio<5>), g64, dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"2 tiles per wave, prefetch, 6w", [&](int s) { hipLaunchKernelGGL((v_tiles<2, 6>), dim3((unsigned)(a.bpr / 128), (unsigned)(H / 8)), dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"2 tiles per wave, prefetch, 5w", [&](int s) { hipLaunchKernelGGL((v_tiles<2, 5>), dim3((unsigned)(a.bpr / 128), (unsigned)(H / 8)), dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"4 tiles per wave, prefetch, 6w", [&](int s) { hipLaunchKernelGGL((v_tiles<4, 6>), dim3((unsigned)(a.bpr / 256), (unsigned)(H / 8)), dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"4 tiles per wave, prefetch, 5w", [&](int s) { hipLaunchKernelGGL((v_tiles<4, 5>), dim3((unsigned)(a.bpr / 256), (unsigned)(H / 8)), dim3(64), 0, 0, args(s)); }, {}, true});
+  vs.push_back({"16 tiles per wave (a row), 6w", [&](int s) { hipLaunchKernelGGL((v_tiles<16, 6>), dim3((unsigned)(a.bpr / 1024), (unsigned)(H / 8)), dim3(64), 0, 0, args(s)); }, {}, true});
   vs.push_back({"loader + 4 compute, 1 WG/row, 5w", [&](int s) { hipLaunchKernelGGL((v_loader<4, 5, 1>), dim3((unsigned)(H / 8)), dim3(320), 0, 0, args(s)); }, {}, true});
   vs.push_back({"loader + 4 compute, 2 WG/row, 5w", [&](int s) { hipLaunchKernelGGL((v_loader<4, 5, 2>), dim3((unsigned)(H / 8) * 2), dim3(320), 0, 0, args(s)); }, {}, true});
   vs.push_back({"loader + 2 compute, 2 WG/row, 6w", [&](int s) { hipLaunchKernelGGL((v_loader<2, 6, 2>), dim3((unsigned)(H / 8) * 2), dim3(192), 0, 0, args(s)); }, {}, true});
