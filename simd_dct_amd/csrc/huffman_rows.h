@@ -153,6 +153,7 @@ struct HuffRowCoder
     }
     if (lane == 63)
       tot[par][wave] = incl;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (explicit, see the window loop below)
     __syncthreads(); // also: every wave has flushed (and cleared) the previous chunk's words
     uint32_t wave_start = 0, chunk_bits = 0, lane0_len = 0;
 #pragma unroll
@@ -183,7 +184,13 @@ struct HuffRowCoder
     for (uint32_t win = w_first; win <= w_end; win += kHuffRing)
     {
       if (win != w_first)
-        __syncthreads(); // the previous window's slots are cleared
+      { // the previous window's slots are cleared -- and the clearing ds_writes have LANDED: the compiler emits this barrier without
+        // the s_waitcnt lgkmcnt(0) every other barrier of the kernel gets (ISA, ROCm 7.2), and a clear that is still queued when
+        // another SIMD's wave passes the barrier overtakes that wave's ds_or: one row in ~10^5 of those that need several windows
+        // lost bits of a word (tools/soak_jpeg_scan.py)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       if (live)
       {
         const uint32_t cur = base_bits + wave_start + (incl - bits) + (lane ? lane0_len : 0u); // bit position in the row
@@ -341,6 +348,7 @@ struct HuffRowCoder16
     }
     if (lane == 63)
       tot[par][wave] = incl;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (explicit, see the window loop below)
     __syncthreads(); // also: every wave has flushed (and cleared) the previous chunk's words
     uint32_t wave_start = 0, chunk_bits = 0, lane0_len = 0;
 #pragma unroll
@@ -365,7 +373,13 @@ struct HuffRowCoder16
     for (uint32_t win = w_first; win <= w_end; win += RING)
     {
       if (win != w_first)
-        __syncthreads(); // the previous window's slots are cleared
+      { // the previous window's slots are cleared -- and the clearing ds_writes have LANDED: the compiler emits this barrier without
+        // the s_waitcnt lgkmcnt(0) every other barrier of the kernel gets (ISA, ROCm 7.2), and a clear that is still queued when
+        // another SIMD's wave passes the barrier overtakes that wave's ds_or: one row in ~10^5 of those that need several windows
+        // lost bits of a word (tools/soak_jpeg_scan.py)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       if (live)
       {
         const uint32_t cur = base_bits + wave_start + (incl - bits) + (lane ? lane0_len : 0u);

@@ -485,6 +485,55 @@ def test_one_launch_pixels_to_scan_equals_the_two_launch_path():
     assert api.fwd_u8_jpeg_scan(d_img, 8, 8, seg_w, work[1:].view(torch.uint8)[4:], got, off, check=False) == 1
 
 
+@pytest.mark.gpu
+def test_dense_rows_that_need_several_ring_windows_code_the_same_bytes_every_time():
+    """Rows whose code does not fit the coder's LDS ring at once go through it in windows; between two windows the slots are cleared and
+    OR-ed into again.  The barrier between them once came out of the compiler without its LDS wait, and under the LDS traffic of the
+    one-launch encoder (other rows of the CU copying their segments) a clear still in flight overtook the next window's first ds_or:
+    one launch in a few hundred lost bits of a word (found by tools/soak_jpeg_scan.py; explicit s_waitcnt in huffman_rows.h since).
+    2048-wide planes (one 256-block chunk per row) at ~7.5 bit/px: every launch of the one-launch encoder, the fused kernel and the staged
+    coder compared with the first on the device; a sample of the first's rows against the checker"""
+    api.init(0)
+    W, H = 2048, 7680  # 960 rows: four workgroups on (almost) every CU at once, which is when it happened
+    q = np.ones(64, dtype=np.float32)  # ~15 KiB of code per row: the words lost were among the last-cleared slots (768..1023) of the third and fourth window
+    n, stride, nblk = H // 8, api.huffman_seg_stride(W), (W // 8) * (H // 8)
+    work = torch.zeros((n + 2,), dtype=torch.int64, device="cuda")
+    for seed in (3, 4):
+        img = synth.plane_u8_torch(W, H, "photo", seed=seed)
+        lv = torch.zeros((nblk, 64), dtype=torch.int16, device="cuda")
+        rn = torch.zeros((nblk, 64), dtype=torch.uint8, device="cuda")
+        ct = torch.zeros((nblk,), dtype=torch.uint8, device="cuda")
+        api.fwd_u8_records(img, W, H, lv, rn, ct, lut=q)
+        seg0 = torch.zeros((n * stride,), dtype=torch.uint8, device="cuda")
+        nb0 = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        ff0 = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        api.fwd_u8_huffman_rows(img, W, H, seg0, nb0, lut=q, ff_counts=ff0)
+        assert int(nb0.min().item()) > 2 * 4096  # every row needs at least three windows of 1024 words
+        total = int(nb0.sum().item()) + int(ff0.sum().item()) + 2 * (n - 1)
+        scan0 = torch.zeros((total,), dtype=torch.uint8, device="cuda")
+        off0 = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
+        api.jpeg_pack_rows(seg0, nb0, stride, n, scan0, off0, ff_counts=ff0)
+        if seed == 3:  # the checker on a few rows (its plain C coder takes its time on rows of this size)
+            lvh, rnh, cth, bpr = lv.cpu().numpy(), rn.cpu().numpy(), ct.cpu().numpy(), W // 8
+            for r in (0, n // 2, n - 1):
+                ws, wn, _ = O.huffman_rows(lvh[r * bpr:(r + 1) * bpr], rnh[r * bpr:(r + 1) * bpr], cth[r * bpr:(r + 1) * bpr], W, 8)
+                assert int(nb0[r].item()) == int(wn[0]) and np.array_equal(seg0[r * stride:r * stride + int(wn[0])].cpu().numpy(), ws[: int(wn[0])]), r
+        seg = torch.zeros_like(seg0)
+        nb = torch.zeros_like(nb0)
+        scan = torch.zeros_like(scan0)
+        off = torch.zeros_like(off0)
+        bad = torch.zeros((3,), dtype=torch.int64, device="cuda")
+        for rep in range(250):  # every launch compared, on the device
+            api.fwd_u8_jpeg_scan(img, W, H, seg, work, scan, off, lut=q)
+            bad[0] += (scan != scan0).sum() + (off != off0).sum()
+            if rep % 5 == 0:
+                api.fwd_u8_huffman_rows(img, W, H, seg, nb, lut=q)
+                bad[1] += (seg != seg0).sum() + (nb != nb0).sum()
+                api.huffman_rows(lv, rn, ct, W, H, seg, nb)
+                bad[2] += (seg != seg0).sum() + (nb != nb0).sum()
+        assert bad.tolist() == [0, 0, 0], (seed, bad.tolist())
+
+
 def test_pack_checker_equals_the_host_writer():
     """orc_jpeg_pack_rows == jfif.scan_bytes (numpy) on segments full of 0xFF bytes, empty rows, a capacity that cuts the scan short"""
     rng = np.random.default_rng(9)
