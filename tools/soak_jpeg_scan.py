@@ -32,6 +32,21 @@ while time.time() - t0 < secs:
     want = torch.zeros((total + 8,), dtype=torch.uint8, device="cuda")
     woff = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
     M.jpeg_pack_rows(seg, nb, stride, n, want, woff, ff_counts=ff)
+    if it % 4 == 0 and W * H <= 1 << 22:  # the staged coder too (3 B/px of records: smaller planes only)
+        nblk = (W // 8) * (H // 8)
+        lv = torch.zeros((nblk, 64), dtype=torch.int16, device="cuda")
+        rn = torch.zeros((nblk, 64), dtype=torch.uint8, device="cuda")
+        ct = torch.zeros((nblk,), dtype=torch.uint8, device="cuda")
+        M.fwd_u8_records(img, W, H, lv, rn, ct, lut=q)
+        seg_s = torch.empty_like(seg)
+        nb_s = torch.zeros_like(nb)
+        M.huffman_rows(lv, rn, ct, W, H, seg_s, nb_s)
+        want_s = torch.zeros_like(want)
+        woff_s = torch.zeros_like(woff)
+        M.jpeg_pack_rows(seg_s, nb_s, stride, n, want_s, woff_s)  # the uncounted packing
+        if not (torch.equal(nb_s, nb) and torch.equal(woff_s, woff) and torch.equal(want_s, want)):
+            print(f"!! MISMATCH at iteration {it}: {W}x{H} {kind}: staged path vs fused kernel + counted packing")
+            sys.exit(1)
     gots = [(torch.zeros((total + 8,), dtype=torch.uint8, device="cuda"), torch.zeros((n + 1,), dtype=torch.int64, device="cuda")) for _ in range(3)]
     seg_w = torch.empty((n * stride,), dtype=torch.uint8, device="cuda")
     for got, off in gots:  # three launches back to back on the same work array
