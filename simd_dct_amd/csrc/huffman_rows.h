@@ -3,6 +3,7 @@
 // (mdct_kernels.hip: records only ever exist in LDS).  Device code only; no reference counterpart.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wg_sync.h"
 #include <stdint.h>
 
 namespace mdct
@@ -153,8 +154,7 @@ struct HuffRowCoder
     }
     if (lane == 63)
       tot[par][wave] = incl;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (explicit, see the window loop below)
-    __syncthreads(); // also: every wave has flushed (and cleared) the previous chunk's words
+    wg_sync(); // also: every wave has flushed (and cleared) the previous chunk's words
     uint32_t wave_start = 0, chunk_bits = 0, lane0_len = 0;
 #pragma unroll
     for (uint32_t w = 0; w < (uint32_t)WAVES; w++)
@@ -188,8 +188,7 @@ struct HuffRowCoder
         // the s_waitcnt lgkmcnt(0) every other barrier of the kernel gets (ISA, ROCm 7.2), and a clear that is still queued when
         // another SIMD's wave passes the barrier overtakes that wave's ds_or: one row in ~10^5 of those that need several windows
         // lost bits of a word (tools/soak_jpeg_scan.py)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        wg_sync();
       }
       if (live)
       {
@@ -241,7 +240,7 @@ struct HuffRowCoder
         if (nacc && widx - win < kHuffRing)
           atomicOr(&ring[widx & (kHuffRing - 1)], acc << (32 - nacc));
       }
-      __syncthreads();
+      wg_sync();
       const uint32_t stop = min(w_end, win + kHuffRing);
       for (uint32_t w = win + tid; w < stop; w += kChunk)
       {
@@ -348,8 +347,7 @@ struct HuffRowCoder16
     }
     if (lane == 63)
       tot[par][wave] = incl;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (explicit, see the window loop below)
-    __syncthreads(); // also: every wave has flushed (and cleared) the previous chunk's words
+    wg_sync(); // also: every wave has flushed (and cleared) the previous chunk's words
     uint32_t wave_start = 0, chunk_bits = 0, lane0_len = 0;
 #pragma unroll
     for (uint32_t w = 0; w < (uint32_t)WAVES; w++)
@@ -377,8 +375,7 @@ struct HuffRowCoder16
         // the s_waitcnt lgkmcnt(0) every other barrier of the kernel gets (ISA, ROCm 7.2), and a clear that is still queued when
         // another SIMD's wave passes the barrier overtakes that wave's ds_or: one row in ~10^5 of those that need several windows
         // lost bits of a word (tools/soak_jpeg_scan.py)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        wg_sync();
       }
       if (live)
       {
@@ -420,7 +417,7 @@ struct HuffRowCoder16
         if (nacc && widx - win < RING)
           atomicOr(&ring[widx & (RING - 1)], acc << (32 - nacc));
       }
-      __syncthreads();
+      wg_sync();
       const uint32_t stop = min(w_end, win + RING);
       for (uint32_t w = win + tid; w < stop; w += kChunk)
       {

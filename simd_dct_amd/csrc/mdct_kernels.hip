@@ -20,6 +20,7 @@
 
 #include <type_traits>
 
+#include "wg_sync.h"
 #include "huffman_rows.h"
 #include "pack_rows.h"
 #include "mdct_kernels.h"
@@ -1007,7 +1008,7 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
     static_assert(kWG == 256, "one table entry per thread");
     __shared__ float div_tab[256];
     div_tab[threadIdx.x] = (float)threadIdx.x / 255.f;
-    __syncthreads();
+    wg_sync();
     px_div255 = div_tab;
   }
 
@@ -1046,7 +1047,7 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
 #pragma unroll
       for (int c = 0; c < 64; c++)
         slds[c * kStereoRowStride + threadIdx.x] = (uint8_t)q[c];
-      __syncthreads();
+      wg_sync();
       uint8_t *out0 = a.to + (size_t)a.by0 * 2 * a.bpr + wg_t0;
 #pragma unroll
       for (int k = 0; k < 4; k++)
@@ -1746,7 +1747,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
     }
   };
   fetch(wave * 64 + lane);
-  __syncthreads(); // tables and the cleared ring
+  wg_sync(); // tables and the cleared ring
   for (uint32_t c0 = 0; c0 < a.bpr; c0 += kChunk)
   {
     const uint32_t bx = c0 + wave * 64 + lane;
@@ -1829,7 +1830,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
   }
   if ((PACK || a.ff_counts) && coder.ff)
     atomicAdd(&ff_total, coder.ff);
-  __syncthreads();
+  wg_sync();
   if constexpr (!PACK)
   {
     if (tid == 0)
@@ -1860,7 +1861,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
       row_info[1] = ff;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's stores of the segment have reached L2 ...
-    __syncthreads();                                  // ... and so have everybody's: the copy below reads them back from there
+    wg_sync();                                  // ... and so have everybody's: the copy below reads them back from there
     const uint32_t nbytes = row_info[0];
     PackRow<true> prow;
     prow.begin(a.out + (size_t)row * a.seg_stride, a.seg_stride, nbytes); // on its way while the chain is consulted

@@ -3,6 +3,7 @@
 // byte-stuffed (ITU-T T.81 B.1.1.5) and followed by its restart marker (E.1.4).  256 threads per workgroup.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "wg_sync.h"
 #include <stdint.h>
 
 #include "huffman_rows.h" // ff_bytes
@@ -36,10 +37,10 @@ __device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t *wave_tot /*
     if (lane >= (uint32_t)d)
       incl += u;
   }
-  __syncthreads(); // the previous use of wave_tot is over
+  wg_sync(); // the previous use of wave_tot is over
   if (lane == 63)
     wave_tot[wave] = incl;
-  __syncthreads();
+  wg_sync();
   uint32_t before = 0;
   total = 0;
 #pragma unroll
@@ -58,10 +59,10 @@ __device__ __forceinline__ unsigned long long wg_sum256(unsigned long long s, un
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1)
     s += __shfl_xor(s, d, 64);
-  __syncthreads(); // the previous use of wave_sum is over
+  wg_sync(); // the previous use of wave_sum is over
   if ((threadIdx.x & 63) == 0)
     wave_sum[threadIdx.x >> 6] = s;
-  __syncthreads();
+  wg_sync();
   return wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
 }
 
@@ -175,7 +176,7 @@ __device__ __forceinline__ void pack_write_windows(PackWindow<COHERENT, BPT> &wi
         }
       }
     }
-    __syncthreads();
+    wg_sync();
     // LDS byte x <-> global byte g - o + x, and g - o is 16-byte aligned
     uint8_t *gb = g - o;
     const uint32_t lim = o + total;

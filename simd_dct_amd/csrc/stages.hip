@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "wg_sync.h"
 #include "huffman_rows.h"
 #include "pack_rows.h"
 #include "mdct.h"
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
   };
 
   fetch(wave * 64);
-  __syncthreads(); // tables and the cleared ring
+  wg_sync(); // tables and the cleared ring
   for (uint32_t c0 = 0; c0 < a.bpr; c0 += kHuffChunk)
   {
     const uint32_t c0w = c0 + wave * 64, bx = c0w + lane;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(kHuffChunk) void k_huffman_rows(HuffArgs a)
     wave_sync();
     coder.chunk(c0, rec_lds + lane * kRecSkew, n, live, prev_dc, reinterpret_cast<const int16_t *>(g_lv + (live ? bx : 0u) * 128u), g_rn + (live ? bx : 0u) * 64u);
   }
-  __syncthreads();
+  wg_sync();
   if (tid == 0)
     a.seg_bytes[row] = coder.finish();
 }
@@ -351,10 +352,10 @@ __global__ __launch_bounds__(256) void k_pack_scan(PackArgs a)
       if (lane >= (uint32_t)d)
         incl += u;
     }
-    __syncthreads();
+    wg_sync();
     if (lane == 63)
       wave_tot[wave] = incl;
-    __syncthreads();
+    wg_sync();
     unsigned long long before = 0, total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < 4; w++)
