@@ -883,6 +883,7 @@ def test_soak_random_differential():
     combos = [("q32_avx", 64), ("stereo_sse", 16), ("stereo_scalar", 16), ("encq_sse", 16), ("encq_scalar", 8)]
     specials = [0.0, -0.7, 1e-6, 1e-30, np.inf, np.nan, 3e38]
     progress = os.environ.get("MDCT_SOAK_PROGRESS")  # a file that gets one line every 5000 cases (long runs on a watched box)
+    SOAK_WORK = torch.zeros((64,), dtype=torch.int64, device="cuda")  # the one-launch encoder's row chain: zeroed once for the whole run
     for it in range(n):
         if progress and it % 5000 == 0:
             with open(progress, "a") as f:
@@ -944,6 +945,27 @@ def test_soak_random_differential():
             assert np.array_equal(nb.cpu().numpy().astype(np.uint32), wn), (it, W2, H2)
             for r in range(H2 // 8):
                 assert np.array_equal(gs[r * stride:r * stride + wn[r]], ws[r * stride:r * stride + wn[r]]), (it, W2, H2, r)
+        # ... and the same rows from pixels in ONE kernel, then on into the finished scan, in one launch and in two
+        want_lv, want_rn, want_ct = O.u8_records(px, W2, H2, lut=table, level_shift=bool(it & 1))
+        ws, wn, _ = O.huffman_rows(want_lv, want_rn, want_ct, W2, H2, chroma=bool(it & 2))
+        wscan, woff = O.jpeg_pack_rows(ws, wn, stride, first_rst=it % 8)
+        seg = torch.zeros(((H2 // 8) * stride,), dtype=torch.uint8, device="cuda")
+        nb = torch.zeros((H2 // 8,), dtype=torch.int32, device="cuda")
+        ff = torch.zeros((H2 // 8,), dtype=torch.int32, device="cuda")
+        M.fwd_u8_huffman_rows(dev(px), W2, H2, seg, nb, lut=table, level_shift=bool(it & 1), chroma=bool(it & 2), ff_counts=ff)
+        gs = seg.cpu().numpy()
+        assert np.array_equal(nb.cpu().numpy().astype(np.uint32), wn), (it, W2, H2, "fused")
+        for r in range(H2 // 8):
+            assert np.array_equal(gs[r * stride:r * stride + wn[r]], ws[r * stride:r * stride + wn[r]]), (it, W2, H2, r, "fused")
+        total = int(woff[-1])
+        for one_launch in (False, True):
+            scan = torch.full((total + 8,), 0x33, dtype=torch.uint8, device="cuda")
+            off = torch.zeros((H2 // 8 + 1,), dtype=torch.int64, device="cuda")
+            if one_launch:
+                M.fwd_u8_jpeg_scan(dev(px), W2, H2, seg, SOAK_WORK, scan, off, lut=table, level_shift=bool(it & 1), chroma=bool(it & 2), first_rst=it % 8, out_capacity=total)
+            else:
+                M.jpeg_pack_rows(seg, nb, stride, H2 // 8, scan, off, first_rst=it % 8, out_capacity=total, ff_counts=ff)
+            assert np.array_equal(off.cpu().numpy().astype(np.uint64), woff) and np.array_equal(scan.cpu().numpy()[:total], wscan[:total]) and (scan[total:] == 0x33).all(), (it, W2, H2, one_launch)
 
 
 RELINKED = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "simd_dct_relinked")
