@@ -2041,14 +2041,14 @@ __global__ __launch_bounds__(kWG) MDCT_F32_ATTR void k_f32(F32Args a)
 #ifndef MDCT_F32_TILE_WAVES
 #define MDCT_F32_TILE_WAVES 2
 #endif
-template <int MODE>
+template <int MODE, bool PRIO = false>
 __device__ __forceinline__ void f32_tile_body(const F32Args &a);
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MDCT_F32_TILE_WAVES, MDCT_F32_TILE_WAVES))) void k_f32_tile(F32Args a)
 {
   f32_tile_body<MODE>(a);
 }
-template <int MODE>
+template <int MODE, bool PRIO>
 __device__ __forceinline__ void f32_tile_body(const F32Args &a)
 {
   typedef float f32x4_g __attribute__((ext_vector_type(4)));
@@ -2073,6 +2073,7 @@ __device__ __forceinline__ void f32_tile_body(const F32Args &a)
       b[r][4 + j] = odd ? B[j] : got;
     }
   }
+  MDCT_PHASE_PRIO(2);
   if constexpr (MODE == MODE_FWD)
   {
     raw_fwd(C, b);
@@ -2087,6 +2088,7 @@ __device__ __forceinline__ void f32_tile_body(const F32Args &a)
       b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.scale[i];
     raw_inv(C, b);
   }
+  MDCT_PHASE_PRIO(3);
 #pragma unroll
   for (int r = 0; r < 8; r++)
   {

@@ -404,6 +404,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
 }
 
 template <int MODE, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void v_f32_tile_prio(F32Args a)
+{
+  f32_tile_body<MODE, true>(a);
+}
+template <int MODE, int WAVES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void v_f32_tile(F32Args a)
 {
   f32_tile_body<MODE>(a);
@@ -745,6 +750,9 @@ int main(int argc, char **argv)
     const dim3 g64((unsigned)(W / 512), (unsigned)(H / 8));
     vs.push_back({"k_f32<FWD, WIDE> linear 256", [&](int s) { hipLaunchKernelGGL((k_f32<MODE_FWD, true>), dim3(nwg), dim3(256), 0, 0, fargs(s)); }, {}});
     vs.push_back({"f32 fwd tile, 2 waves", [&](int s) { hipLaunchKernelGGL((v_f32_tile<MODE_FWD, 2>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"f32 fwd tile, 2 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_f32_tile_prio<MODE_FWD, 2>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"f32 fwd tile, 3 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_f32_tile_prio<MODE_FWD, 3>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
+    vs.push_back({"f32 inv tile, 2 waves, phase prio", [&](int s) { hipLaunchKernelGGL((v_f32_tile_prio<MODE_INV, 2>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
     vs.push_back({"f32 fwd tile, 3 waves", [&](int s) { hipLaunchKernelGGL((v_f32_tile<MODE_FWD, 3>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
     vs.push_back({"f32 fwd tile, 4 waves", [&](int s) { hipLaunchKernelGGL((v_f32_tile<MODE_FWD, 4>), g64, dim3(64), 0, 0, fargs(s)); }, {}});
     vs.push_back({"k_f32<INV, WIDE> linear 256", [&](int s) { hipLaunchKernelGGL((k_f32<MODE_INV, true>), dim3(nwg), dim3(256), 0, 0, fargs(s)); }, {}});
