@@ -20,10 +20,6 @@ struct __attribute__((packed)) PackU32
 {
   uint32_t v;
 };
-struct __attribute__((packed, aligned(4))) PackU128
-{
-  uint32_t v[4];
-};
 
 // sum over the 256 threads of the workgroup (returned to all) and the exclusive prefix of this thread
 __device__ __forceinline__ uint32_t wg_scan256(uint32_t v, uint32_t *wave_tot /* LDS [4] */, uint32_t &total)
