@@ -286,7 +286,12 @@ int run_u8_records(const void *px_, bool i16_in, size_t pitch_px, const float *l
   if ((r = make_own_tables(lut, a.tb, /*pair_order=*/true)))
     return r;
   a.dc_shift = level_shift ? 64.0f * 128.0f : 0.0f;
-  const hipError_t e = mdct::launch_u8_records(a, i16_in, (hipStream_t)stream);
+  // 8-bit pixels: |coefficient| <= 8 * 255 = 2040, so with every table entry >= 1/16 in magnitude (or no table) the quantised value stays
+  // inside int16 (<= 32640) and the kernel's saturations cannot fire (mdct_kernels.hip: k_u8_records<.., CLAMP>)
+  bool clamp = i16_in;
+  for (int i = 0; lut && !clamp && i < 64; i++)
+    clamp = !(fabsf(lut[i]) >= 0.0625f);
+  const hipError_t e = mdct::launch_u8_records(a, i16_in, (hipStream_t)stream, clamp);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "u8 -> records kernel launch");
 }
 

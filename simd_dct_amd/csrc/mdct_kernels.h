@@ -172,7 +172,7 @@ hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool sa
 hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s, bool lut_bounded = false);
 hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s, bool luts_bounded = false);
 hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s);
-hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s);
+hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s, bool clamp = true);
 hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, bool clamp, uint32_t n_rows, hipStream_t s);
 hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s);
 hipError_t launch_stream_copy(const void *from, void *to, size_t bytes, int cus, hipStream_t s);

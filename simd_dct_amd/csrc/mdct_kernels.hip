@@ -1603,7 +1603,9 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_
 // run/level compaction of k_scan (scan_records.h) on the values still in registers.  1 B/px in, 3 B/px out
 // (k_u8_i16 + k_scan move 3 + 5).  Bit for bit the records mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 produce.
 // One wave per workgroup: every wave works alone on 64 consecutive blocks (lane = block).
-template <bool I16_IN>
+// CLAMP = false (8-bit pixels, every table entry >= 1/16 in magnitude or no table, decided on the host): |coefficient| <= 8 * 255, so the
+// quantised value cannot leave int16 and the 64 saturations per block are left out.
+template <bool I16_IN, bool CLAMP = true>
 __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
 {
   __shared__ __attribute__((aligned(16))) uint8_t lv[64 * kLvRow];
@@ -1663,8 +1665,18 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
     { // the int16 the plane would have held (store_i16x8<0>), sign-extended
       f32x2 m;
       MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[j * 8 + v], MDCT_K_LH);
-      val[v * 8 + kA[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.x) & 0xFFFFu);
-      val[v * 8 + kB[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.y) & 0xFFFFu);
+      if constexpr (CLAMP)
+      {
+        val[v * 8 + kA[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.x) & 0xFFFFu);
+        val[v * 8 + kB[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.y) & 0xFFFFu);
+      }
+      else
+      {
+        f32x2 t;
+        MDCT_PKA(t, m, K.magic, MDCT_K_LL);
+        val[v * 8 + kA[j]] = (int)(int16_t)(__float_as_uint(t.x) & 0xFFFFu);
+        val[v * 8 + kB[j]] = (int)(int16_t)(__float_as_uint(t.y) & 0xFFFFu);
+      }
     }
   }
   scan_emit<true>(val, lv, rn, lane, nvalid, valid, (size_t)a.by0 * a.bpr + wave_t0, a.levels, a.runs, a.counts);
@@ -2270,14 +2282,16 @@ hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s)
   return hipGetLastError();
 }
 
-hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s)
+hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s, bool clamp)
 {
   if (a.nblocks == 0)
     return hipSuccess;
   if (i16_in)
     hipLaunchKernelGGL(k_u8_records<true>, dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a);
-  else
+  else if (clamp)
     hipLaunchKernelGGL(k_u8_records<false>, dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_u8_records<false, false>), dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 

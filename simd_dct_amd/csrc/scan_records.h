@@ -14,7 +14,7 @@ typedef unsigned int scan_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
                              35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-constexpr int kLvRow = 144; // 64 int16 + 16 B: slot 64 (inside the pad) takes the writes of zero coefficients
+constexpr int kLvRow = 144; // 64 int16 + 16 B of pad (slot 64 takes the write that clears the run after the last pair)
 constexpr int kRnRow = 80;  // 64 u8 + 16 B, same trick
 
 // The lane's 64 values (natural order v*8+u, 32-bit integers in registers) -> its record in the wave-private LDS areas
@@ -38,18 +38,21 @@ __device__ __forceinline__ void scan_emit(const int (&val)[64], uint8_t *lv, uin
 #pragma unroll
     for (int i = 0; i < kRnRow / 16; i++)
       *reinterpret_cast<u32x4 *>(my_rn + i * 16) = z;
+    // every coefficient writes (level, run) at the current position and only the non-zero ones advance it: a zero's write is
+    // overwritten by the next pair; what the last zeros leave at the final position is level 0 and a run that is cleared below
+    // (no per-coefficient select of the slot)
     uint32_t run = 0;
 #pragma unroll
     for (int k = 0; k < 64; k++)
     {
       const int c = val[kZigZag[k]];
       const bool nz = c != 0;
-      const uint32_t slot = nz ? pos : 64u; // zeros write into the pad
-      *reinterpret_cast<int16_t *>(my_lv + slot * 2) = (int16_t)c;
-      my_rn[slot] = (uint8_t)run;
+      *reinterpret_cast<int16_t *>(my_lv + pos * 2) = (int16_t)c; // pos <= 63 while coefficients remain; slot 64 is inside the pad
+      my_rn[pos] = (uint8_t)run;
       pos += nz ? 1u : 0u;
       run = nz ? 0u : run + 1u;
     }
+    my_rn[pos] = 0; // pos == 64: the pad
   }
   else
   {

@@ -202,6 +202,27 @@ def test_fused_pixels_to_records_equals_the_two_stage_path():
             api.zigzag_rle_i16(coef, W, H, lv2, rn2, ct2)
             assert torch.equal(lv, lv2) and torch.equal(rn, rn2) and torch.equal(ct, ct2)
             del img
+    # the largest values 8-bit pixels can produce (flat 255 / 0, the sign pattern of every basis function) through the smallest table for
+    # which the kernel leaves its int16 saturations out (every entry 1/16: |coefficient| * 16 <= 32640), and through one just below it
+    xs = np.arange(8)
+    cosm = np.cos((2 * xs[None, :] + 1) * xs[:, None] * np.pi / 16)
+    worst = np.zeros((24, 512), dtype=np.uint8)
+    for u in range(8):
+        for v in range(8):
+            blk = np.where(np.outer(cosm[v], cosm[u]) > 0, 255, 0).astype(np.uint8)
+            worst[0:8, (u * 8 + v) * 8:(u * 8 + v) * 8 + 8] = blk
+            worst[8:16, (u * 8 + v) * 8:(u * 8 + v) * 8 + 8] = 255 - blk
+    worst[16:24, :256] = 255
+    for q in (np.full(64, 0.0625, dtype=np.float32), np.full(64, 0.0624, dtype=np.float32), np.full(64, -0.0625, dtype=np.float32)):
+        for shift in (False, True):
+            want = O.u8_records(worst, 512, 24, lut=q, level_shift=shift)
+            assert int(np.abs(want[0].astype(np.int64)).max()) >= 16000
+            lv = torch.full((192, 64), 0x5A5A, dtype=torch.int16, device="cuda")
+            rn = torch.full((192, 64), 0x5A, dtype=torch.uint8, device="cuda")
+            ct = torch.full((192,), 0x5A, dtype=torch.uint8, device="cuda")
+            api.fwd_u8_records(_dev(worst), 512, 24, lv, rn, ct, lut=q, level_shift=shift)
+            for got, w in zip((lv, rn, ct), want):
+                assert np.array_equal(got.cpu().numpy(), w), (float(q[0]), shift)
     assert api.fwd_u8_records(_dev(np.zeros((16, 64), dtype=np.uint8)), 64, 16, lv, rn, ct, lut=np.zeros(64, dtype=np.float32), check=False) == 1  # a zero table entry
     # the int16-plane variant: mdct_fwd_i16_records == mdct_fwd_i16 + mdct_zigzag_rle_i16 == the checker's composition
     for (W, H, pitch) in ((8, 8, 8), (200, 40, 208), (1024, 72, 1024)):
