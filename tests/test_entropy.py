@@ -534,6 +534,19 @@ def test_dense_rows_that_need_several_ring_windows_code_the_same_bytes_every_tim
         assert bad.tolist() == [0, 0, 0], (seed, bad.tolist())
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("MDCT_SOAK_JPEG"), reason="opt-in soak: MDCT_SOAK_JPEG=<seconds> python -m pytest tests -m gpu -k soak_of_the_encoders")
+def test_soak_of_the_encoders():
+    """opt-in: tools/soak_jpeg_scan.py (random sizes / tables / contents; one-launch encoder vs fused kernel + packing vs the staged path) and
+    tools/soak_determinism.py (every kernel at full occupancy, every launch compared with the first) for MDCT_SOAK_JPEG seconds / launches x 10"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    secs = os.environ["MDCT_SOAK_JPEG"]
+    for cmd in ([sys.executable, os.path.join(root, "tools", "soak_jpeg_scan.py"), secs], [sys.executable, os.path.join(root, "tools", "soak_determinism.py"), str(10 * int(float(secs)))]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-500:]
+
+
 def test_pack_checker_equals_the_host_writer():
     """orc_jpeg_pack_rows == jfif.scan_bytes (numpy) on segments full of 0xFF bytes, empty rows, a capacity that cuts the scan short"""
     rng = np.random.default_rng(9)
