@@ -12,7 +12,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -std
 all: lib cli oracle
 
 lib: $(LIB)
-$(LIB): $(CSRC)/shim_host.h $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/stages.hip $(CSRC)/mdct_kernels.h $(CSRC)/scan_records.h $(CSRC)/huffman_rows.h $(CSRC)/pack_rows.h $(CSRC)/wg_sync.h include/mdct.h include/simd_dct_shim.h
+$(LIB): $(CSRC)/shim_host.h $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/stages.hip $(CSRC)/mdct_kernels.h $(CSRC)/scan_records.h $(CSRC)/huffman_rows.h $(CSRC)/pack_rows.h $(CSRC)/wg_sync.h $(CSRC)/batch_plan.h include/mdct.h include/simd_dct_shim.h
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/stages.hip -ldl -o $@
 
 cli: tools/simd_dct_cli

@@ -132,9 +132,9 @@ int mdct_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out
 int mdct_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
                  size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
 
-/* Multi-plane batch (config 3: Y + Cb + Cr with per-plane tables): one launch per group of
- * up to 4 planes, descriptors and tables by value in the kernel arguments (no allocation,
- * no sync, capture-safe).  `planes` is a HOST array. */
+/* Multi-plane call (BASELINE.json configs[2]: Y + Cb + Cr with per-plane tables): the fused round trip of every plane
+ * in ONE launch (== mdct_roundtrip_i16_batch below: any number of planes, descriptors and tables by value in the
+ * kernel arguments -- no allocation, no sync, capture-safe).  `planes` is a HOST array. */
 typedef struct mdct_plane_i16
 {
   const int16_t *from;
@@ -144,6 +144,34 @@ typedef struct mdct_plane_i16
   const float *lut;           /* HOST pointer to 64 floats, or NULL */
 } mdct_plane_i16;
 int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *stream);
+
+/* Plane batches: ANY number of separately allocated planes (sizes, pitches and tables of their own) per call --
+ * BASELINE.json configs[3] ("256 independent 4096x4096 planes") and configs[2] (Y + Cb + Cr); the reference's only
+ * batching affordance is the caller-side row range startY/endY (simd_dct.cpp:2243-2261).  Semantics per plane exactly
+ * those of mdct_fwd_i16 / mdct_inv_i16 / mdct_roundtrip_i16 over the whole plane (to shard a plane, describe the
+ * strip: offset pointers, smaller sizeY).  Every plane is cut into 64-block tiles of one block row (the last tile of
+ * a row may be partial: any sizeX % 8 == 0) and the launch is one 1-D grid over the tiles of all planes.
+ * `planes` is a HOST array; nothing is allocated, copied or synchronised: descriptors and tables travel in the
+ * kernel arguments, as many planes per launch as fit (~50 planes sharing one table; capture-safe).  All planes are
+ * validated before anything is launched. */
+int mdct_fwd_i16_batch(const mdct_plane_i16 *planes, int n_planes, void *stream);
+int mdct_inv_i16_batch(const mdct_plane_i16 *planes, int n_planes, void *stream);
+int mdct_roundtrip_i16_batch(const mdct_plane_i16 *planes, int n_planes, void *stream);
+/* The same with the descriptors and tables in device memory: mdct_batch_create allocates and uploads them once
+ * (synchronous; not capture-safe), mdct_batch_run is then ONE launch for the whole list whatever its length (more
+ * only beyond 2^31 tiles), asynchronous on `stream`, capture-safe, repeatable.  The batch refers to the planes'
+ * memory, not to the `planes` array or the tables, which may be freed after creation. */
+enum
+{
+  MDCT_MODE_FWD = 0,
+  MDCT_MODE_INV = 1,
+  MDCT_MODE_ROUNDTRIP = 2
+};
+typedef struct mdct_batch mdct_batch;
+int mdct_batch_create(mdct_batch **batch, int mode, const mdct_plane_i16 *planes, int n_planes);
+int mdct_batch_run(const mdct_batch *batch, void *stream);
+int mdct_batch_launches(const mdct_batch *batch); /* kernel launches one run takes (host function) */
+int mdct_batch_destroy(mdct_batch *batch);
 
 /* ---- the stages either side of the transform (no reference counterpart: its pipeline starts from a
  * ready-made plane, main.cpp:475-493, and ends at the reorder store, simd_dct.cpp:2221-2230) ----------

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdct_hip.so")
+# MDCT_LIB_PATH: another build of the same library (A/B timing of kernel variants, tools/); never a different product
+LIB_PATH = os.environ.get("MDCT_LIB_PATH") or os.path.join(_HERE, "libmdct_hip.so")
 
 c_size_t = ctypes.c_size_t
 c_void_p = ctypes.c_void_p
@@ -64,6 +65,13 @@ SIGNATURES = {
     "mdct_fwd_f32": (c_int, _PLANE_F32),
     "mdct_inv_f32": (c_int, _PLANE_F32),
     "mdct_roundtrip_i16_planes": (c_int, [ctypes.POINTER(PlaneI16), c_int, c_void_p]),
+    "mdct_fwd_i16_batch": (c_int, [ctypes.POINTER(PlaneI16), c_int, c_void_p]),
+    "mdct_inv_i16_batch": (c_int, [ctypes.POINTER(PlaneI16), c_int, c_void_p]),
+    "mdct_roundtrip_i16_batch": (c_int, [ctypes.POINTER(PlaneI16), c_int, c_void_p]),
+    "mdct_batch_create": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(PlaneI16), c_int]),
+    "mdct_batch_run": (c_int, [c_void_p, c_void_p]),
+    "mdct_batch_launches": (c_int, [c_void_p]),
+    "mdct_batch_destroy": (c_int, [c_void_p]),
     "mdct_zigzag_rle_i16": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdct_zigzag_rle_q32": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdct_zigzag_rle_u8": (c_int, [c_void_p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),

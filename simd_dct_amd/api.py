@@ -59,8 +59,8 @@ def _ptr(t):
 
 
 def _stream(stream=None):
-    if stream is not None:
-        return ctypes.c_void_p(int(stream))
+    if stream is not None:  # a raw hipStream_t or a torch.cuda.Stream
+        return ctypes.c_void_p(int(getattr(stream, "cuda_stream", stream)))
     import torch
 
     if torch.cuda.is_available():
@@ -210,18 +210,74 @@ def inv_f32(src, dst, sizeX, sizeY, by0=0, by1=None, pitch_in=None, pitch_out=No
     return _plane_f32(_lib.load().mdct_inv_f32, src, dst, sizeX, sizeY, by0, by1, pitch_in, pitch_out, stream, check)
 
 
-def roundtrip_i16_planes(planes, stream=None, check=True):
-    """planes: list of (src, dst, sizeX, sizeY, lut-or-None); one launch per 4 planes."""
-    arr = (_lib.PlaneI16 * len(planes))()
+def _plane_array(planes):
+    """planes: list of (src, dst, sizeX, sizeY, lut-or-None[, pitch_in, pitch_out]) -> (mdct_plane_i16 array, objects to keep alive)"""
+    arr = (_lib.PlaneI16 * max(len(planes), 1))()
     keep = []
-    for i, (src, dst, sx, sy, lut) in enumerate(planes):
+    for i, pl in enumerate(planes):
+        src, dst, sx, sy, lut = pl[:5]
+        pin = pl[5] if len(pl) > 5 and pl[5] is not None else sx
+        pout = pl[6] if len(pl) > 6 and pl[6] is not None else sx
         k, lp = _lut_ptr(lut)
-        keep.append(k)
-        arr[i] = _lib.PlaneI16(_ptr(src), _ptr(dst), sx, sx, sx, sy, lp)
+        keep.append((k, src, dst))
+        arr[i] = _lib.PlaneI16(_ptr(src), _ptr(dst), pin, pout, sx, sy, lp)
+    return arr, keep
+
+
+def roundtrip_i16_planes(planes, stream=None, check=True):
+    """planes: list of (src, dst, sizeX, sizeY, lut-or-None); the call BASELINE.json configs[2] is measured on."""
+    arr, keep = _plane_array(planes)
     rc = _lib.load().mdct_roundtrip_i16_planes(arr, len(planes), _stream(stream))
     if check:
         _check(rc)
     return rc
+
+
+MODES = {"fwd": 0, "inv": 1, "roundtrip": 2}  # MDCT_MODE_*
+
+
+def i16_batch(mode, planes, stream=None, check=True):
+    """mdct_{fwd,inv,roundtrip}_i16_batch: any number of separately allocated planes, descriptors in the kernel
+    arguments (no allocation; as many planes per launch as fit).  planes as for _plane_array."""
+    lib = _lib.load()
+    fn = {"fwd": lib.mdct_fwd_i16_batch, "inv": lib.mdct_inv_i16_batch, "roundtrip": lib.mdct_roundtrip_i16_batch}[mode]
+    arr, keep = _plane_array(planes)
+    rc = fn(arr, len(planes), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+class Batch:
+    """mdct_batch: descriptors and tables uploaded once, every run ONE launch (capture-safe)."""
+
+    def __init__(self, mode, planes):
+        lib = _lib.load()
+        arr, self._keep = _plane_array(planes)
+        h = ctypes.c_void_p()
+        _check(lib.mdct_batch_create(ctypes.byref(h), MODES[mode], arr, len(planes)))
+        self._h = h
+        self.launches = lib.mdct_batch_launches(h)
+
+    def run(self, stream=None, check=True):
+        rc = _lib.load().mdct_batch_run(self._h, _stream(stream))
+        if check:
+            _check(rc)
+        return rc
+
+    def prepared(self, stream=None):
+        return Prepared(_lib.load().mdct_batch_run, (self._h, _stream(stream)), self)
+
+    def close(self):
+        if self._h:
+            _lib.load().mdct_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------------- stages either side of the transform
@@ -462,14 +518,15 @@ def prepare_fwd_quant_u8(src, dst, lut, sizeX, sizeY, by0, by1, layout=LAYOUT_Q3
 
 def prepare_roundtrip_i16_planes(planes, stream=None):
     """planes as for roundtrip_i16_planes; descriptors marshalled once"""
+    arr, keep = _plane_array(planes)
+    return Prepared(_lib.load().mdct_roundtrip_i16_planes, (arr, ctypes.c_int(len(planes)), _stream(stream)), keep)
+
+
+def prepare_i16_batch(mode, planes, stream=None):
     lib = _lib.load()
-    arr = (_lib.PlaneI16 * len(planes))()
-    keep = []
-    for i, (src, dst, sx, sy, lut) in enumerate(planes):
-        k, lp = _lut_ptr(lut)
-        keep.append((k, src, dst))
-        arr[i] = _lib.PlaneI16(_ptr(src), _ptr(dst), sx, sx, sx, sy, lp)
-    return Prepared(lib.mdct_roundtrip_i16_planes, (arr, ctypes.c_int(len(planes)), _stream(stream)), keep)
+    fn = {"fwd": lib.mdct_fwd_i16_batch, "inv": lib.mdct_inv_i16_batch, "roundtrip": lib.mdct_roundtrip_i16_batch}[mode]
+    arr, keep = _plane_array(planes)
+    return Prepared(fn, (arr, ctypes.c_int(len(planes)), _stream(stream)), keep)
 
 
 def prepare_stream_copy(src, dst, nbytes, stream=None):

@@ -1,0 +1,181 @@
+// batch_plan.h -- host-only half of the plane-batch entry points (mdct_*_i16_batch, mdct_batch_*): how a list of
+// separately allocated planes becomes the 1-D grid of 64-block tiles k_i16_batch runs on (mdct_kernels.hip).
+// Nothing of the HIP runtime in here: tests/batch_plan_driver.cpp builds it with plain g++ (sanitizers on) and walks
+// every tile index of a launch through batch_locate(), the arithmetic the kernel uses, to see that each tile of each
+// plane is reached exactly once.
+//
+// The reference's only batching affordance is the caller-side row range of every variant (simd_dct.cpp:2243-2261);
+// BASELINE.json's configs[2] (Y + Cb + Cr, own tables) and configs[3] (256 independent planes) need one of the engine's own.
+#ifndef MDCT_BATCH_PLAN_H
+#define MDCT_BATCH_PLAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "mdct.h"
+
+namespace mdct
+{
+
+// What a wave needs of its plane: one 64-byte descriptor, read with scalar loads (one s_load_dwordx16).
+struct BatchDesc
+{
+  const int16_t *from;
+  int16_t *to;
+  uint64_t pitch_in, pitch_out; // elements
+  uint32_t bpr;                 // blocks per block row (sizeX / 8)
+  uint32_t tiles;               // 64-block tiles per block row, the last one possibly partial: (bpr + 63) / 64
+  uint32_t tiles_m, tiles_s;    // exact division by `tiles` (MagicDiv: multiplier, shifts sh1 | sh2 << 8)
+  uint32_t first;               // index of the plane's first tile in the launch
+  uint32_t table;               // byte offset of the plane's tables from the table base
+  uint32_t has_lut;             // fused round trip: 1 = quantise / dequantise in between
+  uint32_t rows;                // block rows (host bookkeeping; the kernel does not read it)
+};
+static_assert(sizeof(BatchDesc) == 64, "one s_load_dwordx16");
+
+// q = n / d for every 32-bit n without a division (Granlund & Montgomery 1994, Figure 4.1):
+// t = mulhi(n, m); q = (t + ((n - t) >> sh1)) >> sh2.  d = 1: m = 0, both shifts 0.
+struct MagicDiv
+{
+  uint32_t m, s; // s = sh1 | sh2 << 8
+};
+inline MagicDiv magic_div(uint32_t d)
+{
+  if (d <= 1)
+    return MagicDiv{0, 0};
+  uint32_t l = 0;
+  while ((1ull << l) < d)
+    l++;
+  const uint64_t m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+  return MagicDiv{(uint32_t)m, 1u | ((l - 1) << 8)};
+}
+inline uint32_t magic_apply(uint32_t n, uint32_t m, uint32_t s)
+{
+  const uint32_t t = (uint32_t)(((uint64_t)n * m) >> 32);
+  return (t + ((n - t) >> (s & 0xFF))) >> (s >> 8);
+}
+
+constexpr int kBatchChain = 8;                // up to this many planes of different shapes are told apart by a compare chain
+constexpr uint32_t kBatchMaxTiles = 0x7FFFFFFFu; // grid limit of one launch
+
+struct BatchLayout
+{
+  std::vector<BatchDesc> descs;  // one per non-empty plane, in order
+  std::vector<int> plane;        // descs[k] describes planes[plane[k]]
+  std::vector<int> tables;       // local table slot -> the caller's table id
+  uint32_t total = 0;            // tiles in the launch
+  uint32_t uniform = 0;          // every plane has the same tile grid
+  uint32_t per_plane = 0;        // tiles per plane when uniform
+  MagicDiv pp{0, 0};
+  uint32_t first8[kBatchChain];
+  int with_lut = 0;              // planes whose has_lut is set
+  int consumed = 0;              // planes taken from the list (empty ones included)
+};
+
+// Lays out planes [i0, n) greedily: as many as fit `blob_bytes` of tables (table_size bytes each) + descriptors
+// (blob_bytes = 0: no limit) and the grid limit.  table_id[i] < 0: plane i needs no table slot; equal ids share a slot.
+// has_lut[i] goes into the descriptor.  Planes without blocks take no descriptor.  Always consumes at least one plane
+// when i0 < n (a single plane that exceeds the grid limit yields consumed = 0: the caller reports it).
+inline void batch_layout(const mdct_plane_i16 *planes, const int *table_id, const unsigned char *has_lut, int i0, int n, size_t blob_bytes, size_t table_size, BatchLayout &out)
+{
+  out = BatchLayout();
+  uint64_t run = 0;
+  for (int i = i0; i < n; i++)
+  {
+    const mdct_plane_i16 &p = planes[i];
+    const uint64_t bpr = p.sizeX / 8, rows = p.sizeY / 8;
+    if (bpr == 0 || rows == 0)
+    {
+      out.consumed++;
+      continue;
+    }
+    const uint64_t tiles = (bpr + 63) / 64;
+    const uint64_t mine = tiles * rows;
+    if (bpr > 0xFFFFFFFFull || tiles * rows / rows != tiles || run + mine > kBatchMaxTiles)
+      break;
+    int slot = -1;
+    bool new_table = false;
+    if (table_id[i] >= 0)
+    {
+      for (size_t k = 0; k < out.tables.size() && slot < 0; k++)
+        if (out.tables[k] == table_id[i])
+          slot = (int)k;
+      new_table = slot < 0;
+      if (new_table)
+        slot = (int)out.tables.size();
+    }
+    if (blob_bytes && (out.tables.size() + (new_table ? 1 : 0)) * table_size + (out.descs.size() + 1) * sizeof(BatchDesc) > blob_bytes)
+      break;
+    if (new_table)
+      out.tables.push_back(table_id[i]);
+    BatchDesc d;
+    d.from = p.from;
+    d.to = p.to;
+    d.pitch_in = p.pitch_in;
+    d.pitch_out = p.pitch_out;
+    d.bpr = (uint32_t)bpr;
+    d.tiles = (uint32_t)tiles;
+    const MagicDiv md = magic_div(d.tiles);
+    d.tiles_m = md.m;
+    d.tiles_s = md.s;
+    d.first = (uint32_t)run;
+    d.table = slot < 0 ? 0u : (uint32_t)(slot * table_size);
+    d.has_lut = has_lut[i] ? 1u : 0u;
+    d.rows = (uint32_t)rows;
+    out.with_lut += has_lut[i] ? 1 : 0;
+    out.descs.push_back(d);
+    out.plane.push_back(i);
+    out.consumed++;
+    run += mine;
+  }
+  out.total = (uint32_t)run;
+  const size_t nd = out.descs.size();
+  out.uniform = nd > 0;
+  for (size_t k = 1; k < nd; k++)
+    if (out.descs[k].tiles != out.descs[0].tiles || out.descs[k].rows != out.descs[0].rows)
+      out.uniform = 0;
+  out.per_plane = out.uniform ? out.descs[0].tiles * out.descs[0].rows : 0;
+  out.pp = magic_div(out.per_plane);
+  for (int k = 0; k < kBatchChain; k++)
+    out.first8[k] = (size_t)k < nd ? out.descs[k].first : 0xFFFFFFFFu;
+}
+
+// Where tile `w` of a launch lies: the kernel's own arithmetic (k_i16_batch), kept here so that the CPU test walks it.
+struct BatchWhere
+{
+  uint32_t p, row, tile;
+};
+inline BatchWhere batch_locate(const BatchDesc *descs, uint32_t n, uint32_t uniform, MagicDiv pp, const uint32_t *first8, uint32_t w)
+{
+  uint32_t p;
+  if (uniform)
+    p = magic_apply(w, pp.m, pp.s);
+  else if (n <= (uint32_t)kBatchChain)
+  {
+    p = 0;
+    for (int i = 1; i < kBatchChain; i++)
+      p += w >= first8[i] ? 1 : 0;
+  }
+  else
+  { // last plane whose first tile is <= w
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1)
+    {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (descs[mid].first <= w)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    p = lo;
+  }
+  const BatchDesc &d = descs[p];
+  const uint32_t lt = w - d.first;
+  const uint32_t row = magic_apply(lt, d.tiles_m, d.tiles_s);
+  return BatchWhere{p, row, lt - row * d.tiles};
+}
+
+} // namespace mdct
+#endif

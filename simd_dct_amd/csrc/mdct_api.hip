@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "mdct.h"
 #include "mdct_kernels.h"
@@ -321,6 +322,114 @@ int run_f32(int mode, const float *from, float *to, size_t pitch_in, size_t pitc
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "f32 kernel launch");
 }
 
+
+// ---- plane batches (mdct_*_i16_batch, mdct_batch_*): validation, table de-duplication, argument blocks ---------------
+struct BatchInput
+{
+  std::vector<mdct::OwnTables> tables; // distinct tables of the whole list
+  std::vector<int> table_id;           // per plane: index into `tables`, -1 = takes no table slot
+  std::vector<unsigned char> has_lut;  // per plane: a quantisation table was given
+  std::vector<unsigned char> bounded;  // per plane: lut_bounded()
+};
+
+int batch_input(int mode, const mdct_plane_i16 *planes, int n, BatchInput &in)
+{
+  if (mode != mdct::MODE_FWD && mode != mdct::MODE_INV && mode != mdct::MODE_ROUNDTRIP)
+    return fail(MDCT_INVALID_PARAMETER, "batch mode %d (MDCT_MODE_FWD / _INV / _ROUNDTRIP)", mode);
+  if (n < 0 || (planes == nullptr && n > 0))
+    return fail(MDCT_INVALID_PARAMETER, "null plane list");
+  const bool rt = mode == mdct::MODE_ROUNDTRIP;
+  in.table_id.assign(n, -1);
+  in.has_lut.assign(n, 0);
+  in.bounded.assign(n, 0);
+  std::vector<const float *> src; // what each distinct table was made from (nullptr = no quantisation)
+  for (int i = 0; i < n; i++)
+  { // validate everything before launching anything
+    const mdct_plane_i16 &p = planes[i];
+    int r = own_plane_args(p.from, p.to, sizeof(int16_t), p.pitch_in, p.pitch_out, p.sizeX, p.sizeY, 0, p.sizeY / 8);
+    if (r)
+      return r;
+    in.has_lut[i] = p.lut != nullptr;
+    in.bounded[i] = lut_bounded(p.lut);
+    if (rt && !p.lut)
+      continue; // the fused round trip without a table needs no multipliers at all (1/64 rides in the rounding)
+    int id = -1;
+    for (size_t k = 0; k < src.size() && id < 0; k++)
+      if (src[k] == p.lut || (src[k] && p.lut && memcmp(src[k], p.lut, 64 * sizeof(float)) == 0))
+        id = (int)k;
+    if (id < 0)
+    {
+      mdct::OwnTables tb;
+      if ((r = make_own_tables(p.lut, tb, /*pair_order=*/rt)))
+        return r;
+      id = (int)src.size();
+      src.push_back(p.lut);
+      in.tables.push_back(tb);
+    }
+    in.table_id[i] = id;
+  }
+  return MDCT_SUCCESS;
+}
+
+struct BatchLaunch
+{
+  mdct::BatchArgs args;
+  uint32_t total;
+  int lutmode;
+  bool sat;
+};
+
+// header of the argument block from a layout; descriptors / tables are attached by the caller (embedded or device memory)
+void batch_header(const mdct::BatchLayout &lay, const BatchInput &in, BatchLaunch &l)
+{
+  mdct::BatchArgs &a = l.args;
+  a.consts = mdct::DctConsts();
+  a.n = (uint32_t)lay.descs.size();
+  a.uniform = lay.uniform;
+  a.per_plane = lay.per_plane;
+  a.pp_m = lay.pp.m;
+  a.pp_s = lay.pp.s;
+  a.table_bytes = (uint32_t)(lay.tables.size() * sizeof(mdct::OwnTables));
+  memcpy(a.first8, lay.first8, sizeof(a.first8));
+  a.descs = nullptr;
+  a.tables = nullptr;
+  l.total = lay.total;
+  l.lutmode = lay.with_lut == 0 ? mdct::BATCH_NO_LUT : (lay.with_lut == (int)lay.descs.size() ? mdct::BATCH_ALL_LUT : mdct::BATCH_MIXED);
+  bool all_bounded = true;
+  for (int i : lay.plane)
+    all_bounded = all_bounded && in.bounded[i];
+  l.sat = !all_bounded;
+}
+
+// no allocation on the device, no copy: descriptors and tables travel in the kernel arguments, as many planes per launch as fit
+int run_i16_batch(int mode, const mdct_plane_i16 *planes, int n, void *stream)
+{
+  BatchInput in;
+  int r = batch_input(mode, planes, n, in);
+  if (r)
+    return r;
+  const mdct_device_info *di;
+  if ((r = current(&di)))
+    return r;
+  for (int i0 = 0; i0 < n;)
+  {
+    mdct::BatchLayout lay;
+    mdct::batch_layout(planes, in.table_id.data(), in.has_lut.data(), i0, n, mdct::kBatchBlob, sizeof(mdct::OwnTables), lay);
+    if (lay.consumed == 0)
+      return fail(MDCT_NOT_SUPPORTED, "plane %d (%zux%zu) exceeds the 2^31 tile limit of one launch; split it", i0, planes[i0].sizeX, planes[i0].sizeY);
+    i0 += lay.consumed;
+    BatchLaunch l;
+    batch_header(lay, in, l);
+    for (size_t k = 0; k < lay.tables.size(); k++)
+      memcpy(l.args.blob + k * sizeof(mdct::OwnTables), &in.tables[lay.tables[k]], sizeof(mdct::OwnTables));
+    memcpy(l.args.blob + l.args.table_bytes, lay.descs.data(), lay.descs.size() * sizeof(mdct::BatchDesc));
+    const hipError_t e = mdct::launch_i16_batch(l.args, l.total, mode, l.lutmode, l.sat, (hipStream_t)stream);
+    if (e != hipSuccess)
+      return hip_fail(e, "plane batch launch");
+  }
+  return MDCT_SUCCESS;
+}
+
 } // namespace
 
 extern "C" {
@@ -585,54 +694,113 @@ int mdct_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out
   return run_f32(mdct::MODE_INV, from, to, pitch_in, pitch_out, sizeX, sizeY, by0, by1, stream);
 }
 
-int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *stream)
+// the call BASELINE.json configs[2] is quoted on (Y + Cb + Cr, own tables): the fused round trip of a plane batch
+int mdct_roundtrip_i16_planes(const mdct_plane_i16 *planes, int n_planes, void *stream) { return run_i16_batch(mdct::MODE_ROUNDTRIP, planes, n_planes, stream); }
+
+int mdct_fwd_i16_batch(const mdct_plane_i16 *planes, int n_planes, void *stream) { return run_i16_batch(mdct::MODE_FWD, planes, n_planes, stream); }
+int mdct_inv_i16_batch(const mdct_plane_i16 *planes, int n_planes, void *stream) { return run_i16_batch(mdct::MODE_INV, planes, n_planes, stream); }
+int mdct_roundtrip_i16_batch(const mdct_plane_i16 *planes, int n_planes, void *stream) { return run_i16_batch(mdct::MODE_ROUNDTRIP, planes, n_planes, stream); }
+
+// A batch whose descriptors and tables live in device memory: created once (allocates, copies, synchronous), run any
+// number of times as ONE launch each (grid limit permitting), capture-safe.
+struct mdct_batch
 {
-  if (planes == nullptr || n_planes < 0)
-    return fail(MDCT_INVALID_PARAMETER, "null plane list");
-  // validate everything before launching anything
-  int r = MDCT_SUCCESS;
-  for (int i = 0; i < n_planes; i++)
-  {
-    const mdct_plane_i16 &p = planes[i];
-    if ((r = own_plane_args(p.from, p.to, sizeof(int16_t), p.pitch_in, p.pitch_out, p.sizeX, p.sizeY, 0, p.sizeY / 8)))
-      return r;
-  }
+  int mode = 0, device = 0, n_planes = 0;
+  void *dev = nullptr;
+  std::vector<BatchLaunch> launches;
+};
+
+int mdct_batch_create(mdct_batch **out, int mode, const mdct_plane_i16 *planes, int n_planes)
+{
+  if (out == nullptr)
+    return fail(MDCT_INVALID_PARAMETER, "null batch handle");
+  *out = nullptr;
+  BatchInput in;
+  int r = batch_input(mode, planes, n_planes, in);
+  if (r)
+    return r;
   const mdct_device_info *di;
   if ((r = current(&di)))
     return r;
-  for (int base = 0; base < n_planes; base += mdct::kMaxPlanes)
+  mdct_batch *b = new mdct_batch;
+  b->mode = mode;
+  b->device = di->device;
+  b->n_planes = n_planes;
+  std::vector<unsigned char> image; // [tables of launch 0][descriptors of launch 0][tables of launch 1] ...
+  std::vector<size_t> at;           // where each launch's tables start in `image`
+  for (int i0 = 0; i0 < n_planes;)
   {
-    mdct::PlaneBatchArgs a;
-    memset(&a, 0, sizeof(a));
-    a.consts = mdct::DctConsts();
-    a.n = n_planes - base < mdct::kMaxPlanes ? n_planes - base : mdct::kMaxPlanes;
-    uint64_t run = 0;
-    bool all_bounded = true; // every plane has a table whose entries are all >= 8.01
-    for (int i = 0; i < a.n; i++)
+    mdct::BatchLayout lay;
+    mdct::batch_layout(planes, in.table_id.data(), in.has_lut.data(), i0, n_planes, 0, sizeof(mdct::OwnTables), lay);
+    if (lay.consumed == 0)
     {
-      const mdct_plane_i16 &p = planes[base + i];
-      a.from[i] = p.from;
-      a.to[i] = p.to;
-      a.pitch_in[i] = p.pitch_in;
-      a.pitch_out[i] = p.pitch_out;
-      a.bpr[i] = (uint32_t)(p.sizeX / 8);
-      if ((r = count_blocks(p.sizeX / 8, p.sizeY / 8, &a.nblk[i])))
-        return r;
-      a.prefix[i] = (uint32_t)run;
-      run += ((uint64_t)a.nblk[i] + 63) / 64 * 64;
-      if (run > 0x7FFFFFFFull)
-        return fail(MDCT_NOT_SUPPORTED, "plane batch exceeds the 2^31 block limit");
-      a.has_lut[i] = p.lut != nullptr;
-      all_bounded = all_bounded && lut_bounded(p.lut);
-      if ((r = make_own_tables(p.lut, a.tb[i], true)))
-        return r;
+      delete b;
+      return fail(MDCT_NOT_SUPPORTED, "plane %d (%zux%zu) exceeds the 2^31 tile limit of one launch; split it", i0, planes[i0].sizeX, planes[i0].sizeY);
     }
-    a.prefix[a.n] = (uint32_t)run;
-    const hipError_t e = mdct::launch_i16_planes(a, (hipStream_t)stream, all_bounded);
+    i0 += lay.consumed;
+    if (lay.descs.empty())
+      continue;
+    BatchLaunch l;
+    batch_header(lay, in, l);
+    memset(l.args.blob, 0, sizeof(l.args.blob));
+    at.push_back(image.size());
+    for (int id : lay.tables)
+    {
+      const unsigned char *t = reinterpret_cast<const unsigned char *>(&in.tables[id]);
+      image.insert(image.end(), t, t + sizeof(mdct::OwnTables));
+    }
+    const unsigned char *d = reinterpret_cast<const unsigned char *>(lay.descs.data());
+    image.insert(image.end(), d, d + lay.descs.size() * sizeof(mdct::BatchDesc));
+    b->launches.push_back(l);
+  }
+  if (!image.empty())
+  {
+    hipError_t e = hipMalloc(&b->dev, image.size());
+    if (e == hipSuccess)
+      e = hipMemcpy(b->dev, image.data(), image.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+      if (b->dev)
+        (void)hipFree(b->dev);
+      delete b;
+      return hip_fail(e, "plane batch: descriptor table");
+    }
+    for (size_t k = 0; k < b->launches.size(); k++)
+    {
+      mdct::BatchArgs &a = b->launches[k].args;
+      unsigned char *base = static_cast<unsigned char *>(b->dev) + at[k];
+      a.tables = reinterpret_cast<const mdct::OwnTables *>(base);
+      a.descs = reinterpret_cast<const mdct::BatchDesc *>(base + a.table_bytes);
+    }
+  }
+  *out = b;
+  return MDCT_SUCCESS;
+}
+
+int mdct_batch_run(const mdct_batch *b, void *stream)
+{
+  if (b == nullptr)
+    return fail(MDCT_INVALID_PARAMETER, "null batch");
+  for (const BatchLaunch &l : b->launches)
+  {
+    const hipError_t e = mdct::launch_i16_batch(l.args, l.total, b->mode, l.lutmode, l.sat, (hipStream_t)stream);
     if (e != hipSuccess)
       return hip_fail(e, "plane batch launch");
   }
   return MDCT_SUCCESS;
+}
+
+int mdct_batch_launches(const mdct_batch *b) { return b ? (int)b->launches.size() : 0; }
+
+int mdct_batch_destroy(mdct_batch *b)
+{
+  if (b == nullptr)
+    return MDCT_SUCCESS;
+  hipError_t e = hipSuccess;
+  if (b->dev)
+    e = hipFree(b->dev);
+  delete b;
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "hipFree");
 }
 
 int mdct_stream_copy(const void *from, void *to, size_t bytes, void *stream)

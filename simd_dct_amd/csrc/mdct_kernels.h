@@ -8,13 +8,12 @@
 #include <stdint.h>
 
 #include "mdct.h"
+#include "batch_plan.h"
 
 namespace mdct
 {
 
 enum { MODE_FWD = 0, MODE_INV = 1, MODE_ROUNDTRIP = 2 };
-
-constexpr int kMaxPlanes = 4;
 
 // simd_dct.cpp:140-146: sqrt(2)*cos(k*pi/16) for k = 1,2,3,5,6,7 and 1/sqrt(8), as the
 // reference's float literals.  Passed by value in every argument block (see mdct_kernels.hip).
@@ -153,24 +152,33 @@ struct F32Args
   uint32_t bpr, by0, nblocks;
 };
 
-struct PlaneBatchArgs
+// ---- plane batches: any number of separately allocated int16 planes in one launch (k_i16_batch) ----------------------
+// One workgroup = one wave = one 64-block tile of one block row of one plane; the launch is a 1-D grid over the tiles of
+// all planes in order.  BatchDesc, the division-free index arithmetic and the host-side layout: batch_plan.h.
+// Descriptors and tables reach the kernel either embedded in the argument block (no allocation: mdct_*_i16_batch chunk their planes
+// so that a chunk fits `blob`) or from device memory (mdct_batch_*: uploaded once at creation, one launch for any number of planes).
+constexpr int kBatchBlob = 3584;
+struct BatchArgs
 {
-  const int16_t *from[kMaxPlanes];
-  int16_t *to[kMaxPlanes];
-  size_t pitch_in[kMaxPlanes], pitch_out[kMaxPlanes];
-  uint32_t bpr[kMaxPlanes];
-  uint32_t nblk[kMaxPlanes];       // real block count of each plane
-  uint32_t prefix[kMaxPlanes + 1]; // exclusive scan of the block counts padded to whole waves
-  uint32_t has_lut[kMaxPlanes];    // 0: plain fwd->inv, 1: quantise/dequantise in between
-  int n;
   DctConsts consts;
-  OwnTables tb[kMaxPlanes];
+  uint32_t n;              // planes in the launch
+  uint32_t uniform;        // every plane has the same tile grid: plane = tile index / per_plane
+  uint32_t per_plane;      // tiles per plane when uniform
+  uint32_t pp_m, pp_s;     // MagicDiv of per_plane
+  uint32_t table_bytes;    // embedded form: descriptors start at blob + table_bytes
+  uint32_t first8[kBatchChain]; // `first` of planes 0..7 (UINT32_MAX beyond n)
+  const BatchDesc *descs;  // device memory, or nullptr: embedded
+  const OwnTables *tables; // device memory, or nullptr: embedded (blob)
+  alignas(64) unsigned char blob[kBatchBlob]; // [tables][descriptors]
 };
+static_assert(sizeof(BatchArgs) <= 4096, "kernel argument block");
+enum { BATCH_NO_LUT = 0, BATCH_ALL_LUT = 1, BATCH_MIXED = 2 };
+// total: tiles in the launch; lutmode / sat matter for MODE_ROUNDTRIP only
+hipError_t launch_i16_batch(const BatchArgs &a, uint32_t total, int mode, int lutmode, bool sat, hipStream_t s);
 
 hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool safe, hipStream_t s);
 // lut_bounded / luts_bounded: every entry of every table >= 8.01 in magnitude (a quantised coefficient cannot leave int16)
 hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s, bool lut_bounded = false);
-hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s, bool luts_bounded = false);
 hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s);
 hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s, bool clamp = true);
 hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, bool clamp, uint32_t n_rows, hipStream_t s);

@@ -150,7 +150,6 @@ struct PkConsts
   f32x2 da, fd, fc, ca; // K_TRUE only: (Cd,Ca) (Cf,Cd) (Cf,Cc) (Cc,Ca)
   f32x2 bias;           // SSE tiers: (1/255, 127.0f);  scalar tiers: (127/255, 255.0f)
 };
-static_assert(kMaxPlanes == 4, "k_i16_planes switches over four plane slots");
 static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernels.h) is the kernel-argument image of PkConsts");
 
 // Phase priorities (template flag PRIO of the block functions): a wave raises its issue priority as it advances through its
@@ -1222,8 +1221,8 @@ __device__ __forceinline__ void store_i16x8(const DctConsts &C, int16_t *dst, co
   st_stream16(dst, pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
 }
 
-template <int MODE, bool HAS_LUT, class Rows>
-__device__ __forceinline__ void i16_block(const DctConsts &C, const Rows rows, const OwnTables &tb)
+template <int MODE, bool HAS_LUT, class Rows, class Tables>
+__device__ __forceinline__ void i16_block(const DctConsts &C, const Rows rows, const Tables &tb)
 {
   float b[8][8];
 #pragma unroll
@@ -1395,28 +1394,32 @@ __device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, 
 // the waves sharing a SIMD the one closest to its stores goes first (shortest remaining work first)
 // SAT = false (decided on the host: every table entry >= 8.01): a quantised coefficient cannot leave int16 -- an orthonormal 8x8
 // DCT coefficient of int16 samples is at most 8 * 32768 in magnitude -- so the two saturations per coefficient pair are left out.
+// tbp: where the plane's OwnTables lie -- in the kernel's argument segment (karg_bytes) or in device memory (const_bytes); read with
+// scalar loads either way
+typedef const __attribute__((address_space(4))) char *kbytes_t;
 template <bool HAS_LUT, class Rows, bool PRIO = false, bool SAT = true>
-__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, size_t tb_off);
-
-// tb_off: where the plane's OwnTables lie in the kernel's argument segment
-template <bool HAS_LUT>
-__device__ __forceinline__ void i16_roundtrip_pk(const DctConsts &C, const int16_t *src, int16_t *dst, size_t pitch_in, size_t pitch_out, size_t tb_off)
-{
-  i16_roundtrip_rows<HAS_LUT>(C, RowsLinear{src, dst, pitch_in, pitch_out}, tb_off);
-}
+__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, kbytes_t tbp);
 
 // The two tables are 128 multiplier pairs = 256 SGPRs if the compiler is left to fetch them when it likes -- it fetches
 // them all at the top and spills (252 v_readlane + 124 v_writelane per wave, 1451 vector instructions instead of ~1000).
 // So the pairs of column pair j are read from the argument segment through a pointer the compiler cannot see through,
 // right where they are used: two s_load_dwordx16 per j, 32 SGPRs live (mdct_api.hip lays the tables out j-major for this).
 typedef const __attribute__((address_space(4))) f32x2 *karg_pairs_t;
-__device__ __forceinline__ karg_pairs_t karg_pairs(size_t byte_off)
+__device__ __forceinline__ kbytes_t karg_bytes(size_t byte_off) { return (kbytes_t)__builtin_amdgcn_kernarg_segment_ptr() + byte_off; }
+__device__ __forceinline__ karg_pairs_t karg_pairs(size_t byte_off) { return (karg_pairs_t)karg_bytes(byte_off); }
+// a wave-uniform device address as a constant-address-space pointer (scalar loads; the memory must not change during the launch)
+__device__ __forceinline__ kbytes_t const_bytes(const void *p)
 {
-  return (karg_pairs_t)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + byte_off);
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (kbytes_t)(((uint64_t)hi << 32) | lo);
 }
 
+// (A wave that walks 2 / 4 / 8 consecutive tiles and issues the next tile's row loads between the row pass and the column pass,
+// into the registers the row pass has just freed, was measured on the bench workload: 44.8-45.4 / 52.2 / 51.4 us against 43.8,
+// profiles/r04_exp_i16_tiles_per_wave.log -- one tile per wave it stays.)
 template <bool HAS_LUT, class Rows, bool PRIO, bool SAT>
-__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, size_t tb_off)
+__device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Rows rows, kbytes_t tbp)
 {
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
   uint4 in[8];
@@ -1441,7 +1444,7 @@ __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Row
     aan_fwd_v(K, P[j]);
     if constexpr (HAS_LUT)
     { // c = sat_i16(rne(y * qf)); z = c * dq  (rne_i16_float), on both halves
-      karg_pairs_t tq = karg_pairs(tb_off + offsetof(OwnTables, qf)) + j * 8, td = karg_pairs(tb_off + offsetof(OwnTables, dq)) + j * 8;
+      karg_pairs_t tq = (karg_pairs_t)(tbp + offsetof(OwnTables, qf)) + j * 8, td = (karg_pairs_t)(tbp + offsetof(OwnTables, dq)) + j * 8;
       asm volatile("" : "+s"(tq), "+s"(td));
 #pragma unroll
       for (int v = 0; v < 8; v++)
@@ -1503,7 +1506,7 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
   const int16_t *src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
   int16_t *dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
   if constexpr (MODE == MODE_ROUNDTRIP)
-    i16_roundtrip_rows<HAS_LUT, RowsLinear, false, SAT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, offsetof(I16Args, tb));
+    i16_roundtrip_rows<HAS_LUT, RowsLinear, false, SAT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, karg_bytes(offsetof(I16Args, tb)));
   else
     i16_block<MODE, HAS_LUT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, a.tb);
 }
@@ -1523,9 +1526,78 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(i16_tile_wav
   const size_t by = a.by0 + blockIdx.y;
   const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
   if constexpr (MODE == MODE_ROUNDTRIP)
-    i16_roundtrip_rows<HAS_LUT, RowsTiled, true, SAT>(a.consts, rows, offsetof(I16Args, tb)); // with phase priorities
+    i16_roundtrip_rows<HAS_LUT, RowsTiled, true, SAT>(a.consts, rows, karg_bytes(offsetof(I16Args, tb))); // with phase priorities
   else
     i16_block<MODE, HAS_LUT>(a.consts, rows, a.tb);
+}
+
+// Any number of separately allocated planes in ONE launch (BASELINE.json configs[2]: Y + Cb + Cr with their own tables; configs[3]:
+// 256 independent planes).  The reference's only batching affordance is the caller-side row range (simd_dct.cpp:2243-2261); this is
+// the engine's: a 1-D grid over the 64-block tiles of all planes in order, one wave per tile with k_i16_tile's wave-uniform
+// addressing.  A wave finds its plane without a division (equal shapes: magic multiply; up to 8 different shapes: a compare chain
+// on kernel arguments; more: a binary search with scalar loads), reads the plane's 64-byte descriptor and its tables with scalar
+// loads, and a row's last tile may be partial (1920- and 3840-wide planes are 240 / 480 blocks per row): lanes beyond the row
+// leave at once -- nothing below crosses lanes.
+__device__ __forceinline__ uint32_t magic_quot(uint32_t n, uint32_t m, uint32_t s)
+{
+  const uint32_t t = __umulhi(n, m);
+  return (t + ((n - t) >> (s & 0xFF))) >> (s >> 8);
+}
+typedef const __attribute__((address_space(4))) BatchDesc *kdesc_t;
+typedef const __attribute__((address_space(4))) OwnTables *ktables_t;
+
+// Scheduling steered per mode like k_i16_tile; measured on the 8K 4:2:0 frame and on batches of one (profiles/r04_exp_batch_variants.log):
+// the fused round trip with phase priorities at 3 waves per SIMD (frame 38.0 us against 40.3 at 2, 8192^2 45.3 against 46.0-46.5),
+// forward and inverse at 2 (8192^2 forward 44.2-44.4 against 44.8-45.0 at 3 and 46.2 at 4).
+constexpr int batch_waves(int mode) { return mode == MODE_ROUNDTRIP ? 3 : 2; }
+template <int MODE, int LUTMODE, bool SAT = true>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(batch_waves(MODE), batch_waves(MODE)))) void k_i16_batch(BatchArgs a)
+{
+  const uint32_t w = blockIdx.x;
+  const kbytes_t blob = karg_bytes(offsetof(BatchArgs, blob));
+  const kdesc_t descs = a.descs ? (kdesc_t)const_bytes(a.descs) : (kdesc_t)(blob + a.table_bytes);
+  const kbytes_t tables = a.tables ? const_bytes(a.tables) : blob;
+  uint32_t p;
+  if (a.uniform)
+    p = magic_quot(w, a.pp_m, a.pp_s);
+  else if (a.n <= kBatchChain)
+  {
+    p = 0;
+#pragma unroll
+    for (int i = 1; i < kBatchChain; i++)
+      p += w >= a.first8[i] ? 1 : 0;
+  }
+  else
+  { // last plane whose first tile is <= w
+    uint32_t lo = 0, hi = a.n;
+    while (hi - lo > 1)
+    {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (descs[mid].first <= w)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    p = lo;
+  }
+  const __attribute__((address_space(4))) BatchDesc &d = descs[p];
+  const uint32_t lt = w - d.first;
+  const uint32_t row = magic_quot(lt, d.tiles_m, d.tiles_s);
+  const uint32_t tile = lt - row * d.tiles;
+  if (tile * 64 + threadIdx.x >= d.bpr)
+    return;
+  const size_t pin = d.pitch_in, pout = d.pitch_out;
+  const RowsTiled rows{d.from + (size_t)row * 8 * pin + (size_t)tile * 512, d.to + (size_t)row * 8 * pout + (size_t)tile * 512, pin, pout, threadIdx.x * 16};
+  const kbytes_t tbp = tables + d.table;
+  if constexpr (MODE == MODE_ROUNDTRIP)
+  {
+    if (LUTMODE == BATCH_ALL_LUT || (LUTMODE == BATCH_MIXED && d.has_lut))
+      i16_roundtrip_rows<true, RowsTiled, true, SAT>(a.consts, rows, tbp);
+    else
+      i16_roundtrip_rows<false, RowsTiled, true>(a.consts, rows, nullptr);
+  }
+  else
+    i16_block<MODE, true>(a.consts, rows, *(ktables_t)tbp);
 }
 
 // 8-bit pixels <-> int16 coefficients (JPEG-style pair): u8 rows are 8 B per lane (512 B per wave
@@ -1894,50 +1966,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
   }
 }
 
-// Several planes (each with its own table) in one launch: linear block index over the
-// concatenation of the planes; prefix[] is the exclusive scan of per-plane block counts.
-// LUTMODE: 0 no plane has a table, 1 every plane has one, 2 mixed (branch per wave)
-#ifndef MDCT_PLANES_WAVES
-#define MDCT_PLANES_WAVES 3
-#endif
-template <int LUTMODE, int WG = kWG, int WAVES = MDCT_PLANES_WAVES, bool PRIO = false, bool SAT = true>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_i16_planes(PlaneBatchArgs a)
-{
-  const uint32_t t = blockIdx.x * WG + threadIdx.x;
-  // plane index from the wave's first block: wave-uniform, so the table reads stay scalar
-  const uint32_t tw = __builtin_amdgcn_readfirstlane(t - (threadIdx.x & 63));
-  if (tw >= a.prefix[a.n])
-    return;
-  int p = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxPlanes; i++)
-    p += (i < a.n && tw >= a.prefix[i]) ? 1 : 0;
-  const uint32_t lt = t - a.prefix[p];
-  if (lt >= a.nblk[p])
-    return;
-  const uint32_t bpr = a.bpr[p];
-  const uint32_t row = lt / bpr;
-  const uint32_t bx = lt - row * bpr;
-  const size_t pin = a.pitch_in[p], pout = a.pitch_out[p];
-  // p is wave-uniform (planes are padded to whole waves): scalar table reads, scalar branch
-  const int16_t *src = a.from[p] + (size_t)row * 8 * pin + (size_t)bx * 8;
-  int16_t *dst = a.to[p] + (size_t)row * 8 * pout + (size_t)bx * 8;
-  if (LUTMODE == 1 || (LUTMODE == 2 && a.has_lut[p]))
-  { // One copy of the packed round trip per plane slot, chosen by a scalar branch: with a STATIC table address the
-    // 128 multiplier pairs arrive in a few batched scalar loads; indexed by p at run time they became 69 separate
-    // s_load_dwordx2 with a wait each (41.6-45 us instead of 36-38 on the 4:2:0 frame, profiles/r02_planes_waves.log).
-    switch (p)
-    {
-    case 0: i16_roundtrip_rows<true, RowsLinear, PRIO, SAT>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 0 * sizeof(OwnTables)); break;
-    case 1: i16_roundtrip_rows<true, RowsLinear, PRIO, SAT>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 1 * sizeof(OwnTables)); break;
-    case 2: i16_roundtrip_rows<true, RowsLinear, PRIO, SAT>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 2 * sizeof(OwnTables)); break;
-    default: i16_roundtrip_rows<true, RowsLinear, PRIO, SAT>(a.consts, RowsLinear{src, dst, pin, pout}, offsetof(PlaneBatchArgs, tb) + 3 * sizeof(OwnTables)); break;
-    }
-  }
-  else
-    i16_roundtrip_rows<false, RowsLinear, PRIO>(a.consts, RowsLinear{src, dst, pin, pout}, 0);
-}
-
 // float32 rows are 32 B per block: if every lane fetched its own 2 x 16 B, each wave load would
 // touch 64 x 16 B at a 32-byte stride (half of every cache line per instruction).  When the
 // wave's 64 blocks are one contiguous 2 KiB row segment (plane width % 512 == 0) the WIDE form
@@ -2243,31 +2271,25 @@ hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s, b
   return hipErrorInvalidValue;
 }
 
-template <int WG, int WAVES, bool PRIO>
-static void launch_i16_planes_v(const PlaneBatchArgs &a, int with, uint32_t total, bool luts_bounded, hipStream_t s)
+hipError_t launch_i16_batch(const BatchArgs &a, uint32_t total, int mode, int lutmode, bool sat, hipStream_t s)
 {
-  const dim3 grid((total + WG - 1) / WG), wg(WG);
-  if (with == 0)
-    hipLaunchKernelGGL((k_i16_planes<0, WG, WAVES, PRIO>), grid, wg, 0, s, a);
-  else if (with == a.n && luts_bounded)
-    hipLaunchKernelGGL((k_i16_planes<1, WG, WAVES, PRIO, false>), grid, wg, 0, s, a);
-  else if (with == a.n)
-    hipLaunchKernelGGL((k_i16_planes<1, WG, WAVES, PRIO>), grid, wg, 0, s, a);
-  else
-    hipLaunchKernelGGL((k_i16_planes<2, WG, WAVES, PRIO>), grid, wg, 0, s, a);
-}
-
-hipError_t launch_i16_planes(const PlaneBatchArgs &a, hipStream_t s, bool luts_bounded)
-{
-  const uint32_t total = a.prefix[a.n];
   if (total == 0)
     return hipSuccess;
-  int with = 0;
-  for (int i = 0; i < a.n; i++)
-    with += a.has_lut[i] ? 1 : 0;
-  // one-wave workgroups, 3 waves per SIMD, no phase priorities: the best of seven combinations by 1-2 % on the single 8192^2
-  // plane and on the 8K 4:2:0 frame (64 / 256 threads x 2 / 3 waves x priorities on / off, profiles/r03_exp_planes_variants.log)
-  launch_i16_planes_v<64, 3, false>(a, with, total, luts_bounded, s);
+  const dim3 g(total), b(64);
+  if (mode == MODE_FWD)
+    hipLaunchKernelGGL((k_i16_batch<MODE_FWD, BATCH_ALL_LUT>), g, b, 0, s, a);
+  else if (mode == MODE_INV)
+    hipLaunchKernelGGL((k_i16_batch<MODE_INV, BATCH_ALL_LUT>), g, b, 0, s, a);
+  else if (mode != MODE_ROUNDTRIP)
+    return hipErrorInvalidValue;
+  else if (lutmode == BATCH_NO_LUT)
+    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_NO_LUT>), g, b, 0, s, a);
+  else if (lutmode == BATCH_ALL_LUT && !sat)
+    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_ALL_LUT, false>), g, b, 0, s, a);
+  else if (lutmode == BATCH_ALL_LUT)
+    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_ALL_LUT>), g, b, 0, s, a);
+  else
+    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_MIXED>), g, b, 0, s, a);
   return hipGetLastError();
 }
 

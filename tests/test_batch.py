@@ -1,0 +1,290 @@
+"""Plane batches (mdct_*_i16_batch, mdct_batch_*): any number of separately allocated planes per call.
+
+CPU: the host half (csrc/batch_plan.h) under ASan + UBSan -- every tile index of a laid-out launch walked through the
+kernel's own index arithmetic -- and the status codes that are decided before a device is touched.
+GPU (-m gpu): the batch entry points against the oracle and against the single-plane entry points on the same planes;
+BASELINE.json configs[2] (8K 4:2:0 frame, one call) and configs[3] (256 separately allocated 4096x4096 planes, forward)
+at full size.  The reference's only batching affordance is the caller-side row range, simd_dct.cpp:2243-2261."""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as G
+from simd_dct_amd import _lib, api, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_batch_layout_and_index_arithmetic_under_sanitizers(tmp_path):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "batch_plan"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "simd_dct_amd", "csrc"), os.path.join(ROOT, "tests", "batch_plan_driver.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in (r.stderr + r.stdout).lower() and "cannot find" in (r.stderr + r.stdout).lower():
+        pytest.skip("sanitizer runtime not installed: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "batch plan ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_kernel_and_host_share_the_layout_header():
+    """the kernel's plane lookup is the arithmetic the CPU test walked: one header, no second copy of the descriptor"""
+    k = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "mdct_kernels.h")).read()
+    assert '#include "batch_plan.h"' in k and "struct BatchDesc" not in k
+    hdr = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "batch_plan.h")).read()
+    code = "\n".join(l.split("//")[0] for l in hdr.splitlines())
+    assert "hip" not in code.lower()  # builds with plain g++
+    api_src = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "mdct_api.hip")).read()
+    assert "mdct::batch_layout(" in api_src
+
+
+def test_batch_status_codes_without_device():
+    G.build_hip()
+    lib = _lib.load()
+    b = np.zeros(64 * 16, dtype=np.int16)
+    ok = (b, b, 64, 16, None)
+    for mode in ("fwd", "inv", "roundtrip"):
+        assert api.i16_batch(mode, [ok, (b, None, 64, 16, None)], check=False) == 1  # null plane pointer: nothing launched
+        assert api.i16_batch(mode, [ok, (b, b, 60, 16, None)], check=False) == 2  # not a multiple of 8x8
+        assert api.i16_batch(mode, [ok, (b[1:], b, 64, 8, None)], check=False) == 1  # rows not 16-byte aligned
+        assert api.i16_batch(mode, [(b, b, 64, 16, None, 32, 64)], check=False) == 1  # pitch below the width
+        bad = np.ones(64, dtype=np.float32)
+        bad[5] = 0.0
+        assert api.i16_batch(mode, [ok, (b, b, 64, 16, bad)], check=False) == 1  # zero table entry
+        assert "table" in api.last_error()
+    assert lib.mdct_fwd_i16_batch(None, 2, None) == 1
+    assert lib.mdct_fwd_i16_batch(None, -1, None) == 1
+    h = ctypes.c_void_p()
+    arr, _keep = api._plane_array([ok])
+    assert lib.mdct_batch_create(ctypes.byref(h), 7, arr, 1) == 1 and not h  # unknown mode
+    assert lib.mdct_batch_create(None, 0, arr, 1) == 1
+    assert lib.mdct_batch_run(None, None) == 1
+    assert lib.mdct_batch_destroy(None) == 0 and lib.mdct_batch_launches(None) == 0
+
+
+# ----------------------------------------------------------------------------------------------- GPU
+gpu = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cuda():
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    torch.cuda.set_device(0)
+    api.init(0)
+    return torch
+
+
+def _lut(scale):
+    return (api.QUANTIZE_BASE * np.float32(scale)).astype(np.float32)
+
+
+CANARY = -21846
+
+
+def _planes(torch, shapes, luts, pad=0, seed0=0):
+    """separately allocated planes; pad > 0: pitched rows whose padding must survive"""
+    import oracle as O  # noqa: F401
+
+    srcs, d_in, d_out = [], [], []
+    for i, (w, h) in enumerate(shapes):
+        s = synth.plane_i16_np(w, h, "photo", seed=synth.SEED + seed0 + i, bits=12 if i % 2 else 8)
+        if pad:
+            full = np.full((h, w + pad), 1234, dtype=np.int16)
+            full[:, :w] = s
+            s = full
+        srcs.append(s)
+        d_in.append(torch.from_numpy(s).cuda())
+        d_out.append(torch.full((h, w + pad), CANARY, dtype=torch.int16, device="cuda"))
+    desc = [(a, b, w, h, l, w + pad, w + pad) for a, b, (w, h), l in zip(d_in, d_out, shapes, luts)]
+    return srcs, d_in, d_out, desc
+
+
+def _check_against_oracle(mode, srcs, d_out, shapes, luts, pad, tag):
+    import oracle as O
+
+    for i, (s, o, (w, h), l) in enumerate(zip(srcs, d_out, shapes, luts)):
+        got = o.cpu().numpy()
+        want = O.i16(mode, np.ascontiguousarray(s[:, :w]), w, h, lut=l)
+        assert np.array_equal(got[:, :w], want), (tag, mode, i, w, h)
+        if pad:
+            assert (got[:, w:] == CANARY).all(), (tag, mode, i, "padding written")
+
+
+@gpu
+@pytest.mark.parametrize("mode", ["fwd", "inv", "roundtrip"])
+def test_batch_mixed_shapes_match_oracle(cuda, mode):
+    """widths that are not multiples of 512 px (partial last tile), one-block planes, shared / distinct / no tables, pitched rows:
+    the no-allocation call and the device-table batch give the oracle's planes and leave everything else alone"""
+    torch = cuda
+    shapes = [(1920, 64), (8, 8), (72, 24), (520, 16), (512, 8), (200, 40), (3840, 16), (1024, 32)]
+    l30, l60 = _lut(30), _lut(60)
+    for luts, pad in (([None] * 8, 0), ([l30, l60, l60, None, l30, _lut(10), None, l60], 24), ([l30] * 8, 8)):
+        for form in ("args", "device"):
+            srcs, d_in, d_out, desc = _planes(torch, shapes, luts, pad)
+            if form == "args":
+                api.i16_batch(mode, desc)
+            else:
+                b = api.Batch(mode, desc)
+                assert b.launches == 1
+                b.run()
+                b.run()  # repeatable
+                b.close()
+            torch.cuda.synchronize()
+            _check_against_oracle(mode, srcs, d_out, shapes, luts, pad, form)
+
+
+@gpu
+def test_batch_more_shapes_than_the_compare_chain_and_more_planes_than_one_argument_block(cuda):
+    """> 8 different shapes: binary search over the descriptors; 130 planes with 5 tables: several launches of the
+    no-allocation call (a chunk ends where tables + descriptors would outgrow the argument block), one of the device batch"""
+    torch = cuda
+    rng = np.random.default_rng(11)
+    shapes = [(8 * int(rng.integers(1, 160)), 8 * int(rng.integers(1, 6))) for _ in range(130)]
+    tabs = [_lut(s) for s in (8, 20, 50, 90, 140)]
+    luts = [tabs[i % 5] if i % 7 else None for i in range(130)]
+    for mode in ("fwd", "roundtrip"):
+        for form in ("args", "device"):
+            srcs, d_in, d_out, desc = _planes(torch, shapes, luts, 8, seed0=500)
+            if form == "args":
+                api.i16_batch(mode, desc)
+            else:
+                b = api.Batch(mode, desc)
+                assert b.launches == 1
+                b.run()
+            torch.cuda.synchronize()
+            _check_against_oracle(mode, srcs, d_out, shapes, luts, 8, form)
+
+
+@gpu
+def test_batch_of_equal_planes_equals_the_single_plane_calls(cuda):
+    """equal shapes take the division-free plane index; 96 separately allocated 520 x 72 planes (65 blocks per row: the second
+    tile of every row holds one block), all three modes, against mdct_*_i16 plane by plane"""
+    torch = cuda
+    shapes = [(520, 72)] * 96
+    lut = _lut(25)
+    for mode, single in (("fwd", api.fwd_i16), ("inv", api.inv_i16), ("roundtrip", api.roundtrip_i16)):
+        for luts in ([None] * 96, [lut] * 96):
+            srcs, d_in, d_out, desc = _planes(torch, shapes, luts, 0, seed0=900)
+            b = api.Batch(mode, desc)
+            b.run()
+            for i in range(96):
+                want = torch.empty_like(d_in[i])
+                single(d_in[i], want, 520, 72, lut=luts[i])
+                assert torch.equal(want, d_out[i]), (mode, i)
+            d_out2 = [torch.full_like(t, CANARY) for t in d_out]
+            api.i16_batch(mode, [(a, o, w, h, l) for (a, _, w, h, l, _, _), o in zip(desc, d_out2)])
+            for a, c in zip(d_out, d_out2):
+                assert torch.equal(a, c), mode
+
+
+@gpu
+def test_batch_is_graph_capturable(cuda):
+    torch = cuda
+    shapes = [(1920, 32), (960, 16), (960, 16)]
+    luts = [_lut(30), _lut(60), _lut(60)]
+    srcs, d_in, d_out, desc = _planes(torch, shapes, luts)
+    b = api.Batch("roundtrip", desc)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        b.run(stream=s)  # warm
+        api.i16_batch("roundtrip", desc, stream=s)
+    s.synchronize()
+    for o in d_out:
+        o.fill_(CANARY)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        b.run(stream=s)
+    g.replay()
+    torch.cuda.synchronize()
+    _check_against_oracle("roundtrip", srcs, d_out, shapes, luts, 0, "graph/device")
+    for o in d_out:
+        o.fill_(CANARY)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=s):
+        api.i16_batch("roundtrip", desc, stream=s)
+    g2.replay()
+    torch.cuda.synchronize()
+    _check_against_oracle("roundtrip", srcs, d_out, shapes, luts, 0, "graph/args")
+
+
+JPEG_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                      18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+JPEG_CHROMA = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.float32)
+
+
+@gpu
+def test_config3_frame_as_a_batch_equals_the_planes_call_and_the_oracle(cuda):
+    """configs[2] at full size: Y 7680x4320 + Cb/Cr 3840x2160 (480 blocks per row = 7.5 tiles) with the Annex-K tables, fused
+    round trip, ONE launch: the no-allocation call, the device batch and mdct_roundtrip_i16_planes agree byte for byte, each plane
+    equals the single-plane entry point, and the chroma plane the threaded oracle"""
+    import oracle as O
+
+    torch = cuda
+    shapes = [(7680, 4320), (3840, 2160), (3840, 2160)]
+    luts = [JPEG_LUMA, JPEG_CHROMA, JPEG_CHROMA]
+    d_in = [synth.plane_i16_torch(w, h, "photo", seed=synth.SEED + i) for i, (w, h) in enumerate(shapes)]
+    outs = {}
+    for form in ("args", "device", "planes"):
+        d_out = [torch.full_like(t, CANARY) for t in d_in]
+        desc = [(a, b, w, h, l) for a, b, (w, h), l in zip(d_in, d_out, shapes, luts)]
+        if form == "args":
+            api.i16_batch("roundtrip", desc)
+        elif form == "device":
+            b = api.Batch("roundtrip", desc)
+            assert b.launches == 1
+            b.run()
+        else:
+            api.roundtrip_i16_planes(desc)
+        outs[form] = d_out
+    for i, ((w, h), l) in enumerate(zip(shapes, luts)):
+        single = torch.empty_like(d_in[i])
+        api.roundtrip_i16(d_in[i], single, w, h, lut=l)
+        for form in outs:
+            assert torch.equal(single, outs[form][i]), (form, i)
+    assert np.array_equal(outs["args"][1].cpu().numpy(), O.i16_par("roundtrip", d_in[1].cpu().numpy(), 3840, 2160, lut=JPEG_CHROMA))
+    # forward / inverse batches of the same frame compose to the fused call
+    coef = [torch.empty_like(t) for t in d_in]
+    api.i16_batch("fwd", [(a, c, w, h, l) for a, c, (w, h), l in zip(d_in, coef, shapes, luts)])
+    back = [torch.empty_like(t) for t in d_in]
+    api.i16_batch("inv", [(c, b, w, h, l) for c, b, (w, h), l in zip(coef, back, shapes, luts)])
+    for i in range(3):
+        assert torch.equal(back[i], outs["args"][i]), i
+
+
+@gpu
+def test_config4_256_separately_allocated_planes_forward_in_one_call(cuda):
+    """configs[3] on one GPU as the config words it: 256 INDEPENDENT 4096x4096 int16 planes (separate allocations, 8 GiB in,
+    8 GiB out), forward only.  One launch of the device batch, six of the no-allocation call; both equal the stacked single
+    launch (whose planes tests/test_gpu_parity.py compares with the oracle one by one), and two planes are checked against
+    the oracle here as well."""
+    import oracle as O
+
+    torch = cuda
+    W = H = 4096
+    n = 256
+    d_in = [synth.plane_i16_torch(W, H, "photo", seed=synth.SEED + 100 + p) for p in range(n)]
+    d_out = [torch.full((H, W), CANARY, dtype=torch.int16, device="cuda") for _ in range(n)]
+    desc = [(a, b, W, H, None) for a, b in zip(d_in, d_out)]
+    b = api.Batch("fwd", desc)
+    assert b.launches == 1
+    b.run()
+    torch.cuda.synchronize()
+    for p in (0, 255):
+        assert np.array_equal(d_out[p].cpu().numpy(), O.i16_par("fwd", d_in[p].cpu().numpy(), W, H)), p
+    want = torch.empty((H, W), dtype=torch.int16, device="cuda")
+    for p in range(n):
+        api.fwd_i16(d_in[p], want, W, H)
+        assert torch.equal(want, d_out[p]), p
+        d_out[p].fill_(CANARY)
+    api.i16_batch("fwd", desc)
+    for p in range(n):
+        api.fwd_i16(d_in[p], want, W, H)
+        assert torch.equal(want, d_out[p]), p
