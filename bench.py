@@ -346,6 +346,103 @@ def main():
                 extras[name] = r
             except Exception as e:
                 extras[name] = {"error": str(e)[:160]}
+        # ---- the other BASELINE.json configurations, each on its own entry point, pre-conditioned like the rest and verified in the
+        # run: the device output of the timed launches is hashed and compared with the SHA-256 the CPU checker's output has for the same
+        # synthetic planes (tests/golden/engine_own_sha256.json, written by tests/golden/make_engine_hashes.py; no oracle call here)
+        try:
+            own_sha = json.load(open(os.path.join(ROOT, "tests", "golden", "engine_own_sha256.json")))
+        except Exception:
+            own_sha = {}
+
+        def sha_of(t):
+            return hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+
+        # configs[2]: Y 7680x4320 + Cb/Cr 3840x2160, per-plane Annex-K tables, fused fwd -> quantise -> dequantise -> inv, ONE call
+        try:
+            frames = []
+            for f in range(NSETS):  # frame 0 = the planes the committed hashes belong to; the others only defeat the Infinity Cache
+                pl = []
+                for (w, h, so, tab) in synth.CONFIG3_PLANES:
+                    a = synth.plane_i16_torch(w, h, "photo", seed=synth.SEED + so + 10 * f)
+                    pl.append((a, torch.zeros_like(a), w, h, synth.JPEG_LUMA if tab == "luma" else synth.JPEG_CHROMA))
+                frames.append(pl)
+            fpx = sum(w * h for (w, h, _, _) in synth.CONFIG3_PLANES)
+            calls3 = [M.prepare_roundtrip_i16_planes(f) for f in frames]
+            r = rate(lambda i: calls3[i % NSETS](), 4 * fpx, n=500, warm=1500)
+            torch.cuda.synchronize()
+            want = own_sha.get("config3_420", {})
+            keys = [f"roundtrip__{w}x{h}__seed+{so}__{tab}" for (w, h, so, tab) in synth.CONFIG3_PLANES]
+            r["sha256_equals_cpu_checker"] = all(k in want and sha_of(frames[0][j][1]) == want[k] for j, k in enumerate(keys)) if want else "no committed hashes"
+            r["Mpx_s"] = round(fpx / (r["ms"] * 1e-3) / 1e6, 0)
+            dev3 = [M.Batch("roundtrip", f) for f in frames]
+            pr3 = [b.prepared() for b in dev3]
+            r["device_table_form"] = rate(lambda i: pr3[i % NSETS](), 4 * fpx, n=500, warm=500)
+            fw3 = [M.prepare_i16_batch("fwd", f) for f in frames]
+            r["forward_only_batch"] = rate(lambda i: fw3[i % NSETS](), 4 * fpx, n=500, warm=500)
+            extras["config3_420_roundtrip_one_call"] = r
+            del frames, calls3, dev3, pr3, fw3
+        except Exception as e:
+            extras["config3_420_roundtrip_one_call"] = {"error": str(e)[:200]}
+        # configs[4]: float32 DCT-II on the 8192x8192 plane (8 algorithmic bytes per pixel)
+        try:
+            fsrc = [srcs[i].to(torch.float32) for i in range(2)]  # plane set 0 = float(int16 photo plane, seed SEED): the committed hash
+            fdst = [torch.zeros_like(t) for t in fsrc]
+            r = rate(lambda i: M.fwd_f32(fsrc[i % 2], fdst[i % 2], W, H), 8 * W * H, n=300, warm=600)
+            torch.cuda.synchronize()
+            want = own_sha.get("config5_f32", {}).get("fwd__8192x8192__seed+0")
+            r["sha256_equals_cpu_checker"] = (sha_of(fdst[0]) == want) if want and rank == 0 and world == 1 else ("rank-0 planes only" if want else "no committed hash")
+            r["Mpx_s"] = round(W * H / (r["ms"] * 1e-3) / 1e6, 0)
+            r["cpu_checker_max_err_over_block_max_vs_double"] = own_sha.get("config5_f32", {}).get("max_err_over_block_max_vs_double")
+            r["stream_copy_same_bytes"] = rate(lambda i: M.stream_copy(fsrc[i % 2], fdst[i % 2], W * H * 4), 8 * W * H, n=300, warm=300)
+            extras["config5_f32_fwd"] = r
+            del fsrc, fdst
+        except Exception as e:
+            extras["config5_f32_fwd"] = {"error": str(e)[:200]}
+        # configs[3] on ONE GPU: 256 independent (separately allocated) 4096x4096 int16 planes, forward only -- one call of the
+        # plane-batch entry point (device-table form: one launch; kernel-argument form: ~6), the same planes stacked as one
+        # tall plane (one launch, needs contiguous memory), and one launch per plane
+        try:
+            PW = PH = 4096
+            NPL = 256
+            pin = [synth.plane_i16_torch(PW, PH, "photo", seed=synth.SEED + 100 + p) for p in range(NPL)]
+            pout = [torch.zeros_like(t) for t in pin]
+            desc = [(a, b, PW, PH, None) for a, b in zip(pin, pout)]
+            bpx = NPL * PW * PH
+            b4 = M.Batch("fwd", desc)
+            run4 = b4.prepared()
+            c4 = {"one_call_device_table": rate(lambda i: run4(), 4 * bpx, n=10, warm=5)}
+            c4["one_call_device_table"]["launches"] = b4.launches
+            torch.cuda.synchronize()
+            want = own_sha.get("config4_planes", {})
+            if rank == 0 and world == 1:
+                c4["sha256_equals_cpu_checker"] = all(f"fwd__4096x4096__seed+{100 + p}" in want and sha_of(pout[p]) == want[f"fwd__4096x4096__seed+{100 + p}"] for p in (0, 1, 255)) if want else "no committed hashes"
+            kept = [t.clone() for t in pout[:8]]
+            for t in pout:
+                t.zero_()
+            args4 = M.prepare_i16_batch("fwd", desc)
+            c4["one_call_kernel_arguments"] = rate(lambda i: args4(), 4 * bpx, n=10, warm=3)
+            torch.cuda.synchronize()
+            c4["kernel_argument_form_equals_device_table_form"] = all(torch.equal(a, b) for a, b in zip(kept, pout[:8]))
+            per4 = [M.prepare_plane_i16("fwd", a, b, PW, PH) for a, b in zip(pin, pout)]
+
+            def all_planes(i):
+                for c in per4:
+                    c()
+
+            c4["one_launch_per_plane"] = rate(all_planes, 4 * bpx, n=5, warm=2)
+            tall_in = torch.cat(pin, dim=0)
+            del pin, per4, args4, run4, b4, desc
+            tall_out = torch.zeros_like(tall_in)
+            st4 = M.prepare_plane_i16("fwd", tall_in, tall_out, PW, NPL * PH)
+            c4["stacked_one_launch"] = rate(lambda i: st4(), 4 * bpx, n=10, warm=3)
+            torch.cuda.synchronize()
+            c4["every_plane_equals_the_stacked_launch"] = all(torch.equal(pout[p], tall_out[p * PH:(p + 1) * PH]) for p in range(NPL))
+            c4["Mpx_s_one_call"] = round(bpx / (c4["one_call_device_table"]["ms"] * 1e-3) / 1e6, 0)
+            extras["config4_256_planes_one_gpu"] = c4
+            del pout, tall_in, tall_out, st4, kept
+            torch.cuda.empty_cache()
+        except Exception as e:
+            extras["config4_256_planes_one_gpu"] = {"error": str(e)[:200]}
         extras["roundtrip_frac_of_measured_copy"] = round(achieved / extras["stream_copy_roofline"]["GBps"], 3)
         # independent planes on two HIP streams: plane k+1's head overlaps plane k's drain
         # (an extra, never `value`: per-kernel durations and throughput differ once launches overlap)
@@ -400,8 +497,7 @@ def main():
             hff = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
             extras["px_to_huffman_rows_fused"] = rate(lambda i: M.fwd_u8_huffman_rows(u8s[i % NSETS], W, H, hseg, hnb, lut=q60, ff_counts=hff), W * H + int(hnb.sum()), n=100, warm=200)
             extras["px_to_huffman_rows_fused"]["table"] = "QUANTIZE_BASE x 60 (the records above)"
-            k1 = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62, 18, 22, 37, 56, 68, 109, 103, 77,
-                           24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+            k1 = synth.JPEG_LUMA  # ITU-T T.81 Annex K.1
             work = torch.zeros((H // 8 + 2,), dtype=torch.int64, device="cuda")
             scan = torch.empty((W * H // 2,), dtype=torch.uint8, device="cuda")
             off = torch.zeros((H // 8 + 1,), dtype=torch.int64, device="cuda")
@@ -424,7 +520,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: single 8192x8192 int16 plane per GPU, forward+inverse 8x8 DCT fused in one kernel",
                        "plane": [W, H], "io": "int16", "planes_per_step_per_gpu": 1, "rotating_plane_sets": NSETS, "untimed_preconditioning_launches": PRECONDITION,
                        "parallelism": f"independent planes x{world}" if world > 1 else "single GPU", "device": info["name"]},
-            "roofline": {"bound": "hbm", "kernel": "mdct::k_i16<MODE_ROUNDTRIP, no table>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "mdct::k_i16_tile<MODE_ROUNDTRIP, no table>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": px_per_step * ALG_BYTES_PER_PX, "avg_launch_ms": round(kernel_ms, 4)},
             "bit_exact_roundtrip_verified": verified,
@@ -455,6 +551,47 @@ def main():
                         "bit_exact_vs_reference": q.get("sha256_equals_real_reference"),
                         "verified_by": "SHA-256 of the whole output plane of the timed call == tests/golden/ref_vectors.json (bytes of the real reference)"}
 
+            def own_block(q, kernel, alg_bytes, what, traffic_key=None, verified_key="sha256_equals_cpu_checker"):
+                # engine-own kernels (no reference counterpart: "parity unpinned" by the reference, pinned by the CPU checker)
+                if not q or "GBps" not in q:
+                    return q
+                return {"bound": "hbm", "kernel": kernel, "what": what, "achieved": q["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(q["GBps"] / HBM_PEAK_GBPS, 4),
+                        "frac_of_measured_copy": round(q["GBps"] / copy, 3) if copy else None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": q["ms"],
+                        "traffic": traffic.get(traffic_key) if traffic_key else None,
+                        "traffic_source": ("profiles/traffic.json: " + traffic.get("source_r04", traffic.get("source", ""))) if traffic_key and traffic.get(traffic_key) else None,
+                        "bit_exact_vs_cpu_checker": q.get(verified_key),
+                        "verified_by": "SHA-256 of the device output of the timed launches == tests/golden/engine_own_sha256.json (output of oracle/dct_oracle.c for the same synthetic planes)"}
+
+            c3 = extras.get("config3_420_roundtrip_one_call", {})
+            if "GBps" in c3:
+                fpx3 = sum(w * h for (w, h, _, _) in synth.CONFIG3_PLANES)
+                line["roofline_config3_420"] = own_block(c3, "mdct::k_i16_batch<MODE_ROUNDTRIP, every plane its table, no saturations>", 4 * fpx3,
+                                                         "BASELINE.json configs[2]: Y 7680x4320 + Cb/Cr 3840x2160, Annex-K tables, fused fwd+inv, ONE call (mdct_roundtrip_i16_planes) = one launch",
+                                                         "k_i16_batch_420_bytes_per_launch")
+                line["roofline_config3_420"]["Mpx_s"] = c3.get("Mpx_s")
+                line["roofline_config3_420"]["device_table_form_ms"] = c3.get("device_table_form", {}).get("ms")
+                line["roofline_config3_420"]["forward_only_batch_ms"] = c3.get("forward_only_batch", {}).get("ms")
+            c5 = extras.get("config5_f32_fwd", {})
+            if "GBps" in c5:
+                line["roofline_f32"] = own_block(c5, "mdct::k_f32_tile<MODE_FWD>", 8 * W * H, "BASELINE.json configs[4]: float32 DCT-II, 8192x8192 plane (mdct_fwd_f32)", "k_f32_tile_fwd_bytes_per_launch")
+                line["roofline_f32"]["Mpx_s"] = c5.get("Mpx_s")
+                line["roofline_f32"]["tolerance"] = {"stated": "1e-5 of the block's max-abs coefficient vs a double-precision DCT-II (SURVEY.md 8c)",
+                                                     "cpu_checker_output_with_this_hash": c5.get("cpu_checker_max_err_over_block_max_vs_double")}
+                if "GBps" in c5.get("stream_copy_same_bytes", {}):
+                    line["roofline_f32"]["frac_of_measured_copy_same_bytes"] = round(c5["GBps"] / c5["stream_copy_same_bytes"]["GBps"], 3)
+            c4 = extras.get("config4_256_planes_one_gpu", {})
+            if "GBps" in c4.get("one_call_device_table", {}):
+                bpx4 = 256 * 4096 * 4096
+                blk = own_block(dict(c4["one_call_device_table"], sha256_equals_cpu_checker=c4.get("sha256_equals_cpu_checker")), "mdct::k_i16_batch<MODE_FWD>", 4 * bpx4,
+                                "BASELINE.json configs[3] on ONE GPU: 256 separately allocated 4096x4096 int16 planes, forward only, one call of mdct_batch_run (one launch)",
+                                "k_i16_batch_fwd_256_bytes_per_launch")
+                blk["verified_by"] += " for planes 0, 1, 255; every plane == the stacked single launch on the device"
+                blk["every_plane_equals_the_stacked_launch"] = c4.get("every_plane_equals_the_stacked_launch")
+                blk["Mpx_s"] = c4.get("Mpx_s_one_call")
+                for k in ("one_call_kernel_arguments", "stacked_one_launch", "one_launch_per_plane"):
+                    if "GBps" in c4.get(k, {}):
+                        blk[k] = {"ms": c4[k]["ms"], "GBps": c4[k]["GBps"], "frac": round(c4[k]["GBps"] / HBM_PEAK_GBPS, 4)}
+                line["roofline_config4_one_gpu"] = blk
             if "GBps" in extras.get("fwd_quant_u8_q32", {}):
                 line["roofline_u8"] = u8_block(extras["fwd_quant_u8_q32"], "k_q32_avx_bytes_per_launch")
             if "GBps" in extras.get("fwd_quant_u8_stereo_sse", {}):
@@ -463,6 +600,12 @@ def main():
             if "GBps" in extras.get("fwd_quant_u8_encq_sse", {}):
                 line["roofline_encq"] = u8_block(extras["fwd_quant_u8_encq_sse"], "k_encq_sse_bytes_per_launch")
                 line["roofline_encq"]["scalar_tier"] = u8_block(extras.get("fwd_quant_u8_encq_scalar"), "k_encq_scalar_bytes_per_launch")
+                # the SSE encq tier writes only half of every block pair (simd_dct.cpp:1662-1676): `frac` above charges the layout's
+                # nominal 2 B/px; on the bytes the tier really moves (1 B/px in + 0.5 B/px out + the one spill) it is lower
+                moved = W * H + W * H // 2 + 64
+                gb = moved / (extras["fwd_quant_u8_encq_sse"]["ms"] * 1e-3) / 1e9
+                line["roofline_encq"]["on_bytes_really_moved"] = {"bytes_per_launch": moved, "achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBPS, 4),
+                                                                  "frac_of_measured_copy": round(gb / copy, 3) if copy else None}
     # The optional whole-node leg runs AFTER the headline line is complete and under a watchdog: a collective that hangs
     # on some node must not cost the run its JSON line.  If the leg does not finish in time, rank 0 prints the line with
     # an error note in "allgather" and every rank exits.

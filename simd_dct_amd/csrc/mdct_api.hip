@@ -197,6 +197,65 @@ static bool lut_bounded(const float *lut)
   return true;
 }
 
+// ---- table cache: quantiser tables parked in device memory -------------------------------------------------------
+// A kernel's argument segment is written afresh by the host for every launch, so tables passed by value are cold in every
+// cache each time; the same 512 bytes in device memory stay hot in L2 across launches (8192^2 round trip with a table: 46.4 ->
+// 44.8 us, the 8K 4:2:0 frame 36.9-38.0 -> 35.7).  Per device: kTableSlots immutable slots, filled on first sight of a table
+// (one blocking 512-byte copy, once per distinct table and order), never evicted -- a slot may be referenced by launches in
+// flight on any stream and by captured graphs for as long as the process lives.  When a table cannot be parked (first seen
+// while the stream is capturing, cache full, allocation failed) the caller falls back to the tables in its arguments: the
+// results are identical either way.
+constexpr int kTableSlots = 256;
+struct TableCache
+{
+  std::mutex mu;
+  mdct::OwnTables *dev = nullptr;
+  bool failed = false;
+  std::vector<mdct::OwnTables> host; // what each filled slot holds
+};
+TableCache g_tables[kMaxDevices];
+
+bool stream_is_capturing(hipStream_t s)
+{
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  const hipError_t e = hipStreamIsCapturing(s, &st);
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError(); // the legacy stream while another stream captures in global mode: treat as "not now"
+    return true;
+  }
+  return st != hipStreamCaptureStatusNone;
+}
+
+// device address of `tb` in the cache of `device`, or nullptr
+const mdct::OwnTables *parked_tables(int device, const mdct::OwnTables &tb, hipStream_t stream)
+{
+  TableCache &c = g_tables[device];
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (size_t k = 0; k < c.host.size(); k++)
+    if (memcmp(&c.host[k], &tb, sizeof(tb)) == 0)
+      return c.dev + k;
+  if (c.failed || c.host.size() >= (size_t)kTableSlots || stream_is_capturing(stream))
+    return nullptr;
+  // allocation and copy must not disturb a capture another thread has open in global mode
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  hipError_t e = hipSuccess;
+  if (!c.dev)
+    e = hipMalloc(reinterpret_cast<void **>(&c.dev), kTableSlots * sizeof(mdct::OwnTables));
+  if (e == hipSuccess)
+    e = hipMemcpy(c.dev + c.host.size(), &tb, sizeof(tb), hipMemcpyHostToDevice);
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError();
+    c.failed = true; // keep working from the arguments
+    return nullptr;
+  }
+  c.host.push_back(tb);
+  return c.dev + (c.host.size() - 1);
+}
+
 int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
 {
   // arguments first (like the reference's dispatchers), device second
@@ -217,6 +276,7 @@ int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t 
     return r;
   if ((r = make_own_tables(lut, a.tb, mode == mdct::MODE_ROUNDTRIP)))
     return r;
+  a.tb_dev = (lut || mode != mdct::MODE_ROUNDTRIP) ? parked_tables(di->device, a.tb, (hipStream_t)stream) : nullptr; // (no table, round trip: no multipliers read)
   const hipError_t e = mdct::launch_i16(a, mode, lut != nullptr, (hipStream_t)stream, lut_bounded(lut));
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "i16 kernel launch");
 }
@@ -384,13 +444,13 @@ void batch_header(const mdct::BatchLayout &lay, const BatchInput &in, BatchLaunc
 {
   mdct::BatchArgs &a = l.args;
   a.consts = mdct::DctConsts();
-  a.n = (uint32_t)lay.descs.size();
-  a.uniform = lay.uniform;
-  a.per_plane = lay.per_plane;
-  a.pp_m = lay.pp.m;
-  a.pp_s = lay.pp.s;
-  a.table_bytes = (uint32_t)(lay.tables.size() * sizeof(mdct::OwnTables));
-  memcpy(a.first8, lay.first8, sizeof(a.first8));
+  memset(&a.head, 0, sizeof(a.head));
+  a.head.n = (uint32_t)lay.descs.size();
+  a.head.uniform = lay.uniform;
+  a.head.pp_m = lay.pp.m;
+  a.head.pp_s = lay.pp.s;
+  a.head.table_bytes = (uint32_t)(lay.tables.size() * sizeof(mdct::OwnTables));
+  memcpy(a.head.first8, lay.first8, sizeof(a.head.first8));
   a.descs = nullptr;
   a.tables = nullptr;
   l.total = lay.total;
@@ -422,7 +482,21 @@ int run_i16_batch(int mode, const mdct_plane_i16 *planes, int n, void *stream)
     batch_header(lay, in, l);
     for (size_t k = 0; k < lay.tables.size(); k++)
       memcpy(l.args.blob + k * sizeof(mdct::OwnTables), &in.tables[lay.tables[k]], sizeof(mdct::OwnTables));
-    memcpy(l.args.blob + l.args.table_bytes, lay.descs.data(), lay.descs.size() * sizeof(mdct::BatchDesc));
+    // the chunk's tables from the device's table cache when all of them are parked there (descriptors: always in the arguments)
+    std::vector<const mdct::OwnTables *> parked(lay.tables.size());
+    bool all_parked = !lay.tables.empty();
+    for (size_t k = 0; k < lay.tables.size() && all_parked; k++)
+      all_parked = (parked[k] = parked_tables(di->device, in.tables[lay.tables[k]], (hipStream_t)stream)) != nullptr;
+    if (all_parked)
+    {
+      const mdct::OwnTables *base = parked[0];
+      for (size_t k = 1; k < parked.size(); k++)
+        base = parked[k] < base ? parked[k] : base;
+      l.args.tables = base;
+      for (mdct::BatchDesc &d : lay.descs)
+        d.table = (uint32_t)((parked[d.table / sizeof(mdct::OwnTables)] - base) * sizeof(mdct::OwnTables));
+    }
+    memcpy(l.args.blob + l.args.head.table_bytes, lay.descs.data(), lay.descs.size() * sizeof(mdct::BatchDesc));
     const hipError_t e = mdct::launch_i16_batch(l.args, l.total, mode, l.lutmode, l.sat, (hipStream_t)stream);
     if (e != hipSuccess)
       return hip_fail(e, "plane batch launch");
@@ -770,7 +844,7 @@ int mdct_batch_create(mdct_batch **out, int mode, const mdct_plane_i16 *planes, 
       mdct::BatchArgs &a = b->launches[k].args;
       unsigned char *base = static_cast<unsigned char *>(b->dev) + at[k];
       a.tables = reinterpret_cast<const mdct::OwnTables *>(base);
-      a.descs = reinterpret_cast<const mdct::BatchDesc *>(base + a.table_bytes);
+      a.descs = reinterpret_cast<const mdct::BatchDesc *>(base + a.head.table_bytes);
     }
   }
   *out = b;

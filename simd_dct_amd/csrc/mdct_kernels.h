@@ -89,6 +89,7 @@ struct I16Args
 {
   const int16_t *from;
   int16_t *to;
+  const OwnTables *tb_dev; // the same tables in device memory (mdct_api.hip: table cache), or nullptr: read `tb` from the argument segment
   OwnTables tb;
   DctConsts consts;
   size_t pitch_in, pitch_out; // elements
@@ -158,19 +159,25 @@ struct F32Args
 // Descriptors and tables reach the kernel either embedded in the argument block (no allocation: mdct_*_i16_batch chunk their planes
 // so that a chunk fits `blob`) or from device memory (mdct_batch_*: uploaded once at creation, one launch for any number of planes).
 constexpr int kBatchBlob = 3584;
+struct BatchHead
+{ // 64 bytes: one s_load_dwordx16 at the top of every wave
+  uint32_t n;              // planes in the launch
+  uint32_t uniform;        // every plane has the same tile grid: plane = tile index / tiles per plane (pp_m, pp_s: its MagicDiv)
+  uint32_t pp_m, pp_s;
+  uint32_t table_bytes;    // embedded form: descriptors start at blob + table_bytes
+  uint32_t pad[3];
+  uint32_t first8[kBatchChain]; // `first` of planes 0..7 (UINT32_MAX beyond n)
+};
+static_assert(sizeof(BatchHead) == 64, "one s_load_dwordx16");
 struct BatchArgs
 {
-  DctConsts consts;
-  uint32_t n;              // planes in the launch
-  uint32_t uniform;        // every plane has the same tile grid: plane = tile index / per_plane
-  uint32_t per_plane;      // tiles per plane when uniform
-  uint32_t pp_m, pp_s;     // MagicDiv of per_plane
-  uint32_t table_bytes;    // embedded form: descriptors start at blob + table_bytes
-  uint32_t first8[kBatchChain]; // `first` of planes 0..7 (UINT32_MAX beyond n)
+  BatchHead head;
   const BatchDesc *descs;  // device memory, or nullptr: embedded
   const OwnTables *tables; // device memory, or nullptr: embedded (blob)
+  DctConsts consts;
   alignas(64) unsigned char blob[kBatchBlob]; // [tables][descriptors]
 };
+static_assert(offsetof(BatchArgs, descs) == 64 && offsetof(BatchArgs, tables) == 72, "k_i16_batch reads head + pointers as 20 consecutive dwords");
 static_assert(sizeof(BatchArgs) <= 4096, "kernel argument block");
 enum { BATCH_NO_LUT = 0, BATCH_ALL_LUT = 1, BATCH_MIXED = 2 };
 // total: tiles in the launch; lutmode / sat matter for MODE_ROUNDTRIP only

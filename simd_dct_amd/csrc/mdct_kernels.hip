@@ -1488,6 +1488,13 @@ __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Row
   }
 }
 
+// Where a single-plane launch finds its tables.  The argument segment is written afresh by the host for every launch, so a wave's
+// scalar loads from it miss every cache the first time round; tables that the host has parked in device memory (mdct_api.hip: the table
+// cache) are hot in L2 across launches.  Measured on the 8192^2 round trip with a table: 46.4 us from the arguments, 44.8 from device
+// memory -- the price of the table disappears (profiles/r04_time_batch_c.log).
+typedef const __attribute__((address_space(4))) OwnTables *ktables_t;
+__device__ __forceinline__ kbytes_t i16_tables(const I16Args &a) { return a.tb_dev ? const_bytes(a.tb_dev) : karg_bytes(offsetof(I16Args, tb)); }
+
 // The compiler's register/scheduling heuristic is steered per mode with amdgpu_waves_per_eu; the
 // values are the measured optimum of {2..6} on MI355X, ROCm 7.2 (profiles/r01_waves_per_eu.log):
 // forward 44.0 us with 2 (46.6 with 4), inverse 45.7 us with 4 (47.8 with 2), fused round trip
@@ -1505,10 +1512,11 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
   const size_t by = a.by0 + row;
   const int16_t *src = a.from + by * 8 * a.pitch_in + (size_t)bx * 8;
   int16_t *dst = a.to + by * 8 * a.pitch_out + (size_t)bx * 8;
+  const kbytes_t tbp = i16_tables(a);
   if constexpr (MODE == MODE_ROUNDTRIP)
-    i16_roundtrip_rows<HAS_LUT, RowsLinear, false, SAT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, karg_bytes(offsetof(I16Args, tb)));
+    i16_roundtrip_rows<HAS_LUT, RowsLinear, false, SAT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, tbp);
   else
-    i16_block<MODE, HAS_LUT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, a.tb);
+    i16_block<MODE, HAS_LUT>(a.consts, RowsLinear{src, dst, a.pitch_in, a.pitch_out}, *(ktables_t)tbp);
 }
 
 // The same for launches whose waves each lie in one block row (sizeX % 512 == 0): one workgroup = one wave = one 64-block
@@ -1525,10 +1533,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(i16_tile_wav
 {
   const size_t by = a.by0 + blockIdx.y;
   const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
+  const kbytes_t tbp = i16_tables(a);
   if constexpr (MODE == MODE_ROUNDTRIP)
-    i16_roundtrip_rows<HAS_LUT, RowsTiled, true, SAT>(a.consts, rows, karg_bytes(offsetof(I16Args, tb))); // with phase priorities
+    i16_roundtrip_rows<HAS_LUT, RowsTiled, true, SAT>(a.consts, rows, tbp); // with phase priorities
   else
-    i16_block<MODE, HAS_LUT>(a.consts, rows, a.tb);
+    i16_block<MODE, HAS_LUT>(a.consts, rows, *(ktables_t)tbp);
 }
 
 // Any number of separately allocated planes in ONE launch (BASELINE.json configs[2]: Y + Cb + Cr with their own tables; configs[3]:
@@ -1543,8 +1552,12 @@ __device__ __forceinline__ uint32_t magic_quot(uint32_t n, uint32_t m, uint32_t 
   const uint32_t t = __umulhi(n, m);
   return (t + ((n - t) >> (s & 0xFF))) >> (s >> 8);
 }
-typedef const __attribute__((address_space(4))) BatchDesc *kdesc_t;
-typedef const __attribute__((address_space(4))) OwnTables *ktables_t;
+typedef uint32_t u32x16_s __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4_s __attribute__((ext_vector_type(4)));
+static_assert(offsetof(BatchDesc, from) == 0 && offsetof(BatchDesc, to) == 8 && offsetof(BatchDesc, pitch_in) == 16 && offsetof(BatchDesc, pitch_out) == 24 && offsetof(BatchDesc, bpr) == 32 &&
+                  offsetof(BatchDesc, tiles) == 36 && offsetof(BatchDesc, tiles_m) == 40 && offsetof(BatchDesc, tiles_s) == 44 && offsetof(BatchDesc, first) == 48 && offsetof(BatchDesc, table) == 52 &&
+                  offsetof(BatchDesc, has_lut) == 56,
+              "k_i16_batch picks the descriptor's fields out of one 16-dword load");
 
 // Scheduling steered per mode like k_i16_tile; measured on the 8K 4:2:0 frame and on batches of one (profiles/r04_exp_batch_variants.log):
 // the fused round trip with phase priorities at 3 waves per SIMD (frame 38.0 us against 40.3 at 2, 8192^2 45.3 against 46.0-46.5),
@@ -1553,45 +1566,57 @@ constexpr int batch_waves(int mode) { return mode == MODE_ROUNDTRIP ? 3 : 2; }
 template <int MODE, int LUTMODE, bool SAT = true>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(batch_waves(MODE), batch_waves(MODE)))) void k_i16_batch(BatchArgs a)
 {
+  // Two dependent rounds of scalar loads stand between a wave's start and its first row load: the header (20 dwords, fetched as ONE
+  // batch -- left to the compiler each field was a load with a wait of its own, ten round trips), then the plane's descriptor.
   const uint32_t w = blockIdx.x;
-  const kbytes_t blob = karg_bytes(offsetof(BatchArgs, blob));
-  const kdesc_t descs = a.descs ? (kdesc_t)const_bytes(a.descs) : (kdesc_t)(blob + a.table_bytes);
-  const kbytes_t tables = a.tables ? const_bytes(a.tables) : blob;
-  uint32_t p;
-  if (a.uniform)
-    p = magic_quot(w, a.pp_m, a.pp_s);
-  else if (a.n <= kBatchChain)
+  kbytes_t args = karg_bytes(0);
+  asm volatile("" : "+s"(args)); // opaque: the loads below stay two wide loads, issued together
+  const u32x16_s h = *(const __attribute__((address_space(4))) u32x16_s *)args;
+  const u32x4_s ptrs = *(const __attribute__((address_space(4))) u32x4_s *)(args + offsetof(BatchArgs, descs));
+  const uint32_t n = h[0], uniform = h[1], pp_m = h[2], pp_s = h[3], table_bytes = h[4];
+  const uint64_t descs_dev = ((uint64_t)ptrs[1] << 32) | ptrs[0], tables_dev = ((uint64_t)ptrs[3] << 32) | ptrs[2];
+  const kbytes_t blob = args + offsetof(BatchArgs, blob);
+  const kbytes_t descs = descs_dev ? (kbytes_t)descs_dev : blob + table_bytes;
+  const kbytes_t tables = tables_dev ? (kbytes_t)tables_dev : blob;
+  uint32_t p = magic_quot(w, pp_m, pp_s); // equal shapes
+  if (!uniform)
   {
-    p = 0;
+    p = 0; // up to kBatchChain different shapes: a compare chain on the header (first8 is UINT32_MAX beyond n)
 #pragma unroll
     for (int i = 1; i < kBatchChain; i++)
-      p += w >= a.first8[i] ? 1 : 0;
-  }
-  else
-  { // last plane whose first tile is <= w
-    uint32_t lo = 0, hi = a.n;
-    while (hi - lo > 1)
-    {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (descs[mid].first <= w)
-        lo = mid;
-      else
-        hi = mid;
+      p += w >= h[8 + i] ? 1u : 0u;
+    if (n > (uint32_t)kBatchChain)
+    { // more: the last plane whose first tile is <= w
+      uint32_t lo = 0, hi = n;
+      while (hi - lo > 1)
+      {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (*(const __attribute__((address_space(4))) uint32_t *)(descs + (size_t)mid * sizeof(BatchDesc) + offsetof(BatchDesc, first)) <= w)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      p = lo;
     }
-    p = lo;
   }
-  const __attribute__((address_space(4))) BatchDesc &d = descs[p];
-  const uint32_t lt = w - d.first;
-  const uint32_t row = magic_quot(lt, d.tiles_m, d.tiles_s);
-  const uint32_t tile = lt - row * d.tiles;
-  if (tile * 64 + threadIdx.x >= d.bpr)
+  p = __builtin_amdgcn_readfirstlane(p); // (the compare chain may have been evaluated on the vector unit)
+  kbytes_t dp = descs + (size_t)p * sizeof(BatchDesc);
+  asm volatile("" : "+s"(dp));
+  const u32x16_s d = *(const __attribute__((address_space(4))) u32x16_s *)dp;
+  const uint32_t d_bpr = d[8], d_tiles = d[9], d_first = d[12], d_table = d[13], d_has_lut = d[14];
+  const uint32_t lt = w - d_first;
+  const uint32_t row = magic_quot(lt, d[10], d[11]);
+  const uint32_t tile = lt - row * d_tiles;
+  if (tile * 64 + threadIdx.x >= d_bpr)
     return;
-  const size_t pin = d.pitch_in, pout = d.pitch_out;
-  const RowsTiled rows{d.from + (size_t)row * 8 * pin + (size_t)tile * 512, d.to + (size_t)row * 8 * pout + (size_t)tile * 512, pin, pout, threadIdx.x * 16};
-  const kbytes_t tbp = tables + d.table;
+  const int16_t *d_from = (const int16_t *)(((uint64_t)d[1] << 32) | d[0]);
+  int16_t *d_to = (int16_t *)(((uint64_t)d[3] << 32) | d[2]);
+  const size_t pin = ((uint64_t)d[5] << 32) | d[4], pout = ((uint64_t)d[7] << 32) | d[6];
+  const RowsTiled rows{d_from + (size_t)row * 8 * pin + (size_t)tile * 512, d_to + (size_t)row * 8 * pout + (size_t)tile * 512, pin, pout, threadIdx.x * 16};
+  const kbytes_t tbp = tables + d_table;
   if constexpr (MODE == MODE_ROUNDTRIP)
   {
-    if (LUTMODE == BATCH_ALL_LUT || (LUTMODE == BATCH_MIXED && d.has_lut))
+    if (LUTMODE == BATCH_ALL_LUT || (LUTMODE == BATCH_MIXED && d_has_lut))
       i16_roundtrip_rows<true, RowsTiled, true, SAT>(a.consts, rows, tbp);
     else
       i16_roundtrip_rows<false, RowsTiled, true>(a.consts, rows, nullptr);

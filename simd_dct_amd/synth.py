@@ -75,3 +75,13 @@ def plane_i16_torch(W, H, kind="photo", seed=SEED, bits=8, device="cuda"):
         h = _mix32_t(((i ^ (seed & _M)) & _M))
         return ((h >> 20) - 2048).to(torch.int16).reshape(H, W)
     return plane_u8_torch(W, H, kind, seed, device).to(torch.int16) - 128
+
+
+# ITU-T T.81 Annex K.1 quantisation tables (Tables K.1 luminance, K.2 chrominance), natural order v*8+u: the per-plane
+# tables of BASELINE.json configs[2] (bench.py, tests, tools/ share these literals)
+JPEG_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                      18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+JPEG_CHROMA = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.float32)
+
+# BASELINE.json configs[2]: the 8K 4:2:0 frame -- (width, height, seed offset, table) of Y, Cb, Cr
+CONFIG3_PLANES = ((7680, 4320, 0, "luma"), (3840, 2160, 1, "chroma"), (3840, 2160, 2, "chroma"))

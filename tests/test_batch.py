@@ -215,9 +215,7 @@ def test_batch_is_graph_capturable(cuda):
     _check_against_oracle("roundtrip", srcs, d_out, shapes, luts, 0, "graph/args")
 
 
-JPEG_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
-                      18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
-JPEG_CHROMA = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.float32)
+JPEG_LUMA, JPEG_CHROMA = synth.JPEG_LUMA, synth.JPEG_CHROMA  # ITU-T T.81 Annex K.1
 
 
 @gpu
@@ -288,3 +286,40 @@ def test_config4_256_separately_allocated_planes_forward_in_one_call(cuda):
     for p in range(n):
         api.fwd_i16(d_in[p], want, W, H)
         assert torch.equal(want, d_out[p]), p
+
+
+@gpu
+def test_table_cache_first_sight_under_capture_and_beyond_its_capacity(cuda):
+    """Tables are parked in device memory on first sight (mdct_api.hip: table cache) -- except when that first sight happens inside a
+    stream capture, or when the cache's 256 slots are taken: then the tables travel in the kernel arguments.  Same bytes either way:
+    a table never seen before used first under capture (single-plane call and batch), then 300 more distinct tables."""
+    import oracle as O
+
+    torch = cuda
+    W, H = 1024, 64
+    src = synth.plane_i16_np(W, H, "photo", seed=77, bits=12)
+    d = torch.from_numpy(src).cuda()
+    rng = np.random.default_rng(2026)
+    fresh = (rng.uniform(9.0, 90.0, 64)).astype(np.float32)
+    out1 = torch.full_like(d, CANARY)
+    out2 = torch.full_like(d, CANARY)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        api.roundtrip_i16(d, out1, W, H, lut=fresh, stream=s)
+        api.i16_batch("roundtrip", [(d, out2, W, H, fresh)], stream=s)
+    g.replay()
+    torch.cuda.synchronize()
+    want = O.i16("roundtrip", src, W, H, lut=fresh)
+    assert np.array_equal(out1.cpu().numpy(), want) and np.array_equal(out2.cpu().numpy(), want)
+    for k in range(300):
+        q = (rng.uniform(8.5, 200.0, 64)).astype(np.float32)
+        mode = ("fwd", "inv", "roundtrip")[k % 3]
+        out = torch.full_like(d, CANARY)
+        if k % 2:
+            {"fwd": api.fwd_i16, "inv": api.inv_i16, "roundtrip": api.roundtrip_i16}[mode](d, out, W, H, lut=q)
+        else:
+            api.i16_batch(mode, [(d, out, W, H, q)])
+        if k % 25 == 0 or k > 290:
+            assert np.array_equal(out.cpu().numpy(), O.i16(mode, src, W, H, lut=q)), (k, mode)

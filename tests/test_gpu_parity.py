@@ -317,9 +317,7 @@ def test_full_size_8192_whole_plane_vs_oracle():
 
 
 # ------------------------------------------------------------------ remaining BASELINE.json configs
-JPEG_LUMA = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
-                      18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
-JPEG_CHROMA = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.float32)
+JPEG_LUMA, JPEG_CHROMA = synth.JPEG_LUMA, synth.JPEG_CHROMA  # ITU-T T.81 Annex K.1
 
 
 def test_config3_420_full_size_one_call():

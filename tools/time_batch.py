@@ -8,9 +8,7 @@ from simd_dct_amd import synth
 
 M.init(0)
 NPL = int(sys.argv[sys.argv.index("--planes") + 1]) if "--planes" in sys.argv else 256
-jl = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
-               18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
-jc = np.array([17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99] + [99] * 32, dtype=np.float32)
+jl, jc = synth.JPEG_LUMA, synth.JPEG_CHROMA
 t = M.Timer()
 
 
@@ -55,6 +53,14 @@ run("Cb 3840x2160 alone, batch of one", [M.prepare_i16_batch("roundtrip", [f[1]]
 big = [mk(8192, 8192, 40 + i) for i in range(4)]
 run("8192^2 mdct_roundtrip_i16 (k_i16_tile)", [M.prepare_plane_i16("roundtrip", a, b, 8192, 8192) for a, b in big], 8192 * 8192)
 run("8192^2 roundtrip, batch of one", [M.prepare_i16_batch("roundtrip", [(a, b, 8192, 8192, None)]) for a, b in big], 8192 * 8192)
+run("8192^2 mdct_roundtrip_i16 + table (tables in the kernel arguments)", [M.prepare_plane_i16("roundtrip", a, b, 8192, 8192, lut=jl) for a, b in big], 8192 * 8192)
+run("8192^2 roundtrip + table, batch of one, kernel arguments", [M.prepare_i16_batch("roundtrip", [(a, b, 8192, 8192, jl)]) for a, b in big], 8192 * 8192)
+b1 = [M.Batch("roundtrip", [(a, b, 8192, 8192, jl)]) for a, b in big]
+run("8192^2 roundtrip + table, batch of one, device table", [x.prepared() for x in b1], 8192 * 8192)
+b2 = [M.Batch("fwd", [(a, b, 8192, 8192, jl)]) for a, b in big]
+run("8192^2 fwd + table, batch of one, device table", [x.prepared() for x in b2], 8192 * 8192)
+run("8192^2 mdct_fwd_i16 + table (k_i16_tile)", [M.prepare_plane_i16("fwd", a, b, 8192, 8192, lut=jl) for a, b in big], 8192 * 8192)
+del b1, b2
 run("8192^2 mdct_fwd_i16 (k_i16_tile)", [M.prepare_plane_i16("fwd", a, b, 8192, 8192) for a, b in big], 8192 * 8192)
 run("8192^2 fwd, batch of one", [M.prepare_i16_batch("fwd", [(a, b, 8192, 8192, None)]) for a, b in big], 8192 * 8192)
 run("8192^2 stream copy", [M.prepare_stream_copy(a, b, 8192 * 8192 * 2) for a, b in big], 8192 * 8192)
