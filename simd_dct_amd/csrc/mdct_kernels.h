@@ -62,7 +62,7 @@ struct PkConstsArg
 {
   float af[2], cd[2], be[2], nm[2];
   float da[2], fd[2], fc[2], ca[2]; // scalar tiers (K_TRUE): (Cd,Ca) (Cf,Cd) (Cf,Cc) (Cc,Ca)
-  float bias[2];                    // SSE tiers: (1/255, 127.0f); scalar tiers: (127/255, 255.0f)
+  float bias[2];                    // SSE tiers: (1/255, 127.0f); scalar tiers: (255.0f, pred(0.5)), with nm = (Cn, 127/255)
 };
 
 struct U8Args

@@ -148,7 +148,7 @@ struct PkConsts
 {
   f32x2 af, cd, be, nm; // (Ca,Cf) (Cc,Cd) (Cb,Ce) (Cn, rounding constant)
   f32x2 da, fd, fc, ca; // K_TRUE only: (Cd,Ca) (Cf,Cd) (Cf,Cc) (Cc,Ca)
-  f32x2 bias;           // SSE tiers: (1/255, 127.0f);  scalar tiers: (127/255, 255.0f)
+  f32x2 bias;           // SSE tiers: (1/255, 127.0f);  scalar tiers: (255.0f, pred(0.5)) and nm = (Cn, 127/255)
 };
 static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernels.h) is the kernel-argument image of PkConsts");
 
@@ -175,19 +175,15 @@ static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernel
 // statement that reads a VGPR written by the asm statement IMMEDIATELY before it the compiler inserts a wait state
 // (it cannot see inside and assumes the gfx940 dst_sel forwarding hazard): 64-76 s_nop per wave in the order the
 // formulas are usually written in.  The operations are therefore emitted so that none consumes its predecessor's
-// result (MDCT_PK_REORDER=0 keeps the textbook order for A/B runs, tools/exp_u8_r3.hip).
-#ifndef MDCT_PK_REORDER
-#define MDCT_PK_REORDER 2
-#endif
+// result (the textbook order and the statement-per-operation forms of the other passes: tools/pk_forms_textbook.h, for A/B runs).
 template <int K1D>
 __device__ __forceinline__ void dct8_h(const PkConsts &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o13, f32x2 &o57)
 {
-#if MDCT_PK_REORDER == 2
   if constexpr (K1D != K_TRUE)
   { // The whole line as ONE asm statement, registers allocated by hand: the four input pairs are reused as scratch
     // (A = a01, B = a23, C = a45, D = a67) plus three temporaries, 28 instructions, no compiler-inserted wait states
     // inside; results leave in T0 = (o0,o4), T1 = (o2,o6), C = (o1,o3), D = (o5,o7).  Same operations, same operands,
-    // same modifiers as the statement-per-operation form below (MDCT_PK_REORDER 0 / 1), which stays the readable spec.
+    // same modifiers as the statement-per-operation form below (which K_TRUE still runs and which stays the readable spec).
     f32x2 T0, T1, T2;
 #define MDCT_XS " op_sel:[0,1] op_sel_hi:[1,0]"
 #define MDCT_DCT8_H_ASM(U13MOD, O13MOD) \
@@ -230,8 +226,6 @@ __device__ __forceinline__ void dct8_h(const PkConsts &K, f32x2 a01, f32x2 a23, 
     o04 = T0; o26 = T1; o13 = a45; o57 = a67;
     return;
   }
-#endif
-#if MDCT_PK_REORDER
   f32x2 s1, s2, d, e, pqp, pqm, r, t, m1, m2, m3, m4, t13, t57;
   MDCT_PKA(s1, a01, a67, MDCT_X);                                  // (p0+p7, p1+p6)
   MDCT_PKA(s2, a23, a45, MDCT_X);                                  // (p2+p5, p3+p4)
@@ -291,69 +285,12 @@ __device__ __forceinline__ void dct8_h(const PkConsts &K, f32x2 a01, f32x2 a23, 
     MDCT_PKM(o13, o13, K.nm, MDCT_K_LL);
     MDCT_PKM(o57, o57, K.nm, MDCT_K_LL);
   }
-#else
-  f32x2 s1, s2, d, e, pqp, pqm, r, t, m1, m2, m3, m4, t13, t57;
-  MDCT_PKA(s1, a01, a67, MDCT_X);                                  // (p0+p7, p1+p6)
-  MDCT_PKA(s2, a23, a45, MDCT_X);                                  // (p2+p5, p3+p4)
-  MDCT_PKA(d, a01, a67, MDCT_X " neg_lo:[0,1] neg_hi:[1,0]");      // (p0-p7, p6-p1)
-  MDCT_PKA(e, a23, a45, MDCT_X " neg_lo:[0,1] neg_hi:[1,0]");      // (p2-p5, p4-p3)
-  MDCT_PKA(pqp, s1, s2, MDCT_X);                                   // (x07p+x34p, x16p+x25p)
-  MDCT_PKA(pqm, s1, s2, MDCT_X " " MDCT_NEG_B);                    // (x07p-x34p, x16p-x25p)
-  MDCT_PKA(o04, pqp, pqp, "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]"); // (pp+qp, pp-qp)
-  MDCT_PKM(r, pqm, K.be, MDCT_K_LL);                               // (Cb pm, Cb qm)
-  MDCT_PKM(t, pqm, K.be, MDCT_K_HH);                               // (Ce pm, Ce qm)
-  MDCT_PKA(o26, r, t, MDCT_X " neg_hi:[1,0]");                     // (Cb pm + Ce qm, Ce pm - Cb qm)
-  MDCT_PKM(m1, d, K.af, MDCT_K_LH);                                // (Ca x07m, Cf x61m)
-  MDCT_PKM(m2, d, K.cd, MDCT_K_LL);                                // (Cc x07m, Cc x61m)
-  MDCT_PKM(m3, d, K.cd, MDCT_K_HH);                                // (Cd x07m, Cd x61m)
-  MDCT_PKM(m4, d, K.af, MDCT_K_HL);                                // (Cf x07m, Ca x61m)
-  MDCT_PKA(t13, m1, m2, MDCT_X " neg_lo:[0,1]");                   // (Ca x07m - Cc x61m, Cf x61m + Cc x07m)
-  MDCT_PKA(t57, m3, m4, MDCT_X);                                   // (Cd x07m + Ca x61m, Cd x61m + Cf x07m)
-  if constexpr (K1D == K_TRUE)
-  { // sequential association: two more terms added one after the other
-    f32x2 g1, g2, g3, g4, h13, h57;
-    MDCT_PKM(g1, e, K.da, "op_sel:[0,0] op_sel_hi:[0,1]");         // (Cd x25m, Ca x25m)
-    MDCT_PKM(g2, e, K.fd, "op_sel:[1,0] op_sel_hi:[1,1]");         // (Cf x43m, Cd x43m)
-    MDCT_PKM(g3, e, K.fc, "op_sel:[0,0] op_sel_hi:[0,1]");         // (Cf x25m, Cc x25m)
-    MDCT_PKM(g4, e, K.ca, "op_sel:[1,0] op_sel_hi:[1,1]");         // (Cc x43m, Ca x43m)
-    MDCT_PKA(h13, t13, g1, "neg_hi:[0,1]");                        // (t1 + Cd x25m, t3 - Ca x25m)
-    MDCT_PKA(o13, h13, g2, "neg_lo:[0,1]");                        // (.. - Cf x43m, .. + Cd x43m)
-    MDCT_PKA(h57, t57, g3, "");                                    // (t5 + Cf x25m, t7 + Cc x25m)
-    MDCT_PKA(o57, h57, g4, "neg_lo:[0,1]");                        // (.. - Cc x43m, .. + Ca x43m)
-  }
-  else
-  {
-    f32x2 n1, n2, n3, n4, u13, u57;
-    MDCT_PKM(n1, e, K.cd, MDCT_K_HH);                              // (Cd x25m, Cd x43m)
-    MDCT_PKM(n2, e, K.af, MDCT_K_LH);                              // (Ca x25m, Cf x43m)
-    MDCT_PKM(n3, e, K.af, MDCT_K_HL);                              // (Cf x25m, Ca x43m)
-    MDCT_PKM(n4, e, K.cd, MDCT_K_LL);                              // (Cc x25m, Cc x43m)
-    MDCT_PKA(u57, n3, n4, MDCT_X " neg_lo:[0,1]");                 // (Cf x25m - Cc x43m, Ca x43m + Cc x25m)
-    if constexpr (K1D == K_AVX)
-    {
-      MDCT_PKA(u13, n1, n2, MDCT_X " neg_lo:[0,1]");               // (Cd x25m - Cf x43m, Cd x43m + Ca x25m)
-      MDCT_PKA(o13, t13, u13, "neg_hi:[0,1]");                     // (t1 + u1, t3 - u3): the k=3 quirk of :2181
-    }
-    else
-    {
-      static_assert(K1D == K_SSE, "unknown 1-D kernel");
-      MDCT_PKA(u13, n1, n2, MDCT_X " neg_hi:[0,1]");               // (Cd x25m + Cf x43m [k=1 quirk, :550], Cd x43m - Ca x25m)
-      MDCT_PKA(o13, t13, u13, "");
-    }
-    MDCT_PKA(o57, t57, u57, "");                                   // (t5 + u5, t7 + u7)
-  }
-  MDCT_PKM(o04, o04, K.nm, MDCT_K_LL);
-  MDCT_PKM(o26, o26, K.nm, MDCT_K_LL);
-  MDCT_PKM(o13, o13, K.nm, MDCT_K_LL);
-  MDCT_PKM(o57, o57, K.nm, MDCT_K_LL);
-#endif
 }
 
 // the same transform down a PAIR of independent columns (or rows), p[r] = (B[r][u1], B[r][u2]), in place
 template <int K1D>
 __device__ __forceinline__ void dct8_v(const PkConsts &K, f32x2 (&p)[8])
 {
-#if MDCT_PK_REORDER == 2
   // Plain vector code: this pass needs no cross-half operand selection -- only whole-pair adds / subtracts and products
   // with one broadcast constant, which the compiler turns into v_pk_add_f32 / v_pk_mul_f32 itself (the broadcast and the
   // subtraction's sign fold into op_sel / neg modifiers: (-x)*c == -(x*c) and a + (-b) == a - b exactly; contraction is
@@ -395,131 +332,6 @@ __device__ __forceinline__ void dct8_v(const PkConsts &K, f32x2 (&p)[8])
   }
   p[0] = Cn * o0; p[1] = Cn * o1; p[2] = Cn * o2; p[3] = Cn * o3;
   p[4] = Cn * o4; p[5] = Cn * o5; p[6] = Cn * o6; p[7] = Cn * o7;
-#elif MDCT_PK_REORDER
-  // products and sums software-pipelined: mul A(i+1) sits between mul B(i) and add(i), so no statement reads its predecessor
-  f32x2 x07p, x16p, x25p, x34p, x07m, x61m, x25m, x43m, pp, pm, qp, qm, o0, o1, o2, o3, o4, o5, o6, o7;
-  MDCT_PKA(x07p, p[0], p[7], ""); MDCT_PKA(x16p, p[1], p[6], ""); MDCT_PKA(x25p, p[2], p[5], ""); MDCT_PKA(x34p, p[3], p[4], "");
-  MDCT_PKA(x07m, p[0], p[7], MDCT_NEG_B); MDCT_PKA(x61m, p[6], p[1], MDCT_NEG_B);
-  MDCT_PKA(x25m, p[2], p[5], MDCT_NEG_B); MDCT_PKA(x43m, p[4], p[3], MDCT_NEG_B);
-  MDCT_PKA(pp, x07p, x34p, ""); MDCT_PKA(pm, x07p, x34p, MDCT_NEG_B);
-  MDCT_PKA(qp, x16p, x25p, ""); MDCT_PKA(qm, x16p, x25p, MDCT_NEG_B);
-  f32x2 a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, t1, t3, t5, t7;
-  MDCT_PKM(a1, pm, K.be, MDCT_K_LL);                       // Cb pm
-  MDCT_PKA(o0, pp, qp, "");
-  MDCT_PKM(b1, qm, K.be, MDCT_K_HH);                       // Ce qm
-  MDCT_PKA(o4, pp, qp, MDCT_NEG_B);
-  MDCT_PKM(a2, pm, K.be, MDCT_K_HH);                       // Ce pm
-  MDCT_PKA(o2, a1, b1, "");                                // Cb pm + Ce qm
-  MDCT_PKM(b2, qm, K.be, MDCT_K_LL);                       // Cb qm
-  MDCT_PKM(a3, x07m, K.af, MDCT_K_LL);                     // Ca x07m
-  MDCT_PKA(o6, a2, b2, MDCT_NEG_B);                        // Ce pm - Cb qm
-  MDCT_PKM(b3, x61m, K.cd, MDCT_K_LL);                     // Cc x61m
-  MDCT_PKM(a4, x07m, K.cd, MDCT_K_LL);                     // Cc x07m
-  MDCT_PKA(t1, a3, b3, MDCT_NEG_B);                        // Ca x07m - Cc x61m
-  MDCT_PKM(b4, x61m, K.af, MDCT_K_HH);                     // Cf x61m
-  MDCT_PKM(a5, x07m, K.cd, MDCT_K_HH);                     // Cd x07m
-  MDCT_PKA(t3, a4, b4, "");                                // Cc x07m + Cf x61m
-  MDCT_PKM(b5, x61m, K.af, MDCT_K_LL);                     // Ca x61m
-  MDCT_PKM(a6, x07m, K.af, MDCT_K_HH);                     // Cf x07m
-  MDCT_PKA(t5, a5, b5, "");                                // Cd x07m + Ca x61m
-  MDCT_PKM(b6, x61m, K.cd, MDCT_K_HH);                     // Cd x61m
-  if constexpr (K1D == K_TRUE)
-  { // ((t + c1 x25m) +- c2 x43m), :166-171
-    f32x2 c1, c3, c5, c7, d1, d3, d5, d7;
-    MDCT_PKM(c1, x25m, K.cd, MDCT_K_HH);                   // Cd x25m
-    MDCT_PKA(t7, a6, b6, "");                              // Cf x07m + Cd x61m
-    MDCT_PKM(c3, x25m, K.af, MDCT_K_LL);                   // Ca x25m
-    MDCT_PKM(c5, x25m, K.af, MDCT_K_HH);                   // Cf x25m
-    MDCT_PKA(t1, t1, c1, "");
-    MDCT_PKM(c7, x25m, K.cd, MDCT_K_LL);                   // Cc x25m
-    MDCT_PKA(t3, t3, c3, MDCT_NEG_B);
-    MDCT_PKM(d1, x43m, K.af, MDCT_K_HH);                   // Cf x43m
-    MDCT_PKA(t5, t5, c5, "");
-    MDCT_PKM(d3, x43m, K.cd, MDCT_K_HH);                   // Cd x43m
-    MDCT_PKA(t7, t7, c7, "");
-    MDCT_PKM(d5, x43m, K.cd, MDCT_K_LL);                   // Cc x43m
-    MDCT_PKA(o1, t1, d1, MDCT_NEG_B);
-    MDCT_PKM(d7, x43m, K.af, MDCT_K_LL);                   // Ca x43m
-    MDCT_PKA(o3, t3, d3, "");
-    MDCT_PKA(o5, t5, d5, MDCT_NEG_B);
-    MDCT_PKA(o7, t7, d7, "");
-  }
-  else
-  {
-    f32x2 c7, d7, c8, d8, c9, d9, c10, d10, u1, u3, u5, u7;
-    MDCT_PKM(c7, x25m, K.af, MDCT_K_HH);                   // Cf x25m
-    MDCT_PKA(t7, a6, b6, "");                              // Cf x07m + Cd x61m
-    MDCT_PKM(d7, x43m, K.cd, MDCT_K_LL);                   // Cc x43m
-    MDCT_PKM(c8, x25m, K.cd, MDCT_K_LL);                   // Cc x25m
-    MDCT_PKA(u5, c7, d7, MDCT_NEG_B);                      // Cf x25m - Cc x43m
-    MDCT_PKM(d8, x43m, K.af, MDCT_K_LL);                   // Ca x43m
-    MDCT_PKM(c9, x25m, K.cd, MDCT_K_HH);                   // Cd x25m
-    MDCT_PKA(u7, c8, d8, "");                              // Cc x25m + Ca x43m
-    MDCT_PKM(d9, x43m, K.af, MDCT_K_HH);                   // Cf x43m
-    MDCT_PKM(c10, x25m, K.af, MDCT_K_LL);                  // Ca x25m
-    if constexpr (K1D == K_AVX)
-      MDCT_PKA(u1, c9, d9, MDCT_NEG_B);                    // Cd x25m - Cf x43m
-    else
-      MDCT_PKA(u1, c9, d9, "");                            // Cd x25m + Cf x43m (k=1 quirk, :550)
-    MDCT_PKM(d10, x43m, K.cd, MDCT_K_HH);                  // Cd x43m
-    MDCT_PKA(o5, t5, u5, "");
-    if constexpr (K1D == K_AVX)
-      MDCT_PKA(u3, c10, d10, "");                          // Ca x25m + Cd x43m
-    else
-      MDCT_PKA(u3, d10, c10, MDCT_NEG_B);                  // Cd x43m - Ca x25m
-    MDCT_PKA(o7, t7, u7, "");
-    MDCT_PKA(o1, t1, u1, "");
-    if constexpr (K1D == K_AVX)
-      MDCT_PKA(o3, t3, u3, MDCT_NEG_B);                    // the k=3 quirk of :2181
-    else
-      MDCT_PKA(o3, t3, u3, "");
-  }
-  MDCT_PKM(p[0], o0, K.nm, MDCT_K_LL); MDCT_PKM(p[4], o4, K.nm, MDCT_K_LL); MDCT_PKM(p[2], o2, K.nm, MDCT_K_LL); MDCT_PKM(p[6], o6, K.nm, MDCT_K_LL);
-  MDCT_PKM(p[5], o5, K.nm, MDCT_K_LL); MDCT_PKM(p[7], o7, K.nm, MDCT_K_LL); MDCT_PKM(p[1], o1, K.nm, MDCT_K_LL); MDCT_PKM(p[3], o3, K.nm, MDCT_K_LL);
-#else
-  f32x2 x07p, x16p, x25p, x34p, x07m, x61m, x25m, x43m, pp, pm, qp, qm, o0, o4, a, b, o2, o6;
-  MDCT_PKA(x07p, p[0], p[7], ""); MDCT_PKA(x16p, p[1], p[6], ""); MDCT_PKA(x25p, p[2], p[5], ""); MDCT_PKA(x34p, p[3], p[4], "");
-  MDCT_PKA(x07m, p[0], p[7], MDCT_NEG_B); MDCT_PKA(x61m, p[6], p[1], MDCT_NEG_B);
-  MDCT_PKA(x25m, p[2], p[5], MDCT_NEG_B); MDCT_PKA(x43m, p[4], p[3], MDCT_NEG_B);
-  MDCT_PKA(pp, x07p, x34p, ""); MDCT_PKA(pm, x07p, x34p, MDCT_NEG_B);
-  MDCT_PKA(qp, x16p, x25p, ""); MDCT_PKA(qm, x16p, x25p, MDCT_NEG_B);
-  MDCT_PKA(o0, pp, qp, ""); MDCT_PKA(o4, pp, qp, MDCT_NEG_B);
-  MDCT_PKM(a, pm, K.be, MDCT_K_LL); MDCT_PKM(b, qm, K.be, MDCT_K_HH); MDCT_PKA(o2, a, b, "");          // Cb pm + Ce qm
-  MDCT_PKM(a, pm, K.be, MDCT_K_HH); MDCT_PKM(b, qm, K.be, MDCT_K_LL); MDCT_PKA(o6, a, b, MDCT_NEG_B);  // Ce pm - Cb qm
-  f32x2 t1, t3, t5, t7, c, dd, o1, o3, o5, o7;
-  MDCT_PKM(a, x07m, K.af, MDCT_K_LL); MDCT_PKM(b, x61m, K.cd, MDCT_K_LL); MDCT_PKA(t1, a, b, MDCT_NEG_B);   // Ca x07m - Cc x61m
-  MDCT_PKM(a, x07m, K.cd, MDCT_K_LL); MDCT_PKM(b, x61m, K.af, MDCT_K_HH); MDCT_PKA(t3, a, b, "");           // Cc x07m + Cf x61m
-  MDCT_PKM(a, x07m, K.cd, MDCT_K_HH); MDCT_PKM(b, x61m, K.af, MDCT_K_LL); MDCT_PKA(t5, a, b, "");           // Cd x07m + Ca x61m
-  MDCT_PKM(a, x07m, K.af, MDCT_K_HH); MDCT_PKM(b, x61m, K.cd, MDCT_K_HH); MDCT_PKA(t7, a, b, "");           // Cf x07m + Cd x61m
-  if constexpr (K1D == K_TRUE)
-  { // ((t + c1 x25m) +- c2 x43m), :166-171
-    MDCT_PKM(c, x25m, K.cd, MDCT_K_HH); MDCT_PKA(t1, t1, c, "");         MDCT_PKM(dd, x43m, K.af, MDCT_K_HH); MDCT_PKA(o1, t1, dd, MDCT_NEG_B);
-    MDCT_PKM(c, x25m, K.af, MDCT_K_LL); MDCT_PKA(t3, t3, c, MDCT_NEG_B); MDCT_PKM(dd, x43m, K.cd, MDCT_K_HH); MDCT_PKA(o3, t3, dd, "");
-    MDCT_PKM(c, x25m, K.af, MDCT_K_HH); MDCT_PKA(t5, t5, c, "");         MDCT_PKM(dd, x43m, K.cd, MDCT_K_LL); MDCT_PKA(o5, t5, dd, MDCT_NEG_B);
-    MDCT_PKM(c, x25m, K.cd, MDCT_K_LL); MDCT_PKA(t7, t7, c, "");         MDCT_PKM(dd, x43m, K.af, MDCT_K_LL); MDCT_PKA(o7, t7, dd, "");
-  }
-  else
-  {
-    f32x2 u1, u3, u5, u7;
-    MDCT_PKM(c, x25m, K.af, MDCT_K_HH); MDCT_PKM(dd, x43m, K.cd, MDCT_K_LL); MDCT_PKA(u5, c, dd, MDCT_NEG_B); // Cf x25m - Cc x43m
-    MDCT_PKM(c, x25m, K.cd, MDCT_K_LL); MDCT_PKM(dd, x43m, K.af, MDCT_K_LL); MDCT_PKA(u7, c, dd, "");         // Cc x25m + Ca x43m
-    if constexpr (K1D == K_AVX)
-    {
-      MDCT_PKM(c, x25m, K.cd, MDCT_K_HH); MDCT_PKM(dd, x43m, K.af, MDCT_K_HH); MDCT_PKA(u1, c, dd, MDCT_NEG_B); // Cd x25m - Cf x43m
-      MDCT_PKM(c, x25m, K.af, MDCT_K_LL); MDCT_PKM(dd, x43m, K.cd, MDCT_K_HH); MDCT_PKA(u3, c, dd, "");         // Ca x25m + Cd x43m
-      MDCT_PKA(o1, t1, u1, ""); MDCT_PKA(o3, t3, u3, MDCT_NEG_B);
-    }
-    else
-    {
-      MDCT_PKM(c, x25m, K.cd, MDCT_K_HH); MDCT_PKM(dd, x43m, K.af, MDCT_K_HH); MDCT_PKA(u1, c, dd, "");         // Cd x25m + Cf x43m (quirk)
-      MDCT_PKM(c, x43m, K.cd, MDCT_K_HH); MDCT_PKM(dd, x25m, K.af, MDCT_K_LL); MDCT_PKA(u3, c, dd, MDCT_NEG_B); // Cd x43m - Ca x25m
-      MDCT_PKA(o1, t1, u1, ""); MDCT_PKA(o3, t3, u3, "");
-    }
-    MDCT_PKA(o5, t5, u5, ""); MDCT_PKA(o7, t7, u7, "");
-  }
-  MDCT_PKM(p[0], o0, K.nm, MDCT_K_LL); MDCT_PKM(p[1], o1, K.nm, MDCT_K_LL); MDCT_PKM(p[2], o2, K.nm, MDCT_K_LL); MDCT_PKM(p[3], o3, K.nm, MDCT_K_LL);
-  MDCT_PKM(p[4], o4, K.nm, MDCT_K_LL); MDCT_PKM(p[5], o5, K.nm, MDCT_K_LL); MDCT_PKM(p[6], o6, K.nm, MDCT_K_LL); MDCT_PKM(p[7], o7, K.nm, MDCT_K_LL);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -625,11 +437,7 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
     {
       const f32x2 qp = reinterpret_cast<const f32x2 *>(qt.q)[v * 4 + j];
       f32x2 m;
-#if MDCT_PK_REORDER == 2
       m = col[j][v] * qp;
-#else
-      MDCT_PKM(m, col[j][v], qp, MDCT_K_LH);
-#endif
       if constexpr (SAFE)
       {
         out[v * 8 + kPairA[j]] = (uint32_t)clamp255((int32_t)((uint32_t)cvtps_epi32_exact(m.x) + 127u));
@@ -640,11 +448,7 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
         f32x2 t;
         m.x = __builtin_amdgcn_fmed3f(m.x, -128.0f, 127.0f);
         m.y = __builtin_amdgcn_fmed3f(m.y, -128.0f, 127.0f);
-#if MDCT_PK_REORDER == 2
         t = m + K.nm.yy; // + (magic, magic)
-#else
-        MDCT_PKA(t, m, K.nm, MDCT_K_HH); // + (magic, magic)
-#endif
         out[v * 8 + kPairA[j]] = __float_as_uint(t.x);
         out[v * 8 + kPairB[j]] = __float_as_uint(t.y);
       }
@@ -652,6 +456,21 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
   }
 }
 
+// Scalar tiers: the table of the 256 quotients px / 255.f lives in LDS and every lane looks up 64 of them.  With ONE copy of the
+// table a wave's 64 lookups of one instruction hit random entries, i.e. random banks: 3.6 conflict cycles per active LDS cycle
+// (profiles/r03_pmc_raw.txt), and the BLOCK layout's kernel stayed at 37 us when its vector work fell from 962 to 738 instructions.
+// kDivTabCopies = 32: entry e of copy k at dword e * 32 + k -- lane l reads copy l & 31, so the 32 lanes an LDS cycle serves sit in 32
+// different banks whatever they look up.  32 KiB per workgroup; the STEREO layout (17 KiB of output staging besides) keeps one copy.
+#ifndef MDCT_BLOCK_STAGE
+#define MDCT_BLOCK_STAGE 1
+#endif
+#ifndef MDCT_DIVTAB_COPIES_BLOCK
+#define MDCT_DIVTAB_COPIES_BLOCK 1
+#endif
+#ifndef MDCT_DIVTAB_COPIES_STEREO
+#define MDCT_DIVTAB_COPIES_STEREO 1
+#endif
+constexpr int kDivTabCopies(int layout) { return layout == MDCT_LAYOUT_BLOCK ? MDCT_DIVTAB_COPIES_BLOCK : MDCT_DIVTAB_COPIES_STEREO; }
 // B2..B5 on packed fp32.  The first pass runs "horizontally" over the 8 lines of the block (rows for the
 // encq tiers, :347-358 / :1608-1636; columns for the stereo tiers, which transpose first, :961-1004 /
 // :225-241), leaving the pairs (0,4)(2,6)(1,3)(5,7) of first-pass coefficients side by side; the second
@@ -669,7 +488,17 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
     constexpr int r = decltype(r_)::value, c = decltype(c_)::value;
     const uint32_t w = c < 4 ? rows[r].x : rows[r].y;
     if constexpr (PROFILE == MDCT_PROFILE_REF_SCALAR)
-      return px_div255[(w >> (8 * (c & 3))) & 0xFF]; // px / 255.f (:222, :343), one of 256 values (see kernel)
+    { // px / 255.f (:222, :343), one of 256 values (see kernel)
+      if constexpr (kDivTabCopies(LAYOUT) == 1)
+        return px_div255[(w >> (8 * (c & 3))) & 0xFF];
+      else
+      { // entry e of the lane's own copy at byte (e << 7) + (lane & 31) * 4: a shift that lands byte c's bits on bits 7..14, then one
+        // v_and_or with the lane's offset (px_div255 arrives already offset by the lane)
+        constexpr int sh = 8 * (c & 3) - 7;
+        const uint32_t moved = sh < 0 ? w << 7 : w >> sh;
+        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(px_div255) + (moved & 0x7F80u));
+      }
+    }
     else
       return ubyte_to_float<(c & 3)>(w);
   };
@@ -689,14 +518,7 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
     f32x2 a67 = {at(integral_constant<int, 6>{}), at(integral_constant<int, 7>{})};
     if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
     { // px * (1.0f / 255.0f), :949
-#if MDCT_PK_REORDER == 2
       a01 = a01 * K.bias.xx; a23 = a23 * K.bias.xx; a45 = a45 * K.bias.xx; a67 = a67 * K.bias.xx;
-#else
-      MDCT_PKM(a01, a01, K.bias, MDCT_K_LL);
-      MDCT_PKM(a23, a23, K.bias, MDCT_K_LL);
-      MDCT_PKM(a45, a45, K.bias, MDCT_K_LL);
-      MDCT_PKM(a67, a67, K.bias, MDCT_K_LL);
-#endif
     }
     dct8_h<K1D>(K, a01, a23, a45, a67, P[0][i], P[1][i], P[2][i], P[3][i]);
   };
@@ -712,18 +534,10 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
       const f32x2 qp = reinterpret_cast<const f32x2 *>(qt.q)[m * 4 + j];
       const int sa = kPairA[j] * 8 + m, sb = kPairB[j] * 8 + m;
       f32x2 v;
-#if MDCT_PK_REORDER == 2
       v = P[j][m] * qp;
-#else
-      MDCT_PKM(v, P[j][m], qp, MDCT_K_LH);
-#endif
       if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
       { // B2/B3 :1020  clamp(rne(f*q + 127.0f), 0, 255)
-#if MDCT_PK_REORDER == 2
         v = v + K.bias.yy;
-#else
-        MDCT_PKA(v, v, K.bias, MDCT_K_HH);
-#endif
         if constexpr (SAFE)
         {
           out[sa] = (uint32_t)clamp255(cvtps_epi32_exact(v.x));
@@ -734,40 +548,29 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
           f32x2 t;
           v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 255.0f);
           v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 255.0f);
-#if MDCT_PK_REORDER == 2
           t = v + K.nm.yy;
-#else
-          MDCT_PKA(t, v, K.nm, MDCT_K_HH);
-#endif
           out[sa] = __float_as_uint(t.x);
           out[sb] = __float_as_uint(t.y);
         }
       }
       else
-      { // B4/B5 :245, :362  (uint8_t)roundf(_clamp(f*qs + 127/255, 0, 1) * 255), see quant_scalar
-        f32x2 x, t, r, d;
-#if MDCT_PK_REORDER == 2
-        v = v + K.bias.xx;
-#else
-        MDCT_PKA(v, v, K.bias, MDCT_K_LL);
-#endif
-        // _clamp(v, 0, 1) of :50-54 with NaN -> 0: v_med3_f32 returns min3 when an operand is NaN, and min ignores NaN
-        v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 1.0f);
-        v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 1.0f);
-#if MDCT_PK_REORDER == 2
-        x = v * K.bias.yy;
-        t = x + K.nm.yy;
-        asm volatile("" : "+v"(t)); // keeps (x + magic) - magic from being folded back to x
-        r = t - K.nm.yy;
-        d = x - r;
-#else
-        MDCT_PKM(x, v, K.bias, MDCT_K_HH);
-        MDCT_PKA(t, x, K.nm, MDCT_K_HH);
-        MDCT_PKA(r, t, K.nm, MDCT_K_HH " " MDCT_NEG_B);
-        MDCT_PKA(d, x, r, MDCT_NEG_B);
-#endif
-        out[sa] = __float_as_uint(t.x) + (d.x == 0.5f ? 1u : 0u);
-        out[sb] = __float_as_uint(t.y) + (d.y == 0.5f ? 1u : 0u);
+      { // B4/B5 :245, :362  (uint8_t)roundf(_clamp(f*qs + 127/255, 0, 1) * 255) in three operations per coefficient pair:
+        //   c = clamp(v + 127/255, 0, 1)   one v_pk_add_f32 with the clamp modifier; NaN -> 0 (DX10_CLAMP), which is what
+        //                                  _clamp (:50-54, NaN passes) followed by x86's (uint8_t) cast of NaN yields
+        //   s = fma(c, 255, pred(0.5))     one rounding; pred(0.5) = 0.5 - 2^-25
+        //   byte = trunc(s)                v_cvt_u32_f32
+        // roundf(rn(c * 255)) == trunc(rn(c * 255 + pred(0.5))) for EVERY float c in [0, 1]: checked exhaustively over all 2^30 + 1
+        // of them (tools/check_roundf_forms.py, profiles/r04_roundf_forms_exhaustive.log; with 0.5 instead of pred(0.5), fused or
+        // not, exactly one c fails: 0x3B008080, whose c * 255 rounds to pred(0.5)).  The fused multiply-add is not the reference's
+        // arithmetic, it is a shorter way to the same byte -- 5 vector instructions per pair where magic-number rounding plus the
+        // tie fix-up took 11 (944 -> 752 per wave).
+        f32x2 s2;
+        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] clamp\n\t"
+            "v_pk_fma_f32 %0, %0, %3, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]"
+            : "=&v"(s2)
+            : "v"(v), "s"(K.nm), "s"(K.bias));
+        out[sa] = (uint32_t)s2.x;
+        out[sb] = (uint32_t)s2.y;
       }
     }
   }
@@ -1005,10 +808,25 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
   if constexpr (PROFILE == MDCT_PROFILE_REF_SCALAR)
   {
     static_assert(kWG == 256, "one table entry per thread");
-    __shared__ float div_tab[256];
-    div_tab[threadIdx.x] = (float)threadIdx.x / 255.f;
+    constexpr int COPIES = kDivTabCopies(LAYOUT);
+    static_assert(COPIES == 1 || COPIES == 32, "one copy, or one per lane of a half wave");
+    __shared__ __attribute__((aligned(16))) float div_tab[256 * COPIES];
+    const float quot = (float)threadIdx.x / 255.f;
+    if constexpr (COPIES == 1)
+    {
+      div_tab[threadIdx.x] = quot;
+      px_div255 = div_tab;
+    }
+    else
+    {
+      typedef float f32x4_l __attribute__((ext_vector_type(4)));
+      const f32x4_l q4 = {quot, quot, quot, quot};
+#pragma unroll
+      for (int k = 0; k < COPIES / 4; k++)
+        reinterpret_cast<f32x4_l *>(div_tab + threadIdx.x * COPIES)[k] = q4;
+      px_div255 = div_tab + (threadIdx.x & 31);
+    }
     wg_sync();
-    px_div255 = div_tab;
   }
 
   uint32_t q[64];
@@ -1069,6 +887,11 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
   }
   else if constexpr (LAYOUT == MDCT_LAYOUT_BLOCK)
   {
+    // Left to itself a lane stores its block's 64 bytes as 4 x 16: every store instruction of the wave then touches a quarter of each
+    // of 64 cache lines.  MDCT_BLOCK_STAGE: the pieces go through wave-private LDS (block stride 80 B: conflict-free b128 both ways)
+    // and leave as four contiguous 1 KiB stores, like the q32 layout's.
+    constexpr int kBlockStride = 80;
+    __shared__ __attribute__((aligned(16))) uint8_t blds[(TILED && MDCT_BLOCK_STAGE) ? (kWG / 64) * 64 * kBlockStride : 16];
     if (valid)
     {
       uint8_t *dst = a.to + (size_t)by * a.out_strip + (size_t)bx * 64;
@@ -1080,10 +903,24 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
 #pragma unroll
         for (int j = 0; j < 4; j++)
           w[j] = pack4_lo8(q[k * 16 + j * 4], q[k * 16 + j * 4 + 1], q[k * 16 + j * 4 + 2], q[k * 16 + j * 4 + 3]);
-        if constexpr (TILED)
+        if constexpr (TILED && MDCT_BLOCK_STAGE)
+          *reinterpret_cast<uint4 *>(blds + (threadIdx.x >> 6) * (64 * kBlockStride) + (threadIdx.x & 63) * kBlockStride + k * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        else if constexpr (TILED)
           *reinterpret_cast<u32x4_g __attribute__((address_space(1))) *>(dst_g + threadIdx.x * 64 + k * 16) = u32x4_g{w[0], w[1], w[2], w[3]};
         else
           *reinterpret_cast<uint4 *>(dst + k * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      if constexpr (TILED && MDCT_BLOCK_STAGE)
+      { // the wave's 64 blocks are 4 KiB of contiguous output: read the staged pieces back so that every store instruction covers 1 KiB
+        // (lane l of store k takes bytes [1024 k + 16 l, + 16) = piece l & 3 of the wave's block 16 k + (l >> 2)); wave-private, no barrier
+        const uint32_t lane = threadIdx.x & 63;
+        const uint8_t *wl = blds + (threadIdx.x >> 6) * (64 * kBlockStride);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+        {
+          const uint4 v = *reinterpret_cast<const uint4 *>(wl + (16 * k + (lane >> 2)) * kBlockStride + (lane & 3) * 16);
+          store16_g(dst_g + (threadIdx.x & ~63u) * 64 + k * 1024 + lane * 16, u32x4_g{v.x, v.y, v.z, v.w});
+        }
       }
     }
   }
