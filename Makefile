@@ -16,8 +16,8 @@ $(LIB): $(CSRC)/shim_host.h $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/mdct_kernels.hip $(CSRC)/mdct_api.hip $(CSRC)/shim.hip $(CSRC)/comm.hip $(CSRC)/stages.hip -ldl -o $@
 
 cli: tools/simd_dct_cli
-tools/simd_dct_cli: tools/simd_dct_cli.cpp $(LIB)
-	$(HIPCC) -O2 -std=c++17 -x hip --offload-arch=$(ARCH) -Iinclude $< -Lsimd_dct_amd -lmdct_hip -Wl,-rpath,'$$ORIGIN/../simd_dct_amd' -o $@
+tools/simd_dct_cli: tools/simd_dct_cli.cpp tools/node_pipeline.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 -x hip --offload-arch=$(ARCH) -Iinclude -Itools $< -Lsimd_dct_amd -lmdct_hip -Wl,-rpath,'$$ORIGIN/../simd_dct_amd' -o $@
 
 # plain C on the C-ABI: pixels -> baseline JPEG (tools/mdct_jpeg.c)
 jpeg_example: tools/mdct_jpeg

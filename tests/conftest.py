@@ -23,3 +23,14 @@ def golden():
     with open(os.path.join(d, "ref_vectors.json")) as f:
         meta = json.load(f)
     return meta, np.load(os.path.join(d, "ref_vectors.npz"))
+
+
+@pytest.fixture(scope="session")
+def fake_rccl(tmp_path_factory):
+    """tests/fake_rccl.c built as a shared library: the RCCL stand-in over POSIX shared memory that libmdct_hip.so binds through MDCT_RCCL_LIB"""
+    import subprocess
+
+    so = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-Wall", "-Werror", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    os.path.join(ROOT, "tests", "fake_rccl.c"), "-o", so, "-lrt", "-pthread"], check=True)
+    return so

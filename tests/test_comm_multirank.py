@@ -17,14 +17,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HERE = os.path.join(ROOT, "tests")
 
 
-@pytest.fixture(scope="session")
-def fake_rccl(tmp_path_factory):
-    so = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
-    subprocess.run(["gcc", "-O2", "-std=gnu11", "-Wall", "-Werror", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                    os.path.join(HERE, "fake_rccl.c"), "-o", so, "-lrt", "-pthread"], check=True)
-    return so
-
-
 def run_world(fake, world, cases, tmp_path, timeout=300):
     idfile = str(tmp_path / f"id_{world}")
     env = dict(os.environ, MDCT_RCCL_LIB=fake, MDCT_NO_TORCH_PRELOAD="1", OMP_NUM_THREADS="1")

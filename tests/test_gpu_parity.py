@@ -593,6 +593,40 @@ def test_cxx_cli_on_the_reference_api(tmp_path):
             assert np.array_equal(got, want), (mode, extra)
 
 
+def test_cxx_cli_async_calls_and_whole_node_batch_run(tmp_path):
+    """(i) --resident --async: the reference-API calls issued back to back with one final wait, beside the synchronous rows; the dump
+    is still the oracle's bytes.  (ii) --gpus 1 --batch: north_star's whole-node run through the C-ABI from C++ (tools/node_pipeline.h:
+    chunked mdct_batch_run on one stream, mdct_allgather_rows of every chunk on a second one behind an event) -- with one rank the
+    collective is trivial, the control flow, the three timings and the sampled verification are the real thing; world 2 and 8 of the
+    same header run on the CPU (tests/test_node_pipeline.py)."""
+    import subprocess
+
+    import __graft_entry__ as G
+
+    cli = G.build_cli()
+    W, H = 1024, 512
+    dump = tmp_path / "async.bin"
+    r = subprocess.run([cli, "synthetic:photo", str(W), str(H), "--mode", "enc-quant32", "--quality", "8", "--runs", "16", "--resident", "--async", "--to", str(dump)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    head = next(l for l in r.stdout.splitlines() if l.startswith("mode (async)"))
+    assert "calls back to back, one final wait: us per call" in head
+    rows = [l for l in r.stdout.splitlines() if l.startswith("enc-quant32 ")]
+    assert len(rows) == 2  # the synchronous row and the asynchronous one
+    per_call_us = float(rows[1].split("|")[2])
+    sync_ns_per_byte = float(rows[0].split("|")[4])
+    assert 0 < per_call_us <= sync_ns_per_byte * W * H * 1e-3 * 1.5  # not slower than waiting for every call
+    rc, want = O.run_behaviour("q32_avx", synth.plane_u8_np(W, H, "photo"), lut_x(8), W, H, 0, H)
+    assert np.array_equal(np.fromfile(dump, dtype=np.uint8), want)
+    r = subprocess.run([cli, "synthetic:photo", "0", "0", "--gpus", "1", "--batch", "24x2048x1024", "--chunk", "5", "--runs", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "24 planes per rank in 6 chunk(s) of 4" in r.stdout and "sampled slots verified" in r.stdout  # chunk 5 shrunk to a divisor of 24
+    line = next(l for l in r.stdout.splitlines() if "compute only" in l and "pipelined" in l)
+    secs = [float(x.split()[-2]) for x in line.split("|")]
+    assert len(secs) == 3 and all(0 < t < 5 for t in secs)
+    bad = subprocess.run([cli, "synthetic:photo", "0", "0", "--gpus", "1", "--batch", "24x2044x1024"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "Invalid Parameter" in bad.stdout
+
+
 def test_host_pointer_pipeline_multi_chunk():
     """plain host memory through the reference API on a plane large enough for the shim's
     chunked two-stream pipeline (several ~4 MiB strips), full range and a partial range;

@@ -9,7 +9,10 @@
 //
 //   simd_dct_cli <raw_grayscale_image_file | synthetic:noise | synthetic:photo> <X> <Y>
 //        [--to <file>] [--quality <n>] [--runs <n>] [--mode enc-quant|enc-quant32|enc-quant-stereo]...
-//        [--max-simd avx512bw|avx512f|avx2|avx|sse4.2|sse4.1|ssse3|sse3|sse2|none] [--cpu-core <n>] [--resident] [--pin] [--cold] [--device <n>] [--gpus <n>]
+//        [--max-simd avx512bw|avx512f|avx2|avx|sse4.2|sse4.1|ssse3|sse3|sse2|none] [--cpu-core <n>] [--resident [--async]] [--pin] [--cold] [--device <n>] [--gpus <n>]
+//   simd_dct_cli synthetic:photo 0 0 --gpus <n> --batch <planes>x<X>x<Y> [--chunk <planes>] [--runs <n>]
+//        north_star's whole-node run at BASELINE.json configs[3]'s shape: int16 planes, forward only, planes sharded over the ranks,
+//        every chunk all-gathered under the next chunk's kernel (tools/node_pipeline.h); compute-only / gather-only / pipelined seconds
 //
 // Build: hipcc -O2 -std=c++17 -Iinclude tools/simd_dct_cli.cpp -Lsimd_dct_amd -lmdct_hip -Wl,-rpath,'$ORIGIN/../simd_dct_amd' -o tools/simd_dct_cli
 #include <hip/hip_runtime_api.h>
@@ -33,6 +36,7 @@
 #include <vector>
 
 #include "mdct.h"
+#include "node_pipeline.h"
 #include "simd_dct_shim.h"
 
 namespace
@@ -103,8 +107,9 @@ struct Shared
   unsigned char id[MDCT_UNIQUE_ID_BYTES];
   std::atomic<int> id_ready;
   std::atomic<int> abort; // a rank failed: nobody enters another collective
-  double compute_ns[64], gather_ns[64];
+  double compute_ns[64], gather_ns[64], pipe_ns[64];
   int rc[64];
+  std::atomic<int> arrived[8]; // barriers between the phases of the batch run (one counter per barrier)
 };
 
 int run_rank_body(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file);
@@ -213,7 +218,213 @@ int run_rank_body(Shared *sh, int rank, int world, const std::vector<uint8_t> &i
   return rc;
 }
 
-int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file)
+// ---- --gpus N --batch PxWxH: BASELINE.json configs[3] through the C-ABI, host code in C++ ---------------------------
+// Every rank owns P / N whole planes (the same bytes per rank as 1/N of every plane's block rows), transforms them chunk
+// by chunk with ONE launch per chunk (mdct_batch_run) straight into its slot of the gather buffer, and all-gathers each
+// chunk in place (mdct_allgather_rows: equal shards, one ncclAllGather) on a second stream ordered by events, so that
+// chunk k's gather runs under chunk k + 1's kernel.  The control flow is tools/node_pipeline.h -- the code the CPU test
+// runs with world 2 and 8 over tests/fake_rccl.c.
+struct BatchJob
+{
+  int planes;
+  size_t W, H;
+  int chunk;
+};
+
+struct HipNode
+{
+  typedef hipStream_t Stream;
+  typedef hipEvent_t Event;
+  mdct_node::BatchShape shape;
+  size_t plane_bytes = 0;
+  mdct_comm *comm = nullptr;
+  char *gbuf = nullptr;
+  hipStream_t s_compute = nullptr, s_comm = nullptr;
+  std::vector<hipEvent_t> events;
+  std::vector<mdct_batch *> batches;
+  Shared *sh = nullptr;
+
+  Stream compute_stream() { return s_compute; }
+  Stream comm_stream() { return s_comm; }
+  Event event(int k) { return events[k]; }
+  int launch_compute(int k, Stream s) { return mdct_batch_run(batches[k], s); }
+  int launch_gather(int k, Stream s)
+  {
+    if (sh->abort.load())
+      return 3; // a peer has failed: it will not show up for this collective
+    return mdct_allgather_rows(comm, gbuf + (size_t)shape.slot(k, 0, 0) * plane_bytes, plane_bytes, (size_t)shape.world * shape.chunk_planes, s);
+  }
+  int record(Event e, Stream s) { return hipEventRecord(e, s) == hipSuccess ? 0 : 3; }
+  int wait(Stream s, Event e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess ? 0 : 3; }
+  int sync(Stream s) { return hipStreamSynchronize(s) == hipSuccess ? 0 : 3; }
+};
+
+// all ranks meet here (shared-memory counter; gives up when a rank has failed)
+bool rank_barrier(Shared *sh, int which, int world)
+{
+  sh->arrived[which].fetch_add(1);
+  while (sh->arrived[which].load() < world)
+  {
+    if (sh->abort.load())
+      return false;
+    usleep(50);
+  }
+  return !sh->abort.load();
+}
+
+void synth_i16(std::vector<int16_t> &pl, size_t W, size_t H, uint32_t seed)
+{ // simd_dct_amd/synth.py plane_i16 "photo": the 8-bit picture minus 128
+  for (size_t i = 0; i < W * H; i++)
+  {
+    const uint32_t h = mix32((uint32_t)i ^ seed);
+    const uint64_t x = i % W, y = i / W;
+    const int b = (int)(((x * 3 + y * 5) >> 2) & 0xFF);
+    const int tri = b < 128 ? b : 255 - b;
+    int px = 48 + tri + (int)((h >> 24) % 49) - 24;
+    pl[i] = (int16_t)((px < 0 ? 0 : (px > 255 ? 255 : px)) - 128);
+  }
+}
+
+int comm_setup(Shared *sh, int rank, int world, mdct_comm **comm)
+{
+  if (mdct_init(rank) != MDCT_SUCCESS)
+  {
+    printf("rank %d: mdct_init(%d) failed: %s\n", rank, rank, mdct_last_error());
+    return 2;
+  }
+  if (rank == 0)
+  {
+    if (mdct_comm_get_unique_id(sh->id) != MDCT_SUCCESS)
+    {
+      printf("rank 0: %s\n", mdct_last_error());
+      sh->id_ready.store(-1);
+      return 2;
+    }
+    sh->id_ready.store(1);
+  }
+  while (sh->id_ready.load() == 0 && !sh->abort.load())
+    usleep(1000);
+  if (sh->id_ready.load() <= 0 || sh->abort.load())
+    return 2;
+  if (mdct_comm_init(comm, rank, world, sh->id) != MDCT_SUCCESS)
+  {
+    printf("rank %d: %s\n", rank, mdct_last_error());
+    return 2;
+  }
+  return 0;
+}
+
+int run_rank_batch(Shared *sh, int rank, int world, const BatchJob &job, size_t runs)
+{
+  HipNode node;
+  node.sh = sh;
+  int rc = comm_setup(sh, rank, world, &node.comm);
+  if (rc)
+    return rc;
+  if (!mdct_node::make_shape(job.planes, world, rank, job.chunk, node.shape))
+  {
+    printf("rank %d: %d planes do not split evenly over %d ranks\n", rank, job.planes, world);
+    return 1;
+  }
+  const mdct_node::BatchShape &sp = node.shape;
+  const size_t W = job.W, H = job.H, elems = W * H;
+  node.plane_bytes = elems * sizeof(int16_t);
+  char *src = nullptr, *base = nullptr, *scratch = nullptr;
+  constexpr int kBase = 4; // distinct pictures; plane p of the batch shows picture p % 4
+  if (hipMalloc((void **)&src, (size_t)sp.per_rank * node.plane_bytes) != hipSuccess || hipMalloc((void **)&node.gbuf, (size_t)sp.planes * node.plane_bytes) != hipSuccess ||
+      hipMalloc((void **)&base, kBase * node.plane_bytes) != hipSuccess || hipMalloc((void **)&scratch, node.plane_bytes) != hipSuccess ||
+      hipStreamCreate(&node.s_compute) != hipSuccess || hipStreamCreate(&node.s_comm) != hipSuccess)
+  {
+    printf("rank %d: device allocation failed (%zu MiB for the batch's coefficients)\n", rank, ((size_t)sp.planes * node.plane_bytes) >> 20);
+    return 2;
+  }
+  {
+    std::vector<int16_t> pic(elems);
+    for (int b = 0; b < kBase; b++)
+    {
+      synth_i16(pic, W, H, 20261003u + 100u + (uint32_t)b);
+      if (hipMemcpy(base + (size_t)b * node.plane_bytes, pic.data(), node.plane_bytes, hipMemcpyHostToDevice) != hipSuccess)
+        return 2;
+    }
+    for (int p = 0; p < sp.per_rank; p++)
+      if (hipMemcpy(src + (size_t)p * node.plane_bytes, base + (size_t)((rank * sp.per_rank + p) % kBase) * node.plane_bytes, node.plane_bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+        return 2;
+    if (hipMemset(node.gbuf, 0xEE, (size_t)sp.planes * node.plane_bytes) != hipSuccess)
+      return 2;
+  }
+  node.events.resize(sp.chunks);
+  node.batches.resize(sp.chunks, nullptr);
+  for (int c = 0; c < sp.chunks; c++)
+  {
+    std::vector<mdct_plane_i16> pl(sp.chunk_planes);
+    for (int i = 0; i < sp.chunk_planes; i++)
+    {
+      pl[i].from = (const int16_t *)(src + (size_t)(c * sp.chunk_planes + i) * node.plane_bytes);
+      pl[i].to = (int16_t *)(node.gbuf + (size_t)sp.slot(c, rank, i) * node.plane_bytes);
+      pl[i].pitch_in = pl[i].pitch_out = pl[i].sizeX = W;
+      pl[i].sizeY = H;
+      pl[i].lut = nullptr;
+    }
+    if (hipEventCreateWithFlags(&node.events[c], hipEventDisableTiming) != hipSuccess || mdct_batch_create(&node.batches[c], MDCT_MODE_FWD, pl.data(), sp.chunk_planes) != MDCT_SUCCESS)
+    {
+      printf("rank %d: %s\n", rank, mdct_last_error());
+      return 2;
+    }
+  }
+  mdct_node::Pipeline<HipNode> pipe(node, sp.chunks);
+  double best[3] = {1e300, 1e300, 1e300};
+  int bar = 0;
+  for (int phase = 0; phase < 3 && rc == 0; phase++)
+  { // 0 compute only, 1 gather only, 2 pipelined; every phase entered by all ranks together, first pass of each untimed
+    if (!rank_barrier(sh, bar++, world))
+      return 3;
+    for (size_t i = 0; i < runs + 1 && rc == 0; i++)
+    {
+      const double t0 = now_ns();
+      rc = phase == 0 ? pipe.compute_only() : (phase == 1 ? pipe.gather_only() : pipe.pipelined());
+      const double dt = now_ns() - t0;
+      if (i > 0 && dt < best[phase])
+        best[phase] = dt;
+    }
+    if (rc)
+      printf("rank %d: phase %d failed (%d): %s\n", rank, phase, rc, mdct_last_error());
+  }
+  // what arrived: plane 0 of every owner's slot in the first and the last chunk against this rank's own transform of that picture
+  if (rc == 0)
+  {
+    std::vector<int16_t> got(elems), want(elems);
+    const int cs[2] = {0, sp.chunks - 1};
+    for (int ci = 0; ci < (sp.chunks > 1 ? 2 : 1) && rc == 0; ci++)
+      for (int r = 0; r < world && rc == 0; r++)
+      {
+        const int id = sp.plane_id(r, cs[ci], 0);
+        if (mdct_fwd_i16((const int16_t *)(base + (size_t)(id % kBase) * node.plane_bytes), (int16_t *)scratch, W, W, nullptr, W, H, 0, H / 8, nullptr) != MDCT_SUCCESS ||
+            hipDeviceSynchronize() != hipSuccess || hipMemcpy(want.data(), scratch, node.plane_bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(got.data(), node.gbuf + (size_t)sp.slot(cs[ci], r, 0) * node.plane_bytes, node.plane_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+          rc = 3;
+        else if (memcmp(got.data(), want.data(), node.plane_bytes) != 0)
+        {
+          printf("rank %d: gathered plane %d (owner %d, chunk %d) differs from the transform of its picture\n", rank, id, r, cs[ci]);
+          rc = 6;
+        }
+      }
+  }
+  sh->compute_ns[rank] = best[0];
+  sh->gather_ns[rank] = best[1];
+  sh->pipe_ns[rank] = best[2];
+  for (mdct_batch *b : node.batches)
+    mdct_batch_destroy(b);
+  for (hipEvent_t e : node.events)
+    (void)hipEventDestroy(e);
+  mdct_comm_destroy(node.comm);
+  (void)hipFree(src);
+  (void)hipFree(node.gbuf);
+  (void)hipFree(base);
+  (void)hipFree(scratch);
+  return rc;
+}
+
+int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file, const BatchJob *job = nullptr)
 {
   if (world > 64)
   {
@@ -226,12 +437,25 @@ int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y,
   new (sh) Shared();
   sh->id_ready.store(0);
   sh->abort.store(0);
+  for (auto &a : sh->arrived)
+    a.store(0);
   std::vector<pid_t> kids;
   for (int r = 0; r < world; r++)
   {
     const pid_t p = fork(); // nothing has touched HIP yet in this process
     if (p == 0)
-      _exit(run_rank(sh, r, world, in, X, Y, table, stereo, runs, out_file));
+    {
+      int code;
+      if (job)
+      {
+        code = run_rank_batch(sh, r, world, *job, runs);
+        if (code != 0)
+          sh->abort.store(1);
+      }
+      else
+        code = run_rank(sh, r, world, in, X, Y, table, stereo, runs, out_file);
+      _exit(code);
+    }
     kids.push_back(p);
   }
   // Poll, with a deadline: a rank that fails while the others are already inside a collective (ncclCommInitRank, the
@@ -243,6 +467,7 @@ int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y,
   size_t alive = kids.size();
   std::vector<bool> done(kids.size(), false);
   double kill_at_ns = 0;
+  bool killed = false;
   while (alive)
   {
     for (size_t i = 0; i < kids.size(); i++)
@@ -250,7 +475,7 @@ int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y,
       if (done[i])
         continue;
       int st = 0;
-      const pid_t w = waitpid(kids[i], &st, WNOHANG);
+      const pid_t w = waitpid(kids[i], &st, killed ? 0 : WNOHANG); // after the kill: one blocking wait per remaining child
       if (w == 0)
         continue;
       done[i] = true;
@@ -264,19 +489,38 @@ int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y,
       }
     }
     const double t = now_ns();
-    if (alive && ((kill_at_ns != 0 && t > kill_at_ns) || t > deadline_ns))
+    if (alive && !killed && ((kill_at_ns != 0 && t > kill_at_ns) || t > deadline_ns))
     {
       printf("--gpus: %s; ending %zu remaining rank(s)\n", t > deadline_ns ? "timed out" : "a rank failed", alive);
       for (size_t i = 0; i < kids.size(); i++)
         if (!done[i])
           kill(kids[i], SIGKILL);
       rc = rc ? rc : 5;
-      kill_at_ns = deadline_ns + 1e18; // once
+      killed = true; // said and done once
     }
-    if (alive)
+    if (alive && !killed)
       usleep(2000);
   }
-  if (rc == 0)
+  if (rc == 0 && job)
+  {
+    double c = 0, g = 0, pl = 0;
+    for (int r = 0; r < world; r++)
+    {
+      c = sh->compute_ns[r] > c ? sh->compute_ns[r] : c;
+      g = sh->gather_ns[r] > g ? sh->gather_ns[r] : g;
+      pl = sh->pipe_ns[r] > pl ? sh->pipe_ns[r] : pl;
+    }
+    mdct_node::BatchShape sp;
+    mdct_node::make_shape(job->planes, world, 0, job->chunk, sp);
+    const double px = (double)job->planes * job->W * job->H, out_bytes = px * 2;
+    const double bus = world > 1 ? out_bytes * (world - 1) / world / g : 0.0; // bytes per ns == GB/s each rank receives
+    printf("fwd-i16 batch %dx%zux%zu over %d GPU(s): %d planes per rank in %d chunk(s) of %d, one launch + one in-place all-gather per chunk | result sdr_Success (sampled slots verified)\n",
+           job->planes, job->W, job->H, world, sp.per_rank, sp.chunks, sp.chunk_planes);
+    printf("  slowest rank, best of %zu: compute only %.6f s | gather only %.6f s | pipelined (gather k under kernel k+1) %.6f s\n", runs, c * 1e-9, g * 1e-9, pl * 1e-9);
+    printf("  whole batch: %.0f Mpx/s pipelined, %.0f Mpx/s compute only (%.1f GB/s algorithmic per GPU = %.1f %% of 8 TB/s) | gather bus %.1f GB/s per GPU = %.1f %% of 7 x 153 GB/s xGMI\n",
+           px / (pl * 1e-9) / 1e6, px / (c * 1e-9) / 1e6, 4.0 * px / world / c, 100.0 * 4.0 * px / world / c / 8000.0, bus, 100.0 * bus / (7 * 153.0));
+  }
+  else if (rc == 0)
   {
     double c = 0, g = 0;
     for (int r = 0; r < world; r++)
@@ -312,11 +556,16 @@ int main(int argc, char **argv)
     puts("\t--cold\t\t\t\tDo not call mdct_shim_warmup() first: the first run then contains the one-time initialisation.");
     puts("\t--device <n>\t\t\tHIP device ordinal.");
     puts("\t--gpus <n>\t\t\tOne process per GPU: block rows sharded, coefficients all-gathered over RCCL (enc-quant32 or enc-quant-stereo, device-resident).");
+    puts("\t--batch <P>x<X>x<Y> [--chunk <n>]\tWith --gpus: P int16 planes, forward only, sharded by planes; chunks all-gathered under the next chunk's kernel.");
+    puts("\t--async\t\t\t\tWith --resident: also issue the runs back to back on one stream with a single wait at the end.");
     return 1;
   }
   const std::string filename = argv[1];
   const size_t X = strtoull(argv[2], nullptr, 10), Y = strtoull(argv[3], nullptr, 10);
-  if (X == 0 || Y == 0)
+  bool batch_mode = false;
+  for (int i = 4; i < argc; i++)
+    batch_mode = batch_mode || std::string(argv[i]) == "--batch";
+  if ((X == 0 || Y == 0) && !batch_mode)
   {
     puts("Invalid Resolution Specified. Aborting.");
     return 1;
@@ -324,8 +573,9 @@ int main(int argc, char **argv)
   const char *out_file = nullptr;
   size_t runs = 128; // main.cpp:21
   float quality = 1.0f;
-  bool resident = false, pin = false, cold = false;
+  bool resident = false, pin = false, cold = false, async_calls = false;
   int device = 0, max_simd = MDCT_SIMD_AVX2, gpus = 0;
+  BatchJob job{0, 0, 0, 8};
   bool m_encq = false, m_q32 = false, m_stereo = false;
   for (int i = 4; i < argc; i++)
   {
@@ -339,6 +589,19 @@ int main(int argc, char **argv)
     else if (a == "--cold") cold = true;
     else if (a == "--device") device = atoi(next());
     else if (a == "--gpus") gpus = atoi(next());
+    else if (a == "--async") async_calls = true;
+    else if (a == "--chunk") job.chunk = atoi(next());
+    else if (a == "--batch")
+    {
+      unsigned long long bw = 0, bh = 0;
+      if (sscanf(next(), "%dx%llux%llu", &job.planes, &bw, &bh) != 3 || job.planes <= 0 || bw == 0 || bh == 0 || bw % 8 || bh % 8)
+      {
+        puts("Invalid Parameter: --batch <planes>x<X>x<Y> with X, Y multiples of 8.");
+        return 1;
+      }
+      job.W = bw;
+      job.H = bh;
+    }
     else if (a == "--mode")
     {
       const std::string m = next();
@@ -373,6 +636,15 @@ int main(int argc, char **argv)
   {
     puts("Invalid Parameter.");
     return 1;
+  }
+  if (job.planes > 0)
+  { // north_star's whole-node run (int16 planes, forward only); forks before the first HIP call of this process
+    if (gpus <= 0)
+    {
+      puts("--batch needs --gpus <n> (1 is fine).");
+      return 1;
+    }
+    return run_multi_gpu(gpus, std::vector<uint8_t>(), 0, 0, nullptr, false, runs > 16 ? 5 : runs, nullptr, &job);
   }
 
   const size_t fileSize = X * Y;
@@ -501,6 +773,45 @@ int main(int argc, char **argv)
       snprintf(of_copy, sizeof of_copy, "%.1f", 100.0 * alg / copy_GBps);
     printf("%-16s | %-20s | %13.5f | %10.5f (%8.5f) | %13.5f | %10.5f (%8.5f) | %20.2f | %10.2f | %18.1f | %9.1f | %11.1f | %18s\n", m.name, result_name(r), c.min_ns / fileSize, c.mean_ns / fileSize,
            c.sd_ns / fileSize, s.min_ns / fileSize, s.mean_ns / fileSize, s.sd_ns / fileSize, mib / (s.min_ns * 1e-9), mib / (s.mean_ns * 1e-9), px / (s.min_ns * 1e-9) / 1e6, alg, 100.0 * alg / 8000.0, of_copy);
+  }
+
+  if (resident && async_calls)
+  { // The rows above are what a caller of the reference API gets who, like main.cpp:514, waits for every call.  The same calls issued
+    // back to back (mdct_shim_set_async: a device-pointer call returns once its kernel is queued) with one wait at the end:
+    hipStream_t st;
+    if (hipStreamCreate(&st) != hipSuccess)
+      return 2;
+    mdct_shim_set_stream(st);
+    mdct_shim_set_async(1);
+    puts("mode (async)     | result               | calls back to back, one final wait: us per call | actual Mpx/s | alg. GB/s | % of 8 TB/s | % of measured copy");
+    for (const Mode &m : modes)
+    {
+      if (!m.on)
+        continue;
+      simdDctResult r = sdr_Success;
+      for (int warm = 0; warm < 2 && r == sdr_Success; warm++)
+      {
+        const double t0 = now_ns();
+        for (size_t i = 0; i < runs && r == sdr_Success; i++)
+          r = m.fn(p_in, p_out, table, X, Y, 0, Y);
+        if (hipStreamSynchronize(st) != hipSuccess)
+          r = sdr_NotSupported;
+        const double per = (now_ns() - t0) / runs;
+        if (warm == 1 && r == sdr_Success)
+        {
+          const double px = fileSize * m.covered, alg = 2.0 * px / per;
+          printf("%-16s | %-20s | %47.2f | %12.1f | %9.1f | %11.1f | %18.1f\n", m.name, result_name(r), per * 1e-3, px / (per * 1e-9) / 1e6, alg, 100.0 * alg / 8000.0, copy_GBps > 0 ? 100.0 * alg / copy_GBps : 0.0);
+        }
+      }
+      if (r != sdr_Success)
+      {
+        printf("%-16s | %-20s | %s\n", m.name, result_name(r), mdct_last_error());
+        rc_all = 3;
+      }
+    }
+    mdct_shim_set_async(0);
+    mdct_shim_set_stream(nullptr);
+    (void)hipStreamDestroy(st);
   }
 
   if (out_file)
