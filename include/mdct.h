@@ -256,10 +256,12 @@ int mdct_jpeg_pack_rows_counted(const uint8_t *segments, const uint32_t *seg_byt
  * row_work: by1 - by0 + 2 device uint64 that the CALLER ZEROES ONCE (hipMemset) before the first call; every call leaves them ready
  * for the next one, also for replays of a captured launch and for another number of rows.  Calls that share a row_work must
  * not overlap (same stream, or ordered by events); concurrent calls take one row_work each.
- * Every row adds up the lengths of all rows before it: fine up to some tens of thousands of rows (8192 x 8192: 1024), but the work grows with
- * the square of the row count -- at 65535 rows of 8 pixels the two separate calls are 1.6 x faster (tools/time_many_rows.py).
- * Should a row not hear from its predecessors within ~1 s (cannot happen while rows are dispatched in order), it writes
- * UINT64_MAX to its row_offsets entry instead of a scan. */
+ * Up to 16384 rows every row adds up the lengths of all rows before it in the same launch; taller planes take two launches
+ * internally (the fused coder, then the counted packing), same bytes, same arguments.
+ * FAILURE INDICATOR: row_offsets[by1 - by0] == UINT64_MAX.  Should a row not hear from all of its predecessors within ~1 s (cannot
+ * happen while rows are dispatched in order), it sets a sticky word in row_work, the launch ends with UINT64_MAX there, and so does
+ * every later call on the same row_work (without coding anything) until the caller zeroes row_work again.  A total above
+ * out_capacity means the scan did not fit (rows that would end beyond it are not written). */
 int mdct_fwd_u8_jpeg_scan(const uint8_t *px, size_t pitch, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1,
                           int chroma, uint8_t *seg_work, size_t seg_stride, uint64_t *row_work, int first_rst, uint8_t *out, size_t out_capacity,
                           uint64_t *row_offsets, void *stream);

@@ -659,6 +659,7 @@ struct PxScanOut
   uint64_t *row_offsets;
 };
 
+constexpr size_t kChainMaxRows = 16384; // beyond: two launches (see run_px_huffman)
 static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, int chroma, uint8_t *out, size_t seg_stride,
                           uint32_t *seg_bytes, uint32_t *ff_counts, const PxScanOut *pack, void *stream)
 {
@@ -711,7 +712,9 @@ static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const f
   a.dc_shift = level_shift ? 64.0f * 128.0f : 0.0f;
   mdct_huff_build(chroma ? 2 : 0, a.dc, 12);
   mdct_huff_build(chroma ? 3 : 1, a.ac, 256);
-  // 8-bit pixels through a table with every entry >= 1.01: |AC level| <= 8 * 128 / 1.01 < 1023 and the DC fits int16 by far, the
+  // 8-bit pixels through a table with every entry >= 1.01: an AC coefficient of 8-bit pixels is at most 1020 in magnitude (an exact bound -- half of
+  // 8 * 255, reached by the sign patterns of basis functions (0,4), (4,0), (4,4) -- not the looser 8 * 128), so |AC level| <= 1020 / 1.01 = 1009.9 < 1023
+  // (13 levels of margin for the float pipeline's rounding; tests/test_entropy.py drives all 64 patterns through 1.01) and the DC fits int16 by far: the
   // kernel's saturations can never fire (mdct_kernels.hip: CLAMP)
   bool clamp = true;
   if (!i16_in && lut)
@@ -719,6 +722,25 @@ static int run_px_huffman(const void *px_, bool i16_in, size_t pitch_px, const f
     clamp = false;
     for (int i = 0; i < 64; i++)
       clamp = clamp || !(fabsf(lut[i]) >= 1.01f);
+  }
+  if (pack && by1 - by0 > kChainMaxRows)
+  { // Every row of the one-launch form adds up the lengths of all rows before it: quadratic, and past ~16 k rows slower than the packing
+    // kernel's scan (tools/time_many_rows.py).  Taller planes therefore take the fused kernel and mdct_jpeg_pack_rows_counted, with the
+    // per-row byte and 0xFF counts parked in the caller's row_work (8 bytes per row are there), which is zeroed again behind them --
+    // row_work[0..1] (epoch, failure word) are not touched, so the array stays valid for one-launch calls.
+    const size_t n = by1 - by0;
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(pack->row_work + 2);
+    a.scan = nullptr;
+    a.seg_bytes = cnt - by0; // (the kernel indexes both by the plane's row number)
+    a.ff_counts = cnt + n - by0;
+    hipError_t e = mdct::launch_px_huffman(a, i16_in, false, clamp, (uint32_t)n, (hipStream_t)stream);
+    if (e != hipSuccess)
+      return hip_fail(e, "pixels -> Huffman rows kernel launch");
+    r = mdct_jpeg_pack_rows_counted(out + by0 * seg_stride, cnt, cnt + n, seg_stride, n, pack->first_rst, pack->scan, pack->capacity, pack->row_offsets, stream);
+    if (r)
+      return r;
+    e = hipMemsetAsync(pack->row_work + 2, 0, n * sizeof(uint64_t), (hipStream_t)stream);
+    return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "hipMemsetAsync(row_work)");
   }
   const hipError_t e = mdct::launch_px_huffman(a, i16_in, pack != nullptr, clamp, (uint32_t)(by1 - by0), (hipStream_t)stream);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "pixels -> Huffman rows kernel launch");

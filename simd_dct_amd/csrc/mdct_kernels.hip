@@ -1650,7 +1650,19 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
   const uint32_t row = a.by0 + blockIdx.x;
   uint32_t tag = 0; // PACK: the chain's epoch, read now so that nobody waits for it later
   if constexpr (PACK)
+  {
+    if (chain_failed(a.work))
+    { // an earlier launch on this work array failed: nothing is coded or published until the caller has zeroed it again
+      if (tid == 0)
+      {
+        a.row_off[blockIdx.x] = ~0ull;
+        if (blockIdx.x + 1 == a.n_rows)
+          a.row_off[a.n_rows] = ~0ull;
+      }
+      return;
+    }
     tag = __builtin_amdgcn_readfirstlane(chain_epoch_tag(a.work));
+  }
   for (uint32_t i = tid; i < 256; i += kChunk)
     ac[i] = a.ac[i];
   if (tid < 12)
@@ -1816,11 +1828,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
     const unsigned long long base = chain_base(a.work, r, tag, wave_sum, ok);
     if (tid == 0)
     {
+      if (!ok)
+        __hip_atomic_fetch_or(a.work + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sticky: this launch and every later one fail visibly
       a.row_off[r] = ok ? base : ~0ull;
       if (!marker)
-      {
-        chain_next_epoch(a.work, tag);
-        a.row_off[a.n_rows] = ok ? base + len : ~0ull;
+      { // the last row has waited for every other row, so any row that gave up has set work[1] by now
+        const bool failed = !ok || chain_failed(a.work);
+        if (!failed)
+          chain_next_epoch(a.work, tag); // (a failed launch keeps its epoch: its stragglers must not look like the next launch's rows)
+        a.row_off[a.n_rows] = failed ? ~0ull : base + len;
       }
     }
     if (ok && base + len <= a.capacity) // a row that does not fit is not written: the caller sees row_off[n_rows] > capacity

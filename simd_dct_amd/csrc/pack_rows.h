@@ -234,30 +234,39 @@ struct PackRow
 };
 
 // ---- the one-launch encoder's chain between the rows (k_px_huffman_rows<.., PACK>)
-// work[0]: launch epoch, work[1]: reserved, work[2 + r]: epoch tag << 32 | stuffed length of row r.  The caller zeroes `work`
-// once; every launch leaves it ready for the next one (also for a replay of the same captured launch, which is why the epoch
+// work[0]: launch epoch, work[1]: sticky failure word, work[2 + r]: epoch tag << 32 | stuffed length of row r.  The caller zeroes
+// `work` once; every launch leaves it ready for the next one (also for a replay of the same captured launch, which is why the epoch
 // lives on the device and not in the kernel arguments).  A row reads the epoch when it starts and publishes when it has coded its
 // segment; the LAST row, once it has seen every other row's tag, opens the next epoch -- at that point every row of this launch
 // has read the epoch long ago, and rows still waiting compare the tags with their own copy of it.
-constexpr uint32_t kChainSpinLimit = 1u << 22; // x ~0.3 us: a predecessor that has not published by then never will
+// Failure: a row whose predecessors do not all publish within kChainDeadlineTicks (ONE deadline for the whole wait, on the constant
+// 100 MHz clock) sets work[1] and writes no scan.  The last row publishes row_off[n_rows] = UINT64_MAX when work[1] is set -- it waits
+// for every row, so it finishes after any row that gave up -- and does NOT open the next epoch; every later launch on the same work
+// array sees work[1] at its start, writes UINT64_MAX and does nothing else, until the caller zeroes the array again.
+// row_off[n_rows] == UINT64_MAX is thus the one failure indicator of a launch (include/mdct.h).
+// Forward progress rests on in-order dispatch: a row only ever waits for rows with smaller workgroup indices, which the hardware has
+// started before it (one workgroup queue per launch, dealt round-robin to the XCDs in index order), and every row publishes BEFORE it
+// waits -- so the lowest row that has not published yet is running, not queued behind its waiters.
+constexpr unsigned long long kChainDeadlineTicks = 100000000ull; // ~1 s of wall_clock64()
 
 __device__ __forceinline__ uint32_t chain_epoch_tag(const unsigned long long *work)
 {
   const uint32_t tag = (uint32_t)__hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   return tag ? tag : 1u; // 0 is what a slot of the zeroed work array holds
 }
+__device__ __forceinline__ bool chain_failed(const unsigned long long *work) { return __hip_atomic_load(work + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 
 __device__ __forceinline__ void chain_publish(unsigned long long *work, uint32_t r, uint32_t tag, uint32_t len)
 {
   __hip_atomic_store(work + 2 + r, ((unsigned long long)tag << 32) | len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// sum of the lengths of rows 0..r-1 once they are all published (rows are dispatched in order and publish before they wait, so
-// the lowest unfinished row never waits for a row that is not running); ok = false if the spin limit ran out
+// sum of the lengths of rows 0..r-1 once they are all published; ok = false if the deadline passed first (the caller then sets work[1])
 __device__ __forceinline__ unsigned long long chain_base(const unsigned long long *work, uint32_t r, uint32_t tag, unsigned long long *wave_sum, bool &ok)
 {
   unsigned long long s = 0;
   uint32_t bad = 0;
+  const unsigned long long t0 = wall_clock64();
   for (uint32_t i0 = threadIdx.x; i0 < r; i0 += 4 * 256)
   { // four tags per thread in flight; then wait for those that were not there yet
     unsigned long long v[4];
@@ -269,7 +278,7 @@ __device__ __forceinline__ unsigned long long chain_base(const unsigned long lon
     {
       for (uint32_t spins = 0; (uint32_t)(v[k] >> 32) != tag; spins++)
       {
-        if (spins == kChainSpinLimit)
+        if (bad || ((spins & 63) == 63 && wall_clock64() - t0 > kChainDeadlineTicks))
         {
           bad = 1;
           break;

@@ -52,7 +52,7 @@ __device__ __forceinline__ void scan_emit(const int (&val)[64], uint8_t *lv, uin
       pos += nz ? 1u : 0u;
       run = nz ? 0u : run + 1u;
     }
-    my_rn[pos] = 0; // pos == 64: the pad
+    my_rn[pos] = 0; // trailing zeros left their run at [pos]: clear it -- runs beyond the last pair are 0 in the record format (pos == 64 lands in the pad)
   }
   else
   {

@@ -486,6 +486,87 @@ def test_one_launch_pixels_to_scan_equals_the_two_launch_path():
 
 
 @pytest.mark.gpu
+def test_full_occupancy_slices_of_the_soaks():
+    """Always on (the long forms stay opt-in below): every kernel of the library on whole 8192^2 / 4104-wide / 2048-wide planes, 24 launches
+    each compared on the device with the first (tools/soak_determinism.py), and 4 s of the one-launch encoder against the two-launch
+    path on random sizes, tables and contents (tools/soak_jpeg_scan.py).  The small differential cases of the other tests never fill
+    the chip; the barrier without its LDS wait of round 3 (csrc/wg_sync.h) only showed with every CU holding several dense rows."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cmd, ok in (([sys.executable, os.path.join(root, "tools", "soak_determinism.py"), "24"], "soak ok"), ([sys.executable, os.path.join(root, "tools", "soak_jpeg_scan.py"), "4"], None)):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "!!" not in r.stdout and (ok is None or ok in r.stdout), r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_one_launch_scan_failure_word_is_sticky_and_tall_planes_take_two_launches():
+    """(i) row_work[1] is the chain's sticky failure word: with it set (as a row that ran out of patience leaves it) a call codes nothing
+    and ends with row_offsets[n_rows] == UINT64_MAX -- the one failure indicator include/mdct.h names -- call after call, until the caller
+    zeroes row_work; then the same array works again.  (ii) more than 16384 block rows: the call runs the fused coder and the counted
+    packing as two launches (the one-launch form's look-back is quadratic in the row count), same scan and offsets, and leaves row_work
+    fit for one-launch calls."""
+    api.init(0)
+    W, H = 512, 128
+    n, stride = H // 8, api.huffman_seg_stride(W)
+    img = synth.plane_u8_torch(W, H, "photo", seed=5)
+    work = torch.zeros((n + 2,), dtype=torch.int64, device="cuda")
+    seg_w = torch.empty((n * stride,), dtype=torch.uint8, device="cuda")
+    good = torch.zeros((W * H,), dtype=torch.uint8, device="cuda")
+    goff = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
+    api.fwd_u8_jpeg_scan(img, W, H, seg_w, work, good, goff, lut=K1_LUMA)
+    torch.cuda.synchronize()
+    total = int(goff[-1].item())
+    assert 0 < total < W * H
+    work[1] = 1  # what a row whose predecessors did not publish in time leaves behind
+    for rep in range(2):
+        got = torch.full((W * H,), 0x33, dtype=torch.uint8, device="cuda")
+        off = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
+        assert api.fwd_u8_jpeg_scan(img, W, H, seg_w, work, got, off, lut=K1_LUMA, check=False) == 0  # the launch itself succeeds ...
+        torch.cuda.synchronize()
+        assert int(off[-1].item()) == -1 and (got == 0x33).all()  # ... its result says failure (UINT64_MAX), and no scan byte was written
+    work.zero_()
+    got = torch.zeros((W * H,), dtype=torch.uint8, device="cuda")
+    off = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
+    api.fwd_u8_jpeg_scan(img, W, H, seg_w, work, got, off, lut=K1_LUMA)
+    torch.cuda.synchronize()
+    assert torch.equal(off, goff) and torch.equal(got, good)
+    # (ii) 16 px wide, 17000 block rows
+    W2, H2 = 16, 17000 * 8
+    n2, stride2 = H2 // 8, api.huffman_seg_stride(W2)
+    tall = synth.plane_u8_torch(W2, H2, "photo", seed=6)
+    seg = torch.empty((n2 * stride2,), dtype=torch.uint8, device="cuda")
+    nb = torch.zeros((n2,), dtype=torch.int32, device="cuda")
+    ff = torch.zeros((n2,), dtype=torch.int32, device="cuda")
+    api.fwd_u8_huffman_rows(tall, W2, H2, seg, nb, lut=K1_LUMA, ff_counts=ff)
+    want = torch.zeros((W2 * H2,), dtype=torch.uint8, device="cuda")
+    woff = torch.zeros((n2 + 1,), dtype=torch.int64, device="cuda")
+    api.jpeg_pack_rows(seg, nb, stride2, n2, want, woff, ff_counts=ff)
+    work2 = torch.zeros((n2 + 2,), dtype=torch.int64, device="cuda")
+    seg2 = torch.empty((n2 * stride2,), dtype=torch.uint8, device="cuda")
+    for rep in range(2):
+        got2 = torch.zeros((W2 * H2,), dtype=torch.uint8, device="cuda")
+        off2 = torch.zeros((n2 + 1,), dtype=torch.int64, device="cuda")
+        api.fwd_u8_jpeg_scan(tall, W2, H2, seg2, work2, got2, off2, lut=K1_LUMA)
+        torch.cuda.synchronize()
+        assert torch.equal(off2, woff) and torch.equal(got2, want), rep
+        assert (work2 == 0).all()  # left as the caller zeroed it: a one-launch call may use it next
+    got = torch.zeros((W * H,), dtype=torch.uint8, device="cuda")
+    api.fwd_u8_jpeg_scan(img, W, H, seg_w, work2, got, off, lut=K1_LUMA)  # the same work array, now with few rows: the chained form
+    torch.cuda.synchronize()
+    assert torch.equal(off, goff) and torch.equal(got, good)
+    # a sub-range of a tall plane (row numbers of the plane index the segments; offsets count from the sub-range)
+    got2 = torch.zeros((W2 * H2,), dtype=torch.uint8, device="cuda")
+    off3 = torch.zeros((16601,), dtype=torch.int64, device="cuda")
+    api.fwd_u8_jpeg_scan(tall, W2, H2, seg2, work2, got2, off3, lut=K1_LUMA, by0=300, by1=16900, first_rst=300 % 8)
+    torch.cuda.synchronize()
+    base = int(woff[300].item())
+    assert torch.equal(off3[:-1], woff[300:16900] - base) and int(off3[-1].item()) == int(woff[16900].item()) - base - 2  # (the last row of a range carries no restart marker)
+    assert torch.equal(got2[: int(off3[-1].item())], want[base: int(woff[16900].item()) - 2])
+
+
+@pytest.mark.gpu
 def test_dense_rows_that_need_several_ring_windows_code_the_same_bytes_every_time():
     """Rows whose code does not fit the coder's LDS ring at once go through it in windows; between two windows the slots are cleared and
     OR-ed into again.  The barrier between them once came out of the compiler without its LDS wait, and under the LDS traffic of the

@@ -10,8 +10,7 @@ from simd_dct_amd import synth
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 M.init(0)
-K1 = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
-               18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+K1 = synth.JPEG_LUMA
 lut2000 = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
 lut8 = (M.QUANTIZE_BASE * np.float32(8)).astype(np.float32)
 ones = np.ones(64, dtype=np.float32)
@@ -57,6 +56,16 @@ for (W, H) in ((8192, 8192), (4104, 2056 - 2056 % 16), (2048, 7680)):
         soak("i16 forward" + tn, [o16], lambda: M.fwd_i16(i16, o16, W, H, lut=table))
         soak("i16 inverse" + tn, [o16], lambda: M.inv_i16(i16, o16, W, H, lut=table))
     soak("plane batch, 1 plane + table", [o16], lambda: M.roundtrip_i16_planes([(i16, o16, W, H, K1)]))
+    if W == 8192:  # plane batches: three planes of different shapes (partial last tiles), own tables, kernel-argument and device-table forms
+        shapes = [(7680, 4320), (3840, 2160), (3840, 2160)]
+        bi = [synth.plane_i16_torch(w, h, "photo", seed=20 + k) for k, (w, h) in enumerate(shapes)]
+        bo = [torch.empty_like(t) for t in bi]
+        desc = [(a, b, w, h, l) for a, b, (w, h), l in zip(bi, bo, shapes, (K1, synth.JPEG_CHROMA, synth.JPEG_CHROMA))]
+        for mode in ("roundtrip", "fwd", "inv"):
+            soak(f"plane batch 4:2:0 frame, {mode}, kernel arguments", bo, lambda: M.i16_batch(mode, desc))
+        dev_batch = M.Batch("roundtrip", desc)
+        soak("plane batch 4:2:0 frame, roundtrip, device table", bo, lambda: dev_batch.run())
+        del bi, bo, desc, dev_batch
     soak("u8 px -> i16 coef", [o16], lambda: M.fwd_u8_i16(u8, o16, W, H, lut=K1))
     p8 = torch.empty((H, W), dtype=torch.uint8, device="cuda")
     soak("i16 coef -> u8 px", [p8], lambda: M.inv_i16_u8(i16, p8, W, H, lut=K1))

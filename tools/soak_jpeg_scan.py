@@ -10,8 +10,7 @@ from simd_dct_amd import synth
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30
 M.init(0)
 rng = np.random.default_rng(2026)
-K1 = np.array([16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
-               18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99], dtype=np.float32)
+K1 = synth.JPEG_LUMA
 work = torch.zeros((8192 + 2,), dtype=torch.int64, device="cuda")
 t0 = time.time()
 it = 0
