@@ -856,6 +856,11 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
     // 64 coefficient planes; block t of the launch lands at byte (by0*2*bpr + t) of every plane
     // (:1061-1099), so a full workgroup owns 256 consecutive bytes per plane.  Stage them in LDS
     // as [coef][block] and store 16 B per lane (4 wide stores instead of 64 byte stores per lane).
+    // (Two barrier-free forms were measured and lost: a wave-private reorder with 64-byte pieces, 37 vs 32 us,
+    // profiles/r03_exp_stereo_wave_private_reorder.log; one wave walking four tiles so that it owns the 256-byte pieces itself,
+    // 17 KiB of LDS per wave = 9 waves per CU, 49.3 vs 32.0 us (SSE) and 37.7 vs 34.0 (scalar), profiles/r04_exp_stereo_wave4.log.
+    // The tier runs 739 vector instructions per wave against q32's 663 -- the reference's x(1/255) and +127.0f are operations of
+    // their own -- and 30.3 us against 27.3: it sits at the same vector-issue bound as q32, the barrier is not what it waits for.)
     __shared__ __attribute__((aligned(16))) uint8_t slds[64 * kStereoRowStride];
     const uint32_t wg_t0 = TILED ? blockIdx.y * a.bpr + blockIdx.x * kWG : wg_index() * kWG;
     const bool full_wg = TILED || wg_t0 + kWG <= a.nblocks; // workgroup-uniform

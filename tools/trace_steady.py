@@ -25,11 +25,11 @@ for r in rows:
         runs.append([k, [r]])
 last_run = {}
 for k, rs in runs:  # the longest back-to-back run of each kernel = its pre-conditioning + warm-up + timed region
-    if "mdct::" in k and len(rs) >= 50 and len(rs) > len(last_run.get(k, [])):
+    if "mdct::" in k and len(rs) >= 8 and len(rs) > len(last_run.get(k, [])):
         last_run[k] = rs
 print(f"{'kernel':88s} {'n':>5s} {'mean ns':>9s} {'median':>8s} {'min':>8s} {'gap':>6s}")
 for k, rs in sorted(last_run.items()):
-    n = 2000 if len(rs) >= 2200 else (500 if len(rs) >= 1500 else max(40, len(rs) * 2 // 5))
+    n = 2000 if len(rs) >= 2200 else (500 if len(rs) >= 1500 else (max(40, len(rs) * 2 // 5) if len(rs) >= 100 else max(3, len(rs) * 2 // 3)))
     sel = rs[-n:]
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel]
     gaps = [int(sel[i + 1]["Start_Timestamp"]) - int(sel[i]["End_Timestamp"]) for i in range(len(sel) - 1)]
