@@ -379,8 +379,24 @@ def main():
             r["device_table_form"] = rate(lambda i: pr3[i % NSETS](), 4 * fpx, n=500, warm=500)
             fw3 = [M.prepare_i16_batch("fwd", f) for f in frames]
             r["forward_only_batch"] = rate(lambda i: fw3[i % NSETS](), 4 * fpx, n=500, warm=500)
+            # the per-launch fill and drain (~6 us of the 36) is shared when a call carries several frames: the same entry point with
+            # all four frames' twelve planes in ONE call, and single-frame calls alternating over two streams (extras, never the headline)
+            four = M.prepare_roundtrip_i16_planes([pl for f in frames for pl in f])
+            r["four_frames_per_call_ms_per_frame"] = round(rate(lambda i: four(), 16 * fpx, n=200, warm=300)["ms"] / 4, 4)
+            s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+            two = [M.prepare_i16_batch("roundtrip", frames[i], stream=s2[i % 2].cuda_stream) for i in range(NSETS)]
+            for st in s2:
+                st.wait_stream(torch.cuda.current_stream())
+            for i in range(400):
+                two[i % NSETS]()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(1000):
+                two[i % NSETS]()
+            torch.cuda.synchronize()
+            r["two_streams_ms_per_frame"] = round((time.perf_counter() - t0), 4)  # 1000 frames: seconds == ms per frame
             extras["config3_420_roundtrip_one_call"] = r
-            del frames, calls3, dev3, pr3, fw3
+            del frames, calls3, dev3, pr3, fw3, four, two
         except Exception as e:
             extras["config3_420_roundtrip_one_call"] = {"error": str(e)[:200]}
         # configs[4]: float32 DCT-II on the 8192x8192 plane (8 algorithmic bytes per pixel)
@@ -571,6 +587,8 @@ def main():
                 line["roofline_config3_420"]["Mpx_s"] = c3.get("Mpx_s")
                 line["roofline_config3_420"]["device_table_form_ms"] = c3.get("device_table_form", {}).get("ms")
                 line["roofline_config3_420"]["forward_only_batch_ms"] = c3.get("forward_only_batch", {}).get("ms")
+                line["roofline_config3_420"]["four_frames_per_call_ms_per_frame"] = c3.get("four_frames_per_call_ms_per_frame")
+                line["roofline_config3_420"]["two_streams_ms_per_frame"] = c3.get("two_streams_ms_per_frame")
             c5 = extras.get("config5_f32_fwd", {})
             if "GBps" in c5:
                 line["roofline_f32"] = own_block(c5, "mdct::k_f32_tile<MODE_FWD>", 8 * W * H, "BASELINE.json configs[4]: float32 DCT-II, 8192x8192 plane (mdct_fwd_f32)", "k_f32_tile_fwd_bytes_per_launch")
