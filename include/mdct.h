@@ -111,7 +111,12 @@ int mdct_fwd_quant_u8_pitched(const uint8_t *from, uint8_t *to, size_t pitch_in,
  *   inv:       x    = sat_i16(rne(idct(coef * lut[i])))
  *   roundtrip: fwd -> (quantise -> dequantise when lut) -> inv, fused, one pass over HBM;
  *              without a table it returns the input bit-exactly.
- * Rows must be 16-byte aligned (pitch*sizeof(elem) % 16 == 0, base 16-byte aligned).    */
+ * Rows must be 16-byte aligned (pitch*sizeof(elem) % 16 == 0, base 16-byte aligned).
+ * Tables: the FIRST call that sees a table (per device, per distinct content) parks its multipliers in device memory
+ * with one blocking 512-byte copy -- the kernel argument segment is cold in every cache on every launch, device memory
+ * is not; later calls with that table find it there (up to 256 tables per device, never evicted).  A table first seen
+ * while `stream` is capturing, or beyond the 256, travels in the kernel arguments instead: same results, and nothing is
+ * allocated, copied or synchronised inside a capture. */
 int mdct_fwd_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
                  size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
 int mdct_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,

@@ -879,6 +879,9 @@ int mdct_batch_run(const mdct_batch *b, void *stream)
 {
   if (b == nullptr)
     return fail(MDCT_INVALID_PARAMETER, "null batch");
+  int dev = -1;
+  if (!b->launches.empty() && (hipGetDevice(&dev) != hipSuccess || dev != b->device))
+    return fail(MDCT_INVALID_PARAMETER, "the batch was created on device %d, the calling thread's current device is %d", b->device, dev);
   for (const BatchLaunch &l : b->launches)
   {
     const hipError_t e = mdct::launch_i16_batch(l.args, l.total, b->mode, l.lutmode, l.sat, (hipStream_t)stream);

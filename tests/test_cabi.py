@@ -196,3 +196,43 @@ def test_pitched_output_argument_checks(lib):
     # sizeX == 0 passes the reference's shape test and does nothing (simd_dct.cpp:118, :2103)
     assert api.simdDCT_EncodeQuantize32ReorderBuffer(a, a, lut, 0, 16, 0, 16) == api.sdr_Success
     assert api.simdDCT_EncodeQuantizeBuffer(a, a, lut, 0, 16, 0, 16) == api.sdr_Success
+
+
+def test_plain_c_caller_of_the_batch_api_compiles_links_and_gets_status_codes(tmp_path, lib):
+    """include/mdct.h is a C header: a gcc -std=c99 program lists planes in mdct_plane_i16, calls the batch entry points and the
+    device-table form, and -- without a device in this container -- gets the reference's status codes back: argument errors (1, 2)
+    before any device is touched, MDCT_NOT_SUPPORTED (2) with a message where a device would be needed"""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "batch_c.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "mdct.h"
+int main(void) {
+  static int16_t a[64 * 16], b[64 * 16];
+  float lut[64];
+  for (int i = 0; i < 64; i++) lut[i] = 16.0f;
+  mdct_plane_i16 pl[2] = {{a, b, 64, 64, 64, 16, lut}, {a, b, 64, 64, 64, 16, NULL}};
+  mdct_batch *h = (mdct_batch *)1;
+  pl[1].sizeX = 60;
+  printf("%d", mdct_roundtrip_i16_batch(pl, 2, NULL));      /* 2: not a multiple of 8x8, nothing launched */
+  pl[1].sizeX = 64; pl[1].to = NULL;
+  printf(" %d", mdct_fwd_i16_batch(pl, 2, NULL));           /* 1: null plane pointer */
+  pl[1].to = b;
+  printf(" %d", mdct_batch_create(&h, 9, pl, 2));           /* 1: unknown mode; the handle is cleared */
+  printf(" %d", h == NULL);
+  printf(" %d", mdct_batch_create(&h, MDCT_MODE_INV, pl, 2) != MDCT_INVALID_PARAMETER); /* valid arguments: success on a GPU box, 2 here */
+  printf(" %d %d\n", mdct_batch_launches(NULL), mdct_batch_destroy(h == (mdct_batch *)1 ? NULL : h));
+  return 0;
+}
+''')
+    exe = tmp_path / "batch_c"
+    r = subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-L" + os.path.dirname(_lib.LIB_PATH), "-lmdct_hip",
+                        "-Wl,-rpath," + os.path.dirname(_lib.LIB_PATH), "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["2", "1", "1", "1", "1", "0", "0"], r.stdout
