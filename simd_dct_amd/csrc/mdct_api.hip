@@ -212,7 +212,17 @@ struct TableCache
   mdct::OwnTables *dev = nullptr;
   bool failed = false;
   std::vector<mdct::OwnTables> host; // what each filled slot holds
+  std::vector<uint64_t> hash;        // ... and a hash of it: the lookup compares 8 bytes per slot, then one table
 };
+
+uint64_t table_hash(const mdct::OwnTables &tb)
+{ // FNV-1a over the 128 multipliers' bit patterns
+  uint64_t h = 1469598103934665603ull;
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(&tb);
+  for (size_t i = 0; i < sizeof(tb) / 4; i++)
+    h = (h ^ w[i]) * 1099511628211ull;
+  return h;
+}
 TableCache g_tables[kMaxDevices];
 
 bool stream_is_capturing(hipStream_t s)
@@ -232,8 +242,9 @@ const mdct::OwnTables *parked_tables(int device, const mdct::OwnTables &tb, hipS
 {
   TableCache &c = g_tables[device];
   std::lock_guard<std::mutex> lk(c.mu);
+  const uint64_t h = table_hash(tb);
   for (size_t k = 0; k < c.host.size(); k++)
-    if (memcmp(&c.host[k], &tb, sizeof(tb)) == 0)
+    if (c.hash[k] == h && memcmp(&c.host[k], &tb, sizeof(tb)) == 0)
       return c.dev + k;
   if (c.failed || c.host.size() >= (size_t)kTableSlots || stream_is_capturing(stream))
     return nullptr;
@@ -253,6 +264,7 @@ const mdct::OwnTables *parked_tables(int device, const mdct::OwnTables &tb, hipS
     return nullptr;
   }
   c.host.push_back(tb);
+  c.hash.push_back(h);
   return c.dev + (c.host.size() - 1);
 }
 

@@ -944,6 +944,32 @@ def test_soak_random_differential():
             out = torch.empty((H2, W2), dtype=torch.int16, device="cuda")
             fn(dev(src), out, W2, H2, lut=table)
             assert np.array_equal(out.cpu().numpy(), O.i16(mode, src, W2, H2, lut=table)), (it, mode, W2, H2)
+        # plane batches: 1..11 separately allocated planes of random shapes (partial tiles), pitches and tables, all three modes,
+        # kernel-argument form and (every 4th case) the device-table form
+        nbp = int(rng.integers(1, 12))
+        bshapes = [(int(rng.integers(1, 100)) * 8, int(rng.integers(1, 8)) * 8) for _ in range(nbp)]
+        if it % 5 == 0:
+            bshapes = [bshapes[0]] * nbp  # equal shapes: the division-free plane index
+        bpad = [8 * int(rng.integers(0, 3)) for _ in range(nbp)]
+        btabs = [None if rng.random() < 0.3 else (table if (table is not None and rng.random() < 0.5) else (lut_x(float(rng.choice([0.5, 9, 150]))) * rng.uniform(0.3, 3, 64).astype(np.float32)).astype(np.float32))
+                 for _ in range(nbp)]
+        bsrc = []
+        for (bw, bh), pd in zip(bshapes, bpad):
+            full = rng.integers(-2048, 2048, (bh, bw + pd), dtype=np.int16)
+            bsrc.append(full)
+        bmode = ("fwd", "inv", "roundtrip")[it % 3]
+        b_in = [dev(a) for a in bsrc]
+        b_out = [torch.full((bh, bw + pd), 771, dtype=torch.int16, device="cuda") for (bw, bh), pd in zip(bshapes, bpad)]
+        bdesc = [(a, o, bw, bh, l, bw + pd, bw + pd) for a, o, (bw, bh), pd, l in zip(b_in, b_out, bshapes, bpad, btabs)]
+        if it % 4 == 0:
+            bb = M.Batch(bmode, bdesc)
+            bb.run()
+            bb.close()
+        else:
+            M.i16_batch(bmode, bdesc)
+        for a, o, (bw, bh), pd, l in zip(bsrc, b_out, bshapes, bpad, btabs):
+            g = o.cpu().numpy()
+            assert np.array_equal(g[:, :bw], O.i16(bmode, np.ascontiguousarray(a[:, :bw]), bw, bh, lut=l)) and (g[:, bw:] == 771).all(), (it, bmode, bw, bh, pd, "batch")
         px = rng.integers(0, 256, (H2, W2), dtype=np.uint8)
         c = torch.empty((H2, W2), dtype=torch.int16, device="cuda")
         M.fwd_u8_i16(dev(px), c, W2, H2, lut=table, level_shift=bool(it & 1))
