@@ -269,3 +269,32 @@ def test_more_than_65535_block_rows_take_the_linear_kernels():
     torch.cuda.synchronize()
     assert all_periods_equal_first(g, n_per)
     assert np.array_equal(g[:P].cpu().numpy(), O.f32("fwd", s16.astype(np.float32), W, P))
+
+
+def test_plane_batch_beyond_4GiB_and_more_than_65535_block_rows():
+    """the plane-batch kernel (a 1-D grid of tiles: no 65535-row limit of its own) on planes whose byte offsets pass 2^32: one 8192 x 335872
+    int16 plane (5.5 GB, 41984 block rows) and, in the same call, a 2056-wide one with a partial last tile and 70000 block rows -- every
+    period equals the first, the first equals the oracle; both forms of the call; forward and the fused round trip with a table"""
+    lut = lut_x(40)
+    shapes = [(8192, P * 2624), (2056, 560000)]
+    assert shapes[0][0] * shapes[0][1] * 2 > 2**32 + 2**30 and shapes[1][1] // 8 > 65535 and shapes[1][1] % P == 0
+    strips = [synth.plane_i16_np(w, P, "photo", seed=31 + k, bits=12) for k, (w, h) in enumerate(shapes)]
+    srcs = [torch.from_numpy(s).cuda().repeat(h // P, 1).contiguous() for s, (w, h) in zip(strips, shapes)]
+    outs = [torch.empty_like(t) for t in srcs]
+    for mode, table in (("fwd", None), ("roundtrip", lut)):
+        wants = [O.i16(mode, s, w, P, lut=table) for s, (w, h) in zip(strips, shapes)]
+        for form in ("args", "device"):
+            for o in outs:
+                o.fill_(-21846)
+            desc = [(a, o, w, h, table) for a, o, (w, h) in zip(srcs, outs, shapes)]
+            if form == "args":
+                M.i16_batch(mode, desc)
+            else:
+                b = M.Batch(mode, desc)
+                assert b.launches == 1
+                b.run()
+            torch.cuda.synchronize()
+            for o, want, (w, h) in zip(outs, wants, shapes):
+                assert all_periods_equal_first(o, h // P), (mode, form, w)
+                assert np.array_equal(o[:P].cpu().numpy(), want), (mode, form, w)
+    del srcs, outs
