@@ -545,6 +545,9 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
         }
         else
         {
+          // (v_cvt_pk_u8_f32 -- round to nearest even, saturate to [0, 255], NaN -> 0: probed on gfx950, tools/probe_cvt_pk_u8.hip -- would do
+          // clamp + round in one instruction per value: 739 -> 706 vector instructions per wave for stereo/SSE, and no faster: 32.1-32.2 us
+          // against 31.8 in the bench, encq/SSE 23.9-24.1 against 24.1.  The convert is not a full-rate instruction; the magic add stays.)
           f32x2 t;
           v.x = __builtin_amdgcn_fmed3f(v.x, 0.0f, 255.0f);
           v.y = __builtin_amdgcn_fmed3f(v.y, 0.0f, 255.0f);
