@@ -323,3 +323,49 @@ def test_table_cache_first_sight_under_capture_and_beyond_its_capacity(cuda):
             api.i16_batch(mode, [(d, out, W, H, q)])
         if k % 25 == 0 or k > 290:
             assert np.array_equal(out.cpu().numpy(), O.i16(mode, src, W, H, lut=q)), (k, mode)
+
+
+@gpu
+def test_two_host_threads_park_new_tables_and_run_batches_concurrently(cuda):
+    """the table cache is shared by all host threads of a device: two threads, each on its own stream, keep introducing tables nobody has
+    seen (first-sight copies under the cache's lock) while launching single-plane calls and plane batches with them; every result is
+    the oracle's"""
+    import threading
+
+    import oracle as O
+
+    torch = cuda
+    W, H = 1024, 64
+    src = synth.plane_i16_np(W, H, "photo", seed=123, bits=12)
+    errors = []
+
+    def worker(tid):
+        try:
+            torch.cuda.set_device(0)
+            api.init(0)
+            rng = np.random.default_rng(1000 + tid)
+            s = torch.cuda.Stream()
+            d = torch.from_numpy(src).cuda()
+            for k in range(40):
+                q = rng.uniform(9.0, 120.0, 64).astype(np.float32)
+                mode = ("fwd", "roundtrip", "inv")[k % 3]
+                out = torch.full((H, W), CANARY, dtype=torch.int16, device="cuda")
+                out2 = torch.full((H, W), CANARY, dtype=torch.int16, device="cuda")
+                with torch.cuda.stream(s):
+                    {"fwd": api.fwd_i16, "inv": api.inv_i16, "roundtrip": api.roundtrip_i16}[mode](d, out, W, H, lut=q, stream=s)
+                    api.i16_batch(mode, [(d, out2, W, H, q), (d, out, W // 2, H, None)] if k % 5 == 0 else [(d, out2, W, H, q)], stream=s)
+                s.synchronize()
+                want = O.i16(mode, src, W, H, lut=q)
+                if not np.array_equal(out2.cpu().numpy(), want):
+                    errors.append((tid, k, mode, "batch"))
+                if k % 5 and not np.array_equal(out.cpu().numpy(), want):
+                    errors.append((tid, k, mode, "plane"))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
