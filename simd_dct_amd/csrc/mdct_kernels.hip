@@ -9,6 +9,8 @@
 // Bit-exactness contract (u8 path): IEEE binary32, one rounding per written operation,
 // the exact association of the reference tier being reproduced, NO FMA.  This file is
 // compiled with -ffp-contract=off and additionally pins contraction off below.
+// (One fused multiply-add is written out by hand, in the scalar tiers' quantiser: it replaces  (uint8_t)roundf(c * 255.f)  by a form
+//  proven equal for every float c in [0, 1] -- tools/check_roundf_forms.py -- not an operation of the reference's transform.)
 //
 // Reference lines restated (rainerzufalldererste/simd_dct, src/simd_dct.cpp):
 //   1-D kernels   K_AVX :2158-2184   K_SSE :434-654   K_TRUE :138-172
