@@ -773,8 +773,10 @@ __global__ __launch_bounds__(64, MDCT_Q32_MINW) void k_q32_tile(U8Args a)
 #ifdef MDCT_U8_WAVES
 #define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8_WAVES, MDCT_U8_WAVES)))
 #else
-constexpr int u8_waves_lo(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 4 : ((layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR) ? 4 : 1); }
-constexpr int u8_waves_hi(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 4 : ((layout == MDCT_LAYOUT_STEREO && profile == MDCT_PROFILE_REF_SCALAR) ? 4 : 8); }
+// (round 4, tiled kernels, profiles/r04_exp_scalar_waves.log: stereo/SSE 31.9-32.0 us steered to 3 against 33.9 unsteered, 33.4 at 5, 47.6 at 6;
+// stereo/scalar 35.5 at 4 or 5, 37-38 at 3, 46 at 6; encq/scalar 31.4-31.8 unsteered, 32.3-33.6 steered)
+constexpr int u8_waves_lo(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 4 : (layout == MDCT_LAYOUT_STEREO ? (profile == MDCT_PROFILE_REF_SCALAR ? 4 : 3) : 1); }
+constexpr int u8_waves_hi(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 4 : (layout == MDCT_LAYOUT_STEREO ? (profile == MDCT_PROFILE_REF_SCALAR ? 4 : 3) : 8); }
 #define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(u8_waves_lo(PROFILE, LAYOUT), u8_waves_hi(PROFILE, LAYOUT))))
 #endif
 // TILED: 2-D grid for launches whose workgroups each lie in one row of blocks (sizeX % 2048 == 0): blockIdx.y = row of
