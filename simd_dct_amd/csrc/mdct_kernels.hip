@@ -947,6 +947,9 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
 #pragma unroll
       for (int i8 = 0; i8 < 8; i8++)
         L[i8] = pack4_lo8(q[i8 * 8 + 0], q[i8 * 8 + 1], q[i8 * 8 + 4], q[i8 * 8 + 5]);
+      // (Splitting the pair's 64 bytes the other way -- rows {0,1,4,5} / {2,3,6,7} per lane, so that every store instruction writes 32 contiguous bytes
+      // per pair instead of 16 + 16 -- is much slower: 35.1 vs 24.1 us, same bytes.  A lane's two stores to ADJACENT addresses are what the write path
+      // combines; keep them adjacent.)
       uint32_t w[8]; // this lane's 32 bytes: rows 0..3 (even block's lane) or 4..7 (odd block's lane), both blocks' dwords interleaved
 #pragma unroll
       for (int j = 0; j < 4; j++)
