@@ -949,7 +949,8 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
         L[i8] = pack4_lo8(q[i8 * 8 + 0], q[i8 * 8 + 1], q[i8 * 8 + 4], q[i8 * 8 + 5]);
       // (Splitting the pair's 64 bytes the other way -- rows {0,1,4,5} / {2,3,6,7} per lane, so that every store instruction writes 32 contiguous bytes
       // per pair instead of 16 + 16 -- is much slower: 35.1 vs 24.1 us, same bytes.  A lane's two stores to ADJACENT addresses are what the write path
-      // combines; keep them adjacent.)
+      // combines; keep them adjacent.  Staging the wave's 32 x 64 bytes through LDS so that a store instruction covers whole 64-byte halves: 24.8-25.1 us,
+      // no better either -- unlike the scalar tier's BLOCK layout this one is not held back by its stores.)
       uint32_t w[8]; // this lane's 32 bytes: rows 0..3 (even block's lane) or 4..7 (odd block's lane), both blocks' dwords interleaved
 #pragma unroll
       for (int j = 0; j < 4; j++)
