@@ -44,6 +44,8 @@ def _run_world(exe, fake, world, planes, elems, chunk, tmp_path, tag):
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    if any("FATAL: ThreadSanitizer" in e and "memory mapping" in e for _, _, e in outs):
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this environment (address-space layout), not a finding")
     for r, (rc, o, e) in enumerate(outs):
         assert rc == 0 and "node pipeline ok" in o, f"rank {r} of {world} exited {rc}\n{o}\n{e[-3000:]}"
         assert "WARNING: ThreadSanitizer" not in e, e[-3000:]
