@@ -1380,9 +1380,12 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(i16_waves(M
 // (44.1 with 3, 45.1 with 4; k_i16<FWD> 43.7; the copy kernel 43.4), inverse 43.2 with 2 (45.1 with 4; k_i16<INV> 45.4),
 // fused round trip with phase priorities 44.3 with 2, 44.7 with 3, 45.9 with 4 (without priorities 48.4 / 45.8 / 46.0;
 // k_i16<ROUNDTRIP> 47.1-48.6)
-constexpr int i16_tile_waves(int, bool) { return 2; }
-template <int MODE, bool HAS_LUT, bool SAT = true>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(i16_tile_waves(MODE, HAS_LUT), i16_tile_waves(MODE, HAS_LUT)))) void k_i16_tile(I16Args a)
+// WAVES: 2 is the steady-state optimum above; a launch that fills the chip only once or twice over is bound by the latency of a
+// generation of waves, not by the steady state, and finishes sooner with more of it resident: 4096^2 (4096 tiles) 13.8-14.0 us at 2
+// waves per SIMD, 12.3-12.8 at 4 (8192^2: 43.6 against 45.1; profiles/r04_exp_small_planes_waves.log).  The launcher picks by tile count.
+constexpr uint32_t kTileSmallLaunch = 6144; // tiles: up to here 4 waves per SIMD, beyond 2 (7680 x 4320 = 8100 tiles is indifferent)
+template <int MODE, bool HAS_LUT, bool SAT = true, int WAVES = 2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_i16_tile(I16Args a)
 {
   const size_t by = a.by0 + blockIdx.y;
   const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
@@ -2135,12 +2138,26 @@ static hipError_t launch_i16_m(const I16Args &a, bool has_lut, bool lut_bounded,
   if (MDCT_I16_TILED && a.bpr % 64 == 0 && launch_rows <= 65535u)
   {
     const dim3 g(a.bpr / 64, launch_rows);
+    const uint64_t tiles = (uint64_t)g.x * g.y;
+    const bool small = tiles > 2048 && tiles <= kTileSmallLaunch; // (up to 2048 tiles the chip holds the whole launch at 2 waves per SIMD already)
     if (has_lut && RT && lut_bounded)
-      hipLaunchKernelGGL((k_i16_tile<MODE, true, !RT>), g, dim3(64), 0, s, a);
+    {
+      if (small)
+        hipLaunchKernelGGL((k_i16_tile<MODE, true, !RT, 4>), g, dim3(64), 0, s, a);
+      else
+        hipLaunchKernelGGL((k_i16_tile<MODE, true, !RT, 2>), g, dim3(64), 0, s, a);
+    }
     else if (has_lut)
-      hipLaunchKernelGGL((k_i16_tile<MODE, true>), g, dim3(64), 0, s, a);
+    {
+      if (small)
+        hipLaunchKernelGGL((k_i16_tile<MODE, true, true, 4>), g, dim3(64), 0, s, a);
+      else
+        hipLaunchKernelGGL((k_i16_tile<MODE, true, true, 2>), g, dim3(64), 0, s, a);
+    }
+    else if (small)
+      hipLaunchKernelGGL((k_i16_tile<MODE, false, true, 4>), g, dim3(64), 0, s, a);
     else
-      hipLaunchKernelGGL((k_i16_tile<MODE, false>), g, dim3(64), 0, s, a);
+      hipLaunchKernelGGL((k_i16_tile<MODE, false, true, 2>), g, dim3(64), 0, s, a);
     return hipGetLastError();
   }
   if (has_lut && RT && lut_bounded)
