@@ -1419,8 +1419,9 @@ static_assert(offsetof(BatchDesc, from) == 0 && offsetof(BatchDesc, to) == 8 && 
 // the fused round trip with phase priorities at 3 waves per SIMD (frame 38.0 us against 40.3 at 2, 8192^2 45.3 against 46.0-46.5),
 // forward and inverse at 2 (8192^2 forward 44.2-44.4 against 44.8-45.0 at 3 and 46.2 at 4).
 constexpr int batch_waves(int mode) { return mode == MODE_ROUNDTRIP ? 3 : 2; }
-template <int MODE, int LUTMODE, bool SAT = true>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(batch_waves(MODE), batch_waves(MODE)))) void k_i16_batch(BatchArgs a)
+// (and, like k_i16_tile, 4 waves per SIMD for launches of 2049..6144 tiles: SMALL)
+template <int MODE, int LUTMODE, bool SAT = true, bool SMALL = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? 4 : batch_waves(MODE), SMALL ? 4 : batch_waves(MODE)))) void k_i16_batch(BatchArgs a)
 {
   // Two dependent rounds of scalar loads stand between a wave's start and its first row load: the header (20 dwords, fetched as ONE
   // batch -- left to the compiler each field was a load with a wait of its own, ten round trips), then the plane's descriptor.
@@ -2182,26 +2183,32 @@ hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s, b
   return hipErrorInvalidValue;
 }
 
+template <bool SMALL>
+static hipError_t launch_i16_batch_w(const BatchArgs &a, uint32_t total, int mode, int lutmode, bool sat, hipStream_t s)
+{
+  const dim3 g(total), b(64);
+  if (mode == MODE_FWD)
+    hipLaunchKernelGGL((k_i16_batch<MODE_FWD, BATCH_ALL_LUT, true, SMALL>), g, b, 0, s, a);
+  else if (mode == MODE_INV)
+    hipLaunchKernelGGL((k_i16_batch<MODE_INV, BATCH_ALL_LUT, true, SMALL>), g, b, 0, s, a);
+  else if (mode != MODE_ROUNDTRIP)
+    return hipErrorInvalidValue;
+  else if (lutmode == BATCH_NO_LUT)
+    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_NO_LUT, true, SMALL>), g, b, 0, s, a);
+  else if (lutmode == BATCH_ALL_LUT && !sat)
+    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_ALL_LUT, false, SMALL>), g, b, 0, s, a);
+  else if (lutmode == BATCH_ALL_LUT)
+    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_ALL_LUT, true, SMALL>), g, b, 0, s, a);
+  else
+    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_MIXED, true, SMALL>), g, b, 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_i16_batch(const BatchArgs &a, uint32_t total, int mode, int lutmode, bool sat, hipStream_t s)
 {
   if (total == 0)
     return hipSuccess;
-  const dim3 g(total), b(64);
-  if (mode == MODE_FWD)
-    hipLaunchKernelGGL((k_i16_batch<MODE_FWD, BATCH_ALL_LUT>), g, b, 0, s, a);
-  else if (mode == MODE_INV)
-    hipLaunchKernelGGL((k_i16_batch<MODE_INV, BATCH_ALL_LUT>), g, b, 0, s, a);
-  else if (mode != MODE_ROUNDTRIP)
-    return hipErrorInvalidValue;
-  else if (lutmode == BATCH_NO_LUT)
-    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_NO_LUT>), g, b, 0, s, a);
-  else if (lutmode == BATCH_ALL_LUT && !sat)
-    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_ALL_LUT, false>), g, b, 0, s, a);
-  else if (lutmode == BATCH_ALL_LUT)
-    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_ALL_LUT>), g, b, 0, s, a);
-  else
-    hipLaunchKernelGGL((k_i16_batch<MODE_ROUNDTRIP, BATCH_MIXED>), g, b, 0, s, a);
-  return hipGetLastError();
+  return total > 2048 && total <= kTileSmallLaunch ? launch_i16_batch_w<true>(a, total, mode, lutmode, sat, s) : launch_i16_batch_w<false>(a, total, mode, lutmode, sat, s);
 }
 
 hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s)
