@@ -7,7 +7,10 @@ CSRC    := simd_dct_amd/csrc
 LIB     := simd_dct_amd/libmdct_hip.so
 # -ffp-contract=off: bit-exactness contract (no FMA).  -fno-slp-vectorize: the SLP vectoriser packs adjacent scalar ops
 # with v_mov shuffles; where packing pays (the q32 butterflies) it is written by hand.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -fPIC -Wall -Iinclude -I$(CSRC)
+# -mllvm -disable-vector-combine: LLVM's VectorCombine rewrites a scalar float op on elements of a register pair as a PACKED op with one
+# useless half plus a v_mov (twice the issue cycles of the scalar op): the AAN row passes keep 6 / 12 unpaired scalar operations per line
+# on purpose (fused int16 round trip 1024 -> 952 vector instructions per wave, 752 -> 632 of them packed).
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-vector-combine -std=c++17 -fPIC -Wall -Iinclude -I$(CSRC)
 
 all: lib cli oracle
 

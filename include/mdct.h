@@ -137,9 +137,10 @@ int mdct_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out
 int mdct_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
                  size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
 
-/* Multi-plane call (BASELINE.json configs[2]: Y + Cb + Cr with per-plane tables): the fused round trip of every plane
- * in ONE launch (== mdct_roundtrip_i16_batch below: any number of planes, descriptors and tables by value in the
- * kernel arguments -- no allocation, no sync, capture-safe).  `planes` is a HOST array. */
+/* Multi-plane call on int16 planes (Y + Cb + Cr with per-plane tables): == mdct_roundtrip_i16_batch below -- descriptors and
+ * tables by value in the kernel arguments (no allocation, no sync, capture-safe).  ONE launch while the list fits the
+ * 3584-byte argument blob (64 bytes per plane + 512 per distinct table: 3 planes with 3 tables, 48 planes sharing one);
+ * longer lists take several launches -- mdct_batch_create / mdct_batch_run is one launch for any list.  `planes` is a HOST array. */
 typedef struct mdct_plane_i16
 {
   const int16_t *from;
@@ -164,7 +165,8 @@ int mdct_inv_i16_batch(const mdct_plane_i16 *planes, int n_planes, void *stream)
 int mdct_roundtrip_i16_batch(const mdct_plane_i16 *planes, int n_planes, void *stream);
 /* The same with the descriptors and tables in device memory: mdct_batch_create allocates and uploads them once
  * (synchronous; not capture-safe), mdct_batch_run is then ONE launch for the whole list whatever its length (more
- * only beyond 2^31 tiles), asynchronous on `stream`, capture-safe, repeatable.  The batch refers to the planes'
+ * only beyond 2^26 - 1 tiles = 4.29e9 blocks: a tile is a 64-thread workgroup and one launch holds < 2^32 threads),
+ * asynchronous on `stream`, capture-safe, repeatable.  The batch refers to the planes'
  * memory, not to the `planes` array or the tables, which may be freed after creation. */
 enum
 {
@@ -177,6 +179,34 @@ int mdct_batch_create(mdct_batch **batch, int mode, const mdct_plane_i16 *planes
 int mdct_batch_run(const mdct_batch *batch, void *stream);
 int mdct_batch_launches(const mdct_batch *batch); /* kernel launches one run takes (host function) */
 int mdct_batch_destroy(mdct_batch *batch);
+
+/* ---- 8-bit pixels in, 8-bit pixels out: the fused round trip (BASELINE.json configs[2], "3-plane 4:2:0 with per-plane JPEG
+ * quant tables, fwd+inv"; SURVEY.md 8(d): u8 planes, 2 bytes per pixel).  The reference's pixel type is uint8 everywhere
+ * (simd_dct.cpp:2107-2143) and it stops after the quantiser; this is forward -> quantise -> dequantise -> inverse in one
+ * pass over HBM, bit for bit
+ *     mdct_fwd_u8_i16(from -> coef, lut, level_shift)  followed by  mdct_inv_i16_u8(coef -> to, lut, level_shift)
+ * without the int16 plane in between:
+ *     c = sat_i16(rne(dct(px - shift) / lut[i])),  px' = clamp(rne(idct(c * lut[i])) + shift, 0, 255),  shift = level_shift ? 128 : 0.
+ * lut == NULL: no quantisation table (the coefficients are still rounded to int16, as the two calls would).
+ * Pitches in BYTES; no alignment requirement on the planes (like the reference, simd_dct.cpp:2109); sizeX, sizeY multiples of 8.
+ * One 64-block tile of one block row per wave, the last tile of a row may be partial (any sizeX % 8 == 0).
+ * mdct_roundtrip_u8: block rows [by0, by1) of one plane.  _batch: any number of separately allocated planes, each with its own
+ * table, in one launch -- descriptors and tables by value in the kernel arguments exactly like mdct_roundtrip_i16_batch
+ * (no allocation, no synchronisation, capture-safe; Y + Cb + Cr with three tables fit one launch), or device-resident through
+ * mdct_batch_create_u8 / mdct_batch_run / mdct_batch_destroy.  Tables are parked in device memory like those of the int16 calls. */
+typedef struct mdct_plane_u8
+{
+  const uint8_t *from;
+  uint8_t *to;
+  size_t pitch_in, pitch_out; /* bytes */
+  size_t sizeX, sizeY;
+  const float *lut;           /* HOST pointer to 64 floats (finite, non-zero), or NULL */
+} mdct_plane_u8;
+int mdct_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift,
+                      size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
+int mdct_roundtrip_u8_batch(const mdct_plane_u8 *planes, int n_planes, int level_shift, void *stream);
+/* device-resident form: run with mdct_batch_run, free with mdct_batch_destroy (above) */
+int mdct_batch_create_u8(mdct_batch **batch, const mdct_plane_u8 *planes, int n_planes, int level_shift);
 
 /* ---- the stages either side of the transform (no reference counterpart: its pipeline starts from a
  * ready-made plane, main.cpp:475-493, and ends at the reorder store, simd_dct.cpp:2221-2230) ----------

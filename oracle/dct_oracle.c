@@ -631,6 +631,36 @@ int orc_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pi, size_t po, const
   return 0;
 }
 
+/* Fused 8-bit round trip (BASELINE.json configs[2] as SURVEY.md 8(d) states it: u8 planes in, u8 planes out): per block exactly
+ * orc_fwd_u8_i16 followed by orc_inv_i16_u8 with the same table and level shift -- the int16 coefficients exist only in between
+ * (tests/test_oracle.py checks this function against that composition).  pitches in bytes. */
+int orc_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pi, size_t po, const float *lut, int level_shift, size_t W, size_t H, size_t by0, size_t by1)
+{
+  const int e = own_args(from, to, pi, po, W, H, by0, by1);
+  if (e)
+    return e;
+  float qf[64], dq[64];
+  own_tables(lut, qf, dq);
+  FOR_BLOCKS
+  {
+    float blk[64];
+    for (int r = 0; r < 8; r++)
+      for (int c = 0; c < 8; c++)
+        blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c] - (level_shift ? 128.0f : 0.0f);
+    raw_fwd(blk);
+    for (int i = 0; i < 64; i++)
+      blk[i] = (float)sat_i16_rne(blk[i] * qf[i]) * dq[i];
+    raw_inv(blk);
+    for (int i = 0; i < 64; i++)
+    {
+      float r = rintf(blk[i]);
+      r = r + (level_shift ? 128.0f : 0.0f);
+      AT(i >> 3, i & 7) = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+    }
+  }
+  return 0;
+}
+
 int orc_fwd_f32(const float *from, float *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);

@@ -16,7 +16,7 @@
  *               orc_encq_scalar        B5  simd_dct.cpp:300-395
  *   UNPINNED ("parity unpinned": the reference has no int16 / float32-out / inverse
  *             path at all; these restate the engine's OWN arithmetic definition):
- *               orc_fwd_i16, orc_inv_i16, orc_roundtrip_i16, orc_fwd_u8_i16, orc_inv_i16_u8,
+ *               orc_fwd_i16, orc_inv_i16, orc_roundtrip_i16, orc_fwd_u8_i16, orc_inv_i16_u8, orc_roundtrip_u8,
  *               orc_fwd_f32, orc_inv_f32, orc_fwd_f64ref
  *             (and, restating published definitions of ITU-T T.81 rather than engine arithmetic:
  *               orc_zigzag_table, orc_zigzag_rle_i16, orc_zigzag_rle_q32, orc_split420_u8)
@@ -74,6 +74,9 @@ int orc_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pit
                    size_t sizeX, size_t sizeY, size_t by0, size_t by1);
 int orc_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift,
                    size_t sizeX, size_t sizeY, size_t by0, size_t by1);
+/* fused: orc_fwd_u8_i16 then orc_inv_i16_u8 per block, pitches in bytes (configs[2] as SURVEY.md 8(d) defines it: u8 in, u8 out) */
+int orc_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift,
+                     size_t sizeX, size_t sizeY, size_t by0, size_t by1);
 int orc_fwd_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
                 size_t sizeX, size_t sizeY, size_t by0, size_t by1);
 int orc_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,

@@ -44,6 +44,8 @@ class PlaneI16(ctypes.Structure):
     ]
 
 
+PlaneU8 = PlaneI16  # mdct_plane_u8: the same layout, pitches in bytes
+
 _PLANE = [c_void_p, c_void_p, c_size_t, c_size_t, f32p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]
 _PLANE_F32 = [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]
 _REF = [c_int, c_void_p, c_void_p, f32p, c_size_t, c_size_t, c_size_t, c_size_t]
@@ -70,6 +72,9 @@ SIGNATURES = {
     "mdct_roundtrip_i16_batch": (c_int, [ctypes.POINTER(PlaneI16), c_int, c_void_p]),
     "mdct_batch_create": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(PlaneI16), c_int]),
     "mdct_batch_run": (c_int, [c_void_p, c_void_p]),
+    "mdct_roundtrip_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, f32p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mdct_roundtrip_u8_batch": (c_int, [ctypes.POINTER(PlaneU8), c_int, c_int, c_void_p]),
+    "mdct_batch_create_u8": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(PlaneU8), c_int, c_int]),
     "mdct_batch_launches": (c_int, [c_void_p]),
     "mdct_batch_destroy": (c_int, [c_void_p]),
     "mdct_zigzag_rle_i16": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -248,14 +248,38 @@ def i16_batch(mode, planes, stream=None, check=True):
     return rc
 
 
-class Batch:
-    """mdct_batch: descriptors and tables uploaded once, every run ONE launch (capture-safe)."""
+def roundtrip_u8(src, dst, sizeX, sizeY, lut=None, level_shift=True, by0=0, by1=None, pitch_in=None, pitch_out=None, stream=None, check=True):
+    """8-bit pixels -> forward, quantise, dequantise, inverse -> 8-bit pixels in one pass (mdct_roundtrip_u8); pitches in bytes"""
+    keep, lp = _lut_ptr(lut)
+    rc = _lib.load().mdct_roundtrip_u8(_ptr(src), _ptr(dst), sizeX if pitch_in is None else pitch_in, sizeX if pitch_out is None else pitch_out, lp, int(bool(level_shift)),
+                                       sizeX, sizeY, by0, sizeY // 8 if by1 is None else by1, _stream(stream))
+    if check:
+        _check(rc)
+    return rc
 
-    def __init__(self, mode, planes):
+
+def roundtrip_u8_batch(planes, level_shift=True, stream=None, check=True):
+    """mdct_roundtrip_u8_batch: planes as for _plane_array (uint8 tensors, pitches in bytes); the call BASELINE.json configs[2]
+    (Y + Cb + Cr with per-plane tables, 8-bit planes in and out) is measured on."""
+    arr, keep = _plane_array(planes)
+    rc = _lib.load().mdct_roundtrip_u8_batch(arr, len(planes), int(bool(level_shift)), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+class Batch:
+    """mdct_batch: descriptors and tables uploaded once, every run ONE launch (capture-safe).
+    mode 'roundtrip_u8': 8-bit planes (mdct_batch_create_u8), otherwise int16 planes."""
+
+    def __init__(self, mode, planes, level_shift=True):
         lib = _lib.load()
         arr, self._keep = _plane_array(planes)
         h = ctypes.c_void_p()
-        _check(lib.mdct_batch_create(ctypes.byref(h), MODES[mode], arr, len(planes)))
+        if mode == "roundtrip_u8":
+            _check(lib.mdct_batch_create_u8(ctypes.byref(h), arr, len(planes), int(bool(level_shift))))
+        else:
+            _check(lib.mdct_batch_create(ctypes.byref(h), MODES[mode], arr, len(planes)))
         self._h = h
         self.launches = lib.mdct_batch_launches(h)
 
@@ -527,6 +551,19 @@ def prepare_i16_batch(mode, planes, stream=None):
     fn = {"fwd": lib.mdct_fwd_i16_batch, "inv": lib.mdct_inv_i16_batch, "roundtrip": lib.mdct_roundtrip_i16_batch}[mode]
     arr, keep = _plane_array(planes)
     return Prepared(fn, (arr, ctypes.c_int(len(planes)), _stream(stream)), keep)
+
+
+def prepare_u8_batch(planes, level_shift=True, stream=None):
+    """Prepared launch of mdct_roundtrip_u8_batch (planes as for roundtrip_u8_batch)"""
+    arr, keep = _plane_array(planes)
+    return Prepared(_lib.load().mdct_roundtrip_u8_batch, (arr, ctypes.c_int(len(planes)), ctypes.c_int(int(bool(level_shift))), _stream(stream)), keep)
+
+
+def prepare_roundtrip_u8(src, dst, sizeX, sizeY, lut=None, level_shift=True, stream=None):
+    keep, lp = _lut_ptr(lut)
+    sz = ctypes.c_size_t
+    args = (ctypes.c_void_p(_ptr(src)), ctypes.c_void_p(_ptr(dst)), sz(sizeX), sz(sizeX), lp, ctypes.c_int(int(bool(level_shift))), sz(sizeX), sz(sizeY), sz(0), sz(sizeY // 8), _stream(stream))
+    return Prepared(_lib.load().mdct_roundtrip_u8, args, (keep, src, dst))
 
 
 def prepare_stream_copy(src, dst, nbytes, stream=None):

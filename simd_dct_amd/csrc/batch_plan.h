@@ -16,15 +16,23 @@
 
 #include "mdct.h"
 
+// The index arithmetic below is ONE piece of code for the host walk (tests/batch_plan_driver.cpp, plain g++ with sanitizers) and
+// for the kernels (mdct_kernels.hip: k_i16_batch, k_u8_batch call batch_plane_of / magic_apply themselves).
+#if defined(__HIPCC__)
+#define MDCT_HD __host__ __device__ __forceinline__
+#else
+#define MDCT_HD inline
+#endif
+
 namespace mdct
 {
 
 // What a wave needs of its plane: one 64-byte descriptor, read with scalar loads (one s_load_dwordx16).
 struct BatchDesc
 {
-  const int16_t *from;
-  int16_t *to;
-  uint64_t pitch_in, pitch_out; // elements
+  const void *from;             // int16 planes (k_i16_batch) or 8-bit planes (k_u8_batch)
+  void *to;
+  uint64_t pitch_in, pitch_out; // elements (int16 planes) / bytes (8-bit planes)
   uint32_t bpr;                 // blocks per block row (sizeX / 8)
   uint32_t tiles;               // 64-block tiles per block row, the last one possibly partial: (bpr + 63) / 64
   uint32_t tiles_m, tiles_s;    // exact division by `tiles` (MagicDiv: multiplier, shifts sh1 | sh2 << 8)
@@ -51,14 +59,43 @@ inline MagicDiv magic_div(uint32_t d)
   const uint64_t m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
   return MagicDiv{(uint32_t)m, 1u | ((l - 1) << 8)};
 }
-inline uint32_t magic_apply(uint32_t n, uint32_t m, uint32_t s)
+MDCT_HD uint32_t magic_apply(uint32_t n, uint32_t m, uint32_t s)
 {
-  const uint32_t t = (uint32_t)(((uint64_t)n * m) >> 32);
+  const uint32_t t = (uint32_t)(((uint64_t)n * m) >> 32); // device: one s_mul_hi_u32 / v_mul_hi_u32
   return (t + ((n - t) >> (s & 0xFF))) >> (s >> 8);
 }
 
 constexpr int kBatchChain = 8;                // up to this many planes of different shapes are told apart by a compare chain
-constexpr uint32_t kBatchMaxTiles = 0x7FFFFFFFu; // grid limit of one launch
+// Grid limit of one launch: a tile is a 64-thread workgroup and the HIP runtime refuses launches of more than 2^32 - 1 threads
+// (gridDim.x * blockDim.x), so 2^26 - 1 tiles (= 4.29e9 blocks, 275 Gpx); longer lists are split into several launches.
+constexpr uint32_t kBatchMaxTiles = 0xFFFFFFFFu / 64;
+
+// Which plane tile `w` of a launch belongs to -- the ONE implementation, run by the kernels and walked by the CPU test:
+// equal tile grids: a magic multiply; up to kBatchChain different ones: a compare chain on the firsts the header carries
+// (UINT32_MAX beyond n); more: the last plane whose first tile is <= w, `first_of(k)` reading descriptor k's `first`.
+template <class FirstOf>
+MDCT_HD uint32_t batch_plane_of(uint32_t w, uint32_t n, uint32_t uniform, uint32_t pp_m, uint32_t pp_s, const uint32_t (&first8)[kBatchChain], FirstOf first_of)
+{
+  if (uniform)
+    return magic_apply(w, pp_m, pp_s);
+  uint32_t p = 0;
+  for (int i = 1; i < kBatchChain; i++)
+    p += w >= first8[i] ? 1u : 0u;
+  if (n > (uint32_t)kBatchChain)
+  {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1)
+    {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (first_of(mid) <= w)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    p = lo;
+  }
+  return p;
+}
 
 struct BatchLayout
 {
@@ -78,13 +115,14 @@ struct BatchLayout
 // (blob_bytes = 0: no limit) and the grid limit.  table_id[i] < 0: plane i needs no table slot; equal ids share a slot.
 // has_lut[i] goes into the descriptor.  Planes without blocks take no descriptor.  Always consumes at least one plane
 // when i0 < n (a single plane that exceeds the grid limit yields consumed = 0: the caller reports it).
-inline void batch_layout(const mdct_plane_i16 *planes, const int *table_id, const unsigned char *has_lut, int i0, int n, size_t blob_bytes, size_t table_size, BatchLayout &out)
+template <class Plane> // mdct_plane_i16 or mdct_plane_u8: the same field names, pitches in the plane's own unit
+inline void batch_layout(const Plane *planes, const int *table_id, const unsigned char *has_lut, int i0, int n, size_t blob_bytes, size_t table_size, BatchLayout &out)
 {
   out = BatchLayout();
   uint64_t run = 0;
   for (int i = i0; i < n; i++)
   {
-    const mdct_plane_i16 &p = planes[i];
+    const Plane &p = planes[i];
     const uint64_t bpr = p.sizeX / 8, rows = p.sizeY / 8;
     if (bpr == 0 || rows == 0)
     {
@@ -142,35 +180,14 @@ inline void batch_layout(const mdct_plane_i16 *planes, const int *table_id, cons
     out.first8[k] = (size_t)k < nd ? out.descs[k].first : 0xFFFFFFFFu;
 }
 
-// Where tile `w` of a launch lies: the kernel's own arithmetic (k_i16_batch), kept here so that the CPU test walks it.
+// Where tile `w` of a launch lies, as the kernels compute it (batch_plane_of, then the row / tile split by the plane's MagicDiv).
 struct BatchWhere
 {
   uint32_t p, row, tile;
 };
-inline BatchWhere batch_locate(const BatchDesc *descs, uint32_t n, uint32_t uniform, MagicDiv pp, const uint32_t *first8, uint32_t w)
+inline BatchWhere batch_locate(const BatchDesc *descs, uint32_t n, uint32_t uniform, MagicDiv pp, const uint32_t (&first8)[kBatchChain], uint32_t w)
 {
-  uint32_t p;
-  if (uniform)
-    p = magic_apply(w, pp.m, pp.s);
-  else if (n <= (uint32_t)kBatchChain)
-  {
-    p = 0;
-    for (int i = 1; i < kBatchChain; i++)
-      p += w >= first8[i] ? 1 : 0;
-  }
-  else
-  { // last plane whose first tile is <= w
-    uint32_t lo = 0, hi = n;
-    while (hi - lo > 1)
-    {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (descs[mid].first <= w)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    p = lo;
-  }
+  const uint32_t p = batch_plane_of(w, n, uniform, pp.m, pp.s, first8, [descs](uint32_t k) { return descs[k].first; });
   const BatchDesc &d = descs[p];
   const uint32_t lt = w - d.first;
   const uint32_t row = magic_apply(lt, d.tiles_m, d.tiles_s);

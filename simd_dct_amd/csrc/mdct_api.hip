@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "mdct.h"
@@ -401,12 +402,48 @@ struct BatchInput
   std::vector<mdct::OwnTables> tables; // distinct tables of the whole list
   std::vector<int> table_id;           // per plane: index into `tables`, -1 = takes no table slot
   std::vector<unsigned char> has_lut;  // per plane: a quantisation table was given
-  std::vector<unsigned char> bounded;  // per plane: lut_bounded()
+  std::vector<unsigned char> bounded;  // per plane: lut_bounded() (int16 planes) / u8_table_is_tame() (8-bit planes)
 };
 
-int batch_input(int mode, const mdct_plane_i16 *planes, int n, BatchInput &in)
+constexpr int kModeRoundtripU8 = 3; // internal: the fused 8-bit round trip (k_u8_batch); the public modes are MDCT_MODE_*
+
+// 8-bit planes: pitches in bytes, no alignment requirement (the reference's loads are unaligned too, simd_dct.cpp:2109)
+int u8_plane_args(const void *from, const void *to, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1)
 {
-  if (mode != mdct::MODE_FWD && mode != mdct::MODE_INV && mode != mdct::MODE_ROUNDTRIP)
+  if (from == nullptr || to == nullptr)
+    return fail(MDCT_INVALID_PARAMETER, "null plane pointer");
+  if (sizeX % 8 != 0 || sizeY % 8 != 0)
+    return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu is not a multiple of 8x8", sizeX, sizeY);
+  if (pitch_in < sizeX || pitch_out < sizeX || by0 > by1 || by1 > sizeY / 8)
+    return fail(MDCT_INVALID_PARAMETER, "bad pitch or block-row range [%zu,%zu) for %zu rows", by0, by1, sizeY / 8);
+  return MDCT_SUCCESS;
+}
+
+// The fast build of k_u8_batch (mdct_kernels.hip) leaves out the quantiser's saturations and packs the output with
+// v_sat_pk_u8_i16, which sees rne(x) + shift as an int16.  Both are safe when
+//   every |lut[i]| >= 1/16   |coefficient| <= 8 * 255 for 8-bit pixels, so |coefficient / lut| <= 32640 < 32767.5
+//   |lut|_2 <= 40000         Parseval on the orthonormal transform: |x|_inf <= |z|_2 <= |y|_2 + |z - y|_2 <= 2040 + |lut|_2 / 2 = 22040
+//                            (z = dequantised coefficients, each within lut[i] / 2 of y), far inside int16 with the shift added
+// No table: all ones.  Any other finite non-zero table takes the general build.
+bool u8_table_is_tame(const float *lut)
+{
+  if (!lut)
+    return true;
+  double ss = 0.0;
+  for (int i = 0; i < 64; i++)
+  {
+    if (!(fabsf(lut[i]) >= 0.0625f))
+      return false;
+    ss += (double)lut[i] * lut[i];
+  }
+  return ss <= 40000.0 * 40000.0;
+}
+
+template <class Plane>
+int batch_input(int mode, const Plane *planes, int n, BatchInput &in)
+{
+  constexpr bool U8 = std::is_same<Plane, mdct_plane_u8>::value;
+  if (U8 ? mode != kModeRoundtripU8 : (mode != mdct::MODE_FWD && mode != mdct::MODE_INV && mode != mdct::MODE_ROUNDTRIP))
     return fail(MDCT_INVALID_PARAMETER, "batch mode %d (MDCT_MODE_FWD / _INV / _ROUNDTRIP)", mode);
   if (n < 0 || (planes == nullptr && n > 0))
     return fail(MDCT_INVALID_PARAMETER, "null plane list");
@@ -417,14 +454,18 @@ int batch_input(int mode, const mdct_plane_i16 *planes, int n, BatchInput &in)
   std::vector<const float *> src; // what each distinct table was made from (nullptr = no quantisation)
   for (int i = 0; i < n; i++)
   { // validate everything before launching anything
-    const mdct_plane_i16 &p = planes[i];
-    int r = own_plane_args(p.from, p.to, sizeof(int16_t), p.pitch_in, p.pitch_out, p.sizeX, p.sizeY, 0, p.sizeY / 8);
+    const Plane &p = planes[i];
+    int r;
+    if constexpr (U8)
+      r = u8_plane_args(p.from, p.to, p.pitch_in, p.pitch_out, p.sizeX, p.sizeY, 0, p.sizeY / 8);
+    else
+      r = own_plane_args(p.from, p.to, sizeof(int16_t), p.pitch_in, p.pitch_out, p.sizeX, p.sizeY, 0, p.sizeY / 8);
     if (r)
       return r;
     in.has_lut[i] = p.lut != nullptr;
-    in.bounded[i] = lut_bounded(p.lut);
+    in.bounded[i] = U8 ? u8_table_is_tame(p.lut) : lut_bounded(p.lut);
     if (rt && !p.lut)
-      continue; // the fused round trip without a table needs no multipliers at all (1/64 rides in the rounding)
+      continue; // the fused int16 round trip without a table needs no multipliers at all (1/64 rides in the rounding)
     int id = -1;
     for (size_t k = 0; k < src.size() && id < 0; k++)
       if (src[k] == p.lut || (src[k] && p.lut && memcmp(src[k], p.lut, 64 * sizeof(float)) == 0))
@@ -432,7 +473,7 @@ int batch_input(int mode, const mdct_plane_i16 *planes, int n, BatchInput &in)
     if (id < 0)
     {
       mdct::OwnTables tb;
-      if ((r = make_own_tables(p.lut, tb, /*pair_order=*/rt)))
+      if ((r = make_own_tables(p.lut, tb, /*pair_order=*/rt || U8)))
         return r;
       id = (int)src.size();
       src.push_back(p.lut);
@@ -456,6 +497,7 @@ void batch_header(const mdct::BatchLayout &lay, const BatchInput &in, BatchLaunc
 {
   mdct::BatchArgs &a = l.args;
   a.consts = mdct::DctConsts();
+  memset(a.px, 0, sizeof(a.px));
   memset(&a.head, 0, sizeof(a.head));
   a.head.n = (uint32_t)lay.descs.size();
   a.head.uniform = lay.uniform;
@@ -473,8 +515,23 @@ void batch_header(const mdct::BatchLayout &lay, const BatchInput &in, BatchLaunc
   l.sat = !all_bounded;
 }
 
+void u8_px_consts(int level_shift, float (&px)[4])
+{
+  const float shift = level_shift ? 128.0f : 0.0f;
+  px[0] = 64.0f * shift;       // forward: the level shift is "raw DC - 64 * shift"
+  px[1] = 12582912.0f + shift; // 1.5 * 2^23 + shift: even, so ties still round to even; the low bits of x + this are rne(x) + shift
+  px[2] = 0.0f - shift;        // rne(x) + shift in [0, 255]  <=>  x clamped to [-shift, 255 - shift]
+  px[3] = 255.0f - shift;
+}
+
+hipError_t launch_batch(const BatchLaunch &l, int mode, hipStream_t s)
+{
+  return mode == kModeRoundtripU8 ? mdct::launch_u8_batch(l.args, l.total, l.sat, s) : mdct::launch_i16_batch(l.args, l.total, mode, l.lutmode, l.sat, s);
+}
+
 // no allocation on the device, no copy: descriptors and tables travel in the kernel arguments, as many planes per launch as fit
-int run_i16_batch(int mode, const mdct_plane_i16 *planes, int n, void *stream)
+template <class Plane>
+int run_batch(int mode, const Plane *planes, int n, int level_shift, void *stream)
 {
   BatchInput in;
   int r = batch_input(mode, planes, n, in);
@@ -488,10 +545,11 @@ int run_i16_batch(int mode, const mdct_plane_i16 *planes, int n, void *stream)
     mdct::BatchLayout lay;
     mdct::batch_layout(planes, in.table_id.data(), in.has_lut.data(), i0, n, mdct::kBatchBlob, sizeof(mdct::OwnTables), lay);
     if (lay.consumed == 0)
-      return fail(MDCT_NOT_SUPPORTED, "plane %d (%zux%zu) exceeds the 2^31 tile limit of one launch; split it", i0, planes[i0].sizeX, planes[i0].sizeY);
+      return fail(MDCT_NOT_SUPPORTED, "plane %d (%zux%zu) exceeds the limit of 2^26 - 1 tiles per launch; split it", i0, planes[i0].sizeX, planes[i0].sizeY);
     i0 += lay.consumed;
     BatchLaunch l;
     batch_header(lay, in, l);
+    u8_px_consts(level_shift, l.args.px);
     for (size_t k = 0; k < lay.tables.size(); k++)
       memcpy(l.args.blob + k * sizeof(mdct::OwnTables), &in.tables[lay.tables[k]], sizeof(mdct::OwnTables));
     // the chunk's tables from the device's table cache when all of them are parked there (descriptors: always in the arguments)
@@ -509,12 +567,14 @@ int run_i16_batch(int mode, const mdct_plane_i16 *planes, int n, void *stream)
         d.table = (uint32_t)((parked[d.table / sizeof(mdct::OwnTables)] - base) * sizeof(mdct::OwnTables));
     }
     memcpy(l.args.blob + l.args.head.table_bytes, lay.descs.data(), lay.descs.size() * sizeof(mdct::BatchDesc));
-    const hipError_t e = mdct::launch_i16_batch(l.args, l.total, mode, l.lutmode, l.sat, (hipStream_t)stream);
+    const hipError_t e = launch_batch(l, mode, (hipStream_t)stream);
     if (e != hipSuccess)
       return hip_fail(e, "plane batch launch");
   }
   return MDCT_SUCCESS;
 }
+
+int run_i16_batch(int mode, const mdct_plane_i16 *planes, int n, void *stream) { return run_batch(mode, planes, n, 0, stream); }
 
 } // namespace
 
@@ -820,7 +880,10 @@ struct mdct_batch
   std::vector<BatchLaunch> launches;
 };
 
-int mdct_batch_create(mdct_batch **out, int mode, const mdct_plane_i16 *planes, int n_planes)
+} // extern "C" (a template cannot have C linkage)
+
+template <class Plane>
+static int batch_create(mdct_batch **out, int mode, const Plane *planes, int n_planes, int level_shift)
 {
   if (out == nullptr)
     return fail(MDCT_INVALID_PARAMETER, "null batch handle");
@@ -845,13 +908,14 @@ int mdct_batch_create(mdct_batch **out, int mode, const mdct_plane_i16 *planes, 
     if (lay.consumed == 0)
     {
       delete b;
-      return fail(MDCT_NOT_SUPPORTED, "plane %d (%zux%zu) exceeds the 2^31 tile limit of one launch; split it", i0, planes[i0].sizeX, planes[i0].sizeY);
+      return fail(MDCT_NOT_SUPPORTED, "plane %d (%zux%zu) exceeds the limit of 2^26 - 1 tiles per launch; split it", i0, planes[i0].sizeX, planes[i0].sizeY);
     }
     i0 += lay.consumed;
     if (lay.descs.empty())
       continue;
     BatchLaunch l;
     batch_header(lay, in, l);
+    u8_px_consts(level_shift, l.args.px);
     memset(l.args.blob, 0, sizeof(l.args.blob));
     at.push_back(image.size());
     for (int id : lay.tables)
@@ -887,6 +951,23 @@ int mdct_batch_create(mdct_batch **out, int mode, const mdct_plane_i16 *planes, 
   return MDCT_SUCCESS;
 }
 
+extern "C" {
+
+int mdct_batch_create(mdct_batch **out, int mode, const mdct_plane_i16 *planes, int n_planes) { return batch_create(out, mode, planes, n_planes, 0); }
+int mdct_batch_create_u8(mdct_batch **out, const mdct_plane_u8 *planes, int n_planes, int level_shift) { return batch_create(out, kModeRoundtripU8, planes, n_planes, level_shift); }
+
+int mdct_roundtrip_u8_batch(const mdct_plane_u8 *planes, int n_planes, int level_shift, void *stream) { return run_batch(kModeRoundtripU8, planes, n_planes, level_shift, stream); }
+
+// one plane, block rows [by0, by1): the strip as a batch of one (the same kernel, descriptors and table in the arguments)
+int mdct_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
+{
+  const int r = u8_plane_args(from, to, pitch_in, pitch_out, sizeX, sizeY, by0, by1);
+  if (r)
+    return r;
+  const mdct_plane_u8 strip = {from + by0 * 8 * pitch_in, to + by0 * 8 * pitch_out, pitch_in, pitch_out, sizeX, (by1 - by0) * 8, lut};
+  return run_batch(kModeRoundtripU8, &strip, 1, level_shift, stream);
+}
+
 int mdct_batch_run(const mdct_batch *b, void *stream)
 {
   if (b == nullptr)
@@ -896,7 +977,7 @@ int mdct_batch_run(const mdct_batch *b, void *stream)
     return fail(MDCT_INVALID_PARAMETER, "the batch was created on device %d, the calling thread's current device is %d", b->device, dev);
   for (const BatchLaunch &l : b->launches)
   {
-    const hipError_t e = mdct::launch_i16_batch(l.args, l.total, b->mode, l.lutmode, l.sat, (hipStream_t)stream);
+    const hipError_t e = launch_batch(l, b->mode, (hipStream_t)stream);
     if (e != hipSuccess)
       return hip_fail(e, "plane batch launch");
   }

@@ -175,13 +175,18 @@ struct BatchArgs
   const BatchDesc *descs;  // device memory, or nullptr: embedded
   const OwnTables *tables; // device memory, or nullptr: embedded (blob)
   DctConsts consts;
+  alignas(8) float px[4];  // k_u8_batch only: (64 * shift, 1.5 * 2^23 + shift, -shift, 255 - shift), shift = 128 with the level shift, else 0
   alignas(64) unsigned char blob[kBatchBlob]; // [tables][descriptors]
 };
-static_assert(offsetof(BatchArgs, descs) == 64 && offsetof(BatchArgs, tables) == 72, "k_i16_batch reads head + pointers as 20 consecutive dwords");
+static_assert(offsetof(BatchArgs, descs) == 64 && offsetof(BatchArgs, tables) == 72, "the batch kernels read head + pointers as 20 consecutive dwords");
+static_assert(offsetof(BatchArgs, px) % 8 == 0, "k_u8_batch reads px as two register pairs");
 static_assert(sizeof(BatchArgs) <= 4096, "kernel argument block");
 enum { BATCH_NO_LUT = 0, BATCH_ALL_LUT = 1, BATCH_MIXED = 2 };
 // total: tiles in the launch; lutmode / sat matter for MODE_ROUNDTRIP only
 hipError_t launch_i16_batch(const BatchArgs &a, uint32_t total, int mode, int lutmode, bool sat, hipStream_t s);
+// the fused 8-bit round trip on the same descriptors (pointers / pitches in bytes); general: some plane's table needs the saturating
+// quantiser or the clamping output stage (mdct_api.hip: u8_table_is_tame)
+hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, bool general, hipStream_t s);
 
 hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool safe, hipStream_t s);
 // lut_bounded / luts_bounded: every entry of every table >= 8.01 in magnitude (a quantised coefficient cannot leave int16)

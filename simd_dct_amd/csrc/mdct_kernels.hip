@@ -1403,29 +1403,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 // on kernel arguments; more: a binary search with scalar loads), reads the plane's 64-byte descriptor and its tables with scalar
 // loads, and a row's last tile may be partial (1920- and 3840-wide planes are 240 / 480 blocks per row): lanes beyond the row
 // leave at once -- nothing below crosses lanes.
-__device__ __forceinline__ uint32_t magic_quot(uint32_t n, uint32_t m, uint32_t s)
-{
-  const uint32_t t = __umulhi(n, m);
-  return (t + ((n - t) >> (s & 0xFF))) >> (s >> 8);
-}
 typedef uint32_t u32x16_s __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4_s __attribute__((ext_vector_type(4)));
 static_assert(offsetof(BatchDesc, from) == 0 && offsetof(BatchDesc, to) == 8 && offsetof(BatchDesc, pitch_in) == 16 && offsetof(BatchDesc, pitch_out) == 24 && offsetof(BatchDesc, bpr) == 32 &&
                   offsetof(BatchDesc, tiles) == 36 && offsetof(BatchDesc, tiles_m) == 40 && offsetof(BatchDesc, tiles_s) == 44 && offsetof(BatchDesc, first) == 48 && offsetof(BatchDesc, table) == 52 &&
                   offsetof(BatchDesc, has_lut) == 56,
-              "k_i16_batch picks the descriptor's fields out of one 16-dword load");
+              "batch_tile picks the descriptor's fields out of one 16-dword load");
 
-// Scheduling steered per mode like k_i16_tile; measured on the 8K 4:2:0 frame and on batches of one (profiles/r04_exp_batch_variants.log):
-// the fused round trip with phase priorities at 3 waves per SIMD (frame 38.0 us against 40.3 at 2, 8192^2 45.3 against 46.0-46.5),
-// forward and inverse at 2 (8192^2 forward 44.2-44.4 against 44.8-45.0 at 3 and 46.2 at 4).
-constexpr int batch_waves(int mode) { return mode == MODE_ROUNDTRIP ? 3 : 2; }
-// (and, like k_i16_tile, 4 waves per SIMD for launches of 2049..6144 tiles: SMALL)
-template <int MODE, int LUTMODE, bool SAT = true, bool SMALL = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? 4 : batch_waves(MODE), SMALL ? 4 : batch_waves(MODE)))) void k_i16_batch(BatchArgs a)
+// What tile `w` of a batch launch is: its plane's descriptor, the block row and the tile within the row, where the plane's tables lie.
+// Exactly two dependent rounds of scalar loads stand between a wave's start and its first row load: the header (20 dwords, fetched
+// as ONE batch through a pointer the compiler cannot see through -- left to itself it loaded field by field, ten round trips), then
+// the plane's descriptor (one s_load_dwordx16).  The index arithmetic is batch_plan.h's (batch_plane_of, magic_apply): the code the
+// CPU test walks under the sanitizers is the code that runs here.
+struct BatchTile
 {
-  // Two dependent rounds of scalar loads stand between a wave's start and its first row load: the header (20 dwords, fetched as ONE
-  // batch -- left to the compiler each field was a load with a wait of its own, ten round trips), then the plane's descriptor.
-  const uint32_t w = blockIdx.x;
+  u32x16_s d;      // the plane's BatchDesc
+  uint32_t row;    // block row within the plane
+  uint32_t tile;   // 64-block tile within the row (the last one possibly partial)
+  kbytes_t tables; // the plane's OwnTables
+  __device__ __forceinline__ uint32_t bpr() const { return d[8]; }
+  __device__ __forceinline__ uint32_t has_lut() const { return d[14]; }
+  __device__ __forceinline__ uint64_t from() const { return ((uint64_t)d[1] << 32) | d[0]; }
+  __device__ __forceinline__ uint64_t to() const { return ((uint64_t)d[3] << 32) | d[2]; }
+  __device__ __forceinline__ size_t pitch_in() const { return ((uint64_t)d[5] << 32) | d[4]; }
+  __device__ __forceinline__ size_t pitch_out() const { return ((uint64_t)d[7] << 32) | d[6]; }
+};
+__device__ __forceinline__ BatchTile batch_tile(uint32_t w)
+{
   kbytes_t args = karg_bytes(0);
   asm volatile("" : "+s"(args)); // opaque: the loads below stay two wide loads, issued together
   const u32x16_s h = *(const __attribute__((address_space(4))) u32x16_s *)args;
@@ -1435,51 +1439,165 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? 4 : 
   const kbytes_t blob = args + offsetof(BatchArgs, blob);
   const kbytes_t descs = descs_dev ? (kbytes_t)descs_dev : blob + table_bytes;
   const kbytes_t tables = tables_dev ? (kbytes_t)tables_dev : blob;
-  uint32_t p = magic_quot(w, pp_m, pp_s); // equal shapes
-  if (!uniform)
-  {
-    p = 0; // up to kBatchChain different shapes: a compare chain on the header (first8 is UINT32_MAX beyond n)
-#pragma unroll
-    for (int i = 1; i < kBatchChain; i++)
-      p += w >= h[8 + i] ? 1u : 0u;
-    if (n > (uint32_t)kBatchChain)
-    { // more: the last plane whose first tile is <= w
-      uint32_t lo = 0, hi = n;
-      while (hi - lo > 1)
-      {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (*(const __attribute__((address_space(4))) uint32_t *)(descs + (size_t)mid * sizeof(BatchDesc) + offsetof(BatchDesc, first)) <= w)
-          lo = mid;
-        else
-          hi = mid;
-      }
-      p = lo;
-    }
-  }
+  const uint32_t first8[kBatchChain] = {h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]};
+  static_assert(kBatchChain == 8 && offsetof(BatchHead, first8) == 32, "first8 = dwords 8..15 of the header");
+  uint32_t p = batch_plane_of(w, n, uniform, pp_m, pp_s, first8, [descs](uint32_t k) {
+    return *(const __attribute__((address_space(4))) uint32_t *)(descs + (size_t)k * sizeof(BatchDesc) + offsetof(BatchDesc, first));
+  });
   p = __builtin_amdgcn_readfirstlane(p); // (the compare chain may have been evaluated on the vector unit)
   kbytes_t dp = descs + (size_t)p * sizeof(BatchDesc);
   asm volatile("" : "+s"(dp));
-  const u32x16_s d = *(const __attribute__((address_space(4))) u32x16_s *)dp;
-  const uint32_t d_bpr = d[8], d_tiles = d[9], d_first = d[12], d_table = d[13], d_has_lut = d[14];
-  const uint32_t lt = w - d_first;
-  const uint32_t row = magic_quot(lt, d[10], d[11]);
-  const uint32_t tile = lt - row * d_tiles;
-  if (tile * 64 + threadIdx.x >= d_bpr)
+  BatchTile t;
+  t.d = *(const __attribute__((address_space(4))) u32x16_s *)dp;
+  const uint32_t lt = w - t.d[12];
+  t.row = magic_apply(lt, t.d[10], t.d[11]);
+  t.tile = lt - t.row * t.d[9];
+  t.tables = tables + t.d[13];
+  return t;
+}
+
+// Scheduling steered per mode like k_i16_tile; measured on the 8K 4:2:0 frame and on batches of one (profiles/r04_exp_batch_variants.log):
+// the fused round trip with phase priorities at 3 waves per SIMD (frame 38.0 us against 40.3 at 2, 8192^2 45.3 against 46.0-46.5),
+// forward and inverse at 2 (8192^2 forward 44.2-44.4 against 44.8-45.0 at 3 and 46.2 at 4).
+constexpr int batch_waves(int mode) { return mode == MODE_ROUNDTRIP ? 3 : 2; }
+// (and, like k_i16_tile, 4 waves per SIMD for launches of 2049..6144 tiles: SMALL)
+template <int MODE, int LUTMODE, bool SAT = true, bool SMALL = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? 4 : batch_waves(MODE), SMALL ? 4 : batch_waves(MODE)))) void k_i16_batch(BatchArgs a)
+{
+  const BatchTile t = batch_tile(blockIdx.x);
+  if (t.tile * 64 + threadIdx.x >= t.bpr())
     return;
-  const int16_t *d_from = (const int16_t *)(((uint64_t)d[1] << 32) | d[0]);
-  int16_t *d_to = (int16_t *)(((uint64_t)d[3] << 32) | d[2]);
-  const size_t pin = ((uint64_t)d[5] << 32) | d[4], pout = ((uint64_t)d[7] << 32) | d[6];
-  const RowsTiled rows{d_from + (size_t)row * 8 * pin + (size_t)tile * 512, d_to + (size_t)row * 8 * pout + (size_t)tile * 512, pin, pout, threadIdx.x * 16};
-  const kbytes_t tbp = tables + d_table;
+  const size_t pin = t.pitch_in(), pout = t.pitch_out();
+  const RowsTiled rows{(const int16_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.tile * 512, (int16_t *)t.to() + (size_t)t.row * 8 * pout + (size_t)t.tile * 512, pin, pout, threadIdx.x * 16};
   if constexpr (MODE == MODE_ROUNDTRIP)
   {
-    if (LUTMODE == BATCH_ALL_LUT || (LUTMODE == BATCH_MIXED && d_has_lut))
-      i16_roundtrip_rows<true, RowsTiled, true, SAT>(a.consts, rows, tbp);
+    if (LUTMODE == BATCH_ALL_LUT || (LUTMODE == BATCH_MIXED && t.has_lut()))
+      i16_roundtrip_rows<true, RowsTiled, true, SAT>(a.consts, rows, t.tables);
     else
       i16_roundtrip_rows<false, RowsTiled, true>(a.consts, rows, nullptr);
   }
   else
-    i16_block<MODE, true>(a.consts, rows, *(ktables_t)tbp);
+    i16_block<MODE, true>(a.consts, rows, *(ktables_t)t.tables);
+}
+
+// ---------------------------------------------------------------------------------------
+// 8-bit pixels in, 8-bit pixels out: forward -> quantise -> dequantise -> inverse in one pass (BASELINE.json configs[2] as SURVEY.md
+// 8(d) states it: u8 planes, 2 bytes per pixel; the reference's pixel type, simd_dct.cpp:2107-2143, and the half of the codec it
+// does not have).  Bit for bit k_u8_i16<FWD> followed by k_u8_i16<INV>; the int16 coefficients exist only in registers.
+//   rows in      8 x 8 B per lane (a tile row = 512 contiguous bytes per wave load), v_cvt_f32_ubyteN
+//   forward      aan_fwd_h per row, aan_fwd_v per column pair -- the packed butterflies of i16_roundtrip_rows; the level shift is
+//                "raw DC - 64 * 128" (k_u8_i16)
+//   quantiser    c = sat_i16(rne(y * qf)), z = c * dq on register pairs; SAT = false (host: every table entry >= 1/16 in
+//                magnitude, so |y / lut| <= 16 * 2040 stays inside int16) leaves the saturations out
+//   inverse      aan_inv_v, aan_inv_h
+//   rows out     clamp(rne(x) + shift, 0, 255): the magic add (1.5 * 2^23 + shift is even: ties as rne, low bits = rne(x) + shift), then
+//                FIN_SATPK  low halves paired by v_perm_b32, v_sat_pk_u8_i16 saturates both to bytes: 14 instructions per row.  Needs
+//                           |rne(x) + shift| < 2^15, which the host guarantees from the table (Parseval: |x| <= 2040 + |lut|_2 / 2)
+//                FIN_CLAMP  v_med3_f32 before the add, 3 x v_perm_b32 per 4 bytes: 18 per row, any finite x
+// No LDS, nothing crosses lanes: a partial last tile just drops its lanes.
+// ---------------------------------------------------------------------------------------
+enum { FIN_CLAMP = 0, FIN_SATPK = 1 };
+#define MDCT_PKAK(d, a, k, mods) asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "s"(k))
+__device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t v)
+{
+  uint32_t r;
+  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+template <bool SAT, int FIN, bool PRIO>
+__device__ __forceinline__ void u8_roundtrip_rows(const DctConsts &C, const f32x2 shift_magic, const f32x2 lo_hi, const uint8_t *src, uint8_t *dst, size_t pitch_in, size_t pitch_out,
+                                                  uint32_t lane_off, kbytes_t tbp)
+{
+  const AanPk &K = reinterpret_cast<const AanPk &>(C);
+  uint2 rows[8];
+  load_block_rows_g(src, pitch_in, lane_off, rows);
+  MDCT_PHASE_PRIO(1);
+  f32x2 P[4][8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    const f32x2 a01 = {ubyte_to_float<0>(rows[r].x), ubyte_to_float<1>(rows[r].x)}, a23 = {ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
+    const f32x2 a45 = {ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)}, a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
+    aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
+  }
+  MDCT_PHASE_PRIO(2);
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    aan_fwd_v(K, P[j]);
+    if (j == 0)
+      P[0][0].x = P[0][0].x - shift_magic.x; // the level shift is exactly "raw DC minus 64 * 128"
+    karg_pairs_t tq = (karg_pairs_t)(tbp + offsetof(OwnTables, qf)) + j * 8, td = (karg_pairs_t)(tbp + offsetof(OwnTables, dq)) + j * 8;
+    asm volatile("" : "+s"(tq), "+s"(td)); // two s_load_dwordx16 per j, right where they are used (i16_roundtrip_rows)
+#pragma unroll
+    for (int v = 0; v < 8; v++)
+    {
+      const f32x2 qf = tq[v], dq = td[v];
+      f32x2 m;
+      MDCT_PKM(m, P[j][v], qf, MDCT_K_LH);
+      if constexpr (SAT)
+      {
+        m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
+        m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
+      }
+      MDCT_PKA(m, m, K.magic, MDCT_K_LL);
+      MDCT_PKA(m, m, K.magic, MDCT_K_LL " " MDCT_NEG_B);
+      MDCT_PKM(P[j][v], m, dq, MDCT_K_LH);
+    }
+    aan_inv_v(K, P[j]);
+  }
+  MDCT_PHASE_PRIO(3);
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+  {
+    f32x2 o07, o16, o25, o43;
+    aan_inv_h(K, P[0][r], P[1][r], P[2][r], P[3][r], o07, o16, o25, o43);
+    auto fin = [&](f32x2 v) {
+      f32x2 t;
+      if constexpr (FIN == FIN_CLAMP)
+      { // so that rne(x) + shift lands in [0, 255]
+        v.x = __builtin_amdgcn_fmed3f(v.x, lo_hi.x, lo_hi.y);
+        v.y = __builtin_amdgcn_fmed3f(v.y, lo_hi.x, lo_hi.y);
+      }
+      MDCT_PKAK(t, v, shift_magic, MDCT_K_HH);
+      return t;
+    };
+    const f32x2 b07 = fin(o07), b16 = fin(o16), b25 = fin(o25), b43 = fin(o43);
+    uint32_t w0, w1;
+    if constexpr (FIN == FIN_SATPK)
+    { // (x1:x0) (x3:x2) (x5:x4) (x7:x6) as int16 pairs -> saturated byte pairs -> two dwords
+      const uint32_t p10 = sat_pk_u8_i16(pack_lo16(__float_as_uint(b07.x), __float_as_uint(b16.x))), p32 = sat_pk_u8_i16(pack_lo16(__float_as_uint(b25.x), __float_as_uint(b43.y)));
+      const uint32_t p54 = sat_pk_u8_i16(pack_lo16(__float_as_uint(b43.x), __float_as_uint(b25.y))), p76 = sat_pk_u8_i16(pack_lo16(__float_as_uint(b16.y), __float_as_uint(b07.y)));
+      w0 = pack_lo16(p10, p32);
+      w1 = pack_lo16(p54, p76);
+    }
+    else
+    {
+      w0 = pack4_lo8(__float_as_uint(b07.x), __float_as_uint(b16.x), __float_as_uint(b25.x), __float_as_uint(b43.y));
+      w1 = pack4_lo8(__float_as_uint(b43.x), __float_as_uint(b25.y), __float_as_uint(b16.y), __float_as_uint(b07.y));
+    }
+    const u32x2_unaligned_g w = {w0, w1};
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x2_unaligned_g __attribute__((address_space(1))) *>(sgpr_ptr(dst + (size_t)r * pitch_out) + lane_off));
+  }
+}
+
+#ifndef MDCT_U8B_WAVES
+#define MDCT_U8B_WAVES 3
+#endif
+#ifndef MDCT_U8B_WAVES_SMALL
+#define MDCT_U8B_WAVES_SMALL 4
+#endif
+// GENERAL = false: every plane's table is tame (mdct_api.hip: u8_table_is_tame): no saturations, FIN_SATPK
+template <bool GENERAL, bool SMALL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT_U8B_WAVES_SMALL : MDCT_U8B_WAVES, SMALL ? MDCT_U8B_WAVES_SMALL : MDCT_U8B_WAVES))) void k_u8_batch(BatchArgs a)
+{
+  const BatchTile t = batch_tile(blockIdx.x);
+  if (t.tile * 64 + threadIdx.x >= t.bpr())
+    return;
+  const size_t pin = t.pitch_in(), pout = t.pitch_out();
+  const f32x2 shift_magic = {a.px[0], a.px[1]}, lo_hi = {a.px[2], a.px[3]};
+  u8_roundtrip_rows<GENERAL, GENERAL ? FIN_CLAMP : FIN_SATPK, true>(a.consts, shift_magic, lo_hi, (const uint8_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.tile * 512,
+                                                                     (uint8_t *)t.to() + (size_t)t.row * 8 * pout + (size_t)t.tile * 512, pin, pout, threadIdx.x * 8, t.tables);
 }
 
 // 8-bit pixels <-> int16 coefficients (JPEG-style pair): u8 rows are 8 B per lane (512 B per wave
@@ -2209,6 +2327,26 @@ hipError_t launch_i16_batch(const BatchArgs &a, uint32_t total, int mode, int lu
   if (total == 0)
     return hipSuccess;
   return total > 2048 && total <= kTileSmallLaunch ? launch_i16_batch_w<true>(a, total, mode, lutmode, sat, s) : launch_i16_batch_w<false>(a, total, mode, lutmode, sat, s);
+}
+
+hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, bool general, hipStream_t s)
+{
+  if (total == 0)
+    return hipSuccess;
+  const dim3 g(total), b(64);
+  const bool small = total > 2048 && total <= kTileSmallLaunch;
+  if (general)
+  {
+    if (small)
+      hipLaunchKernelGGL((k_u8_batch<true, true>), g, b, 0, s, a);
+    else
+      hipLaunchKernelGGL((k_u8_batch<true, false>), g, b, 0, s, a);
+  }
+  else if (small)
+    hipLaunchKernelGGL((k_u8_batch<false, true>), g, b, 0, s, a);
+  else
+    hipLaunchKernelGGL((k_u8_batch<false, false>), g, b, 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s)

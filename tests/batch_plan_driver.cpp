@@ -164,17 +164,41 @@ int main()
       }
     }
   }
-  { // the grid limit: planes are taken while the launch stays below 2^31 tiles; one plane beyond it is refused
-    auto planes = make_planes({{8 * 64 * 40000, 8 * 30000}, {8 * 64 * 40000, 8 * 30000}, {8 * 64 * 70000, 8 * 40000}});
+  { // the grid limit (kBatchMaxTiles = 2^26 - 1: 64-thread tiles, < 2^32 threads per launch): planes are taken while the launch stays
+    // below it; one plane beyond it is refused
+    static_assert(kBatchMaxTiles == 67108863u, "2^26 - 1");
+    auto planes = make_planes({{8 * 64 * 4000, 8 * 10000}, {8 * 64 * 4000, 8 * 10000}, {8 * 64 * 7000, 8 * 10000}});
     const int ids[] = {0, 0, 0};
     const unsigned char has[] = {1, 1, 1};
     BatchLayout lay;
     batch_layout(planes.data(), ids, has, 0, 3, 0, 512, lay);
-    CHECK(lay.consumed == 1 && lay.total == 1200000000u);
+    CHECK(lay.consumed == 1 && lay.total == 40000000u);
     batch_layout(planes.data(), ids, has, 1, 3, 0, 512, lay);
     CHECK(lay.consumed == 1);
     batch_layout(planes.data(), ids, has, 2, 3, 0, 512, lay);
     CHECK(lay.consumed == 0 && lay.descs.empty());
+    // exactly at the limit is taken, one tile more is not
+    auto edge = make_planes({{8 * 64 * 8191, 8 * 8193}, {8 * 64, 8 * 1}});
+    CHECK(8191ull * 8193ull == 67108863ull);
+    batch_layout(edge.data(), ids, has, 0, 2, 0, 512, lay);
+    CHECK(lay.consumed == 1 && lay.total == kBatchMaxTiles);
+  }
+  { // 8-bit planes lay out through the same template (pitches are the plane's own unit: bytes)
+    std::vector<mdct_plane_u8> planes(3);
+    const size_t w[3] = {7680, 3840, 3840}, h[3] = {4320, 2160, 2160};
+    for (int i = 0; i < 3; i++)
+      planes[i] = mdct_plane_u8{reinterpret_cast<const uint8_t *>((uintptr_t)0x1000 * (i + 1)), reinterpret_cast<uint8_t *>((uintptr_t)0x100000 * (i + 1)), w[i] + 16, w[i], w[i], h[i], nullptr};
+    const int ids[] = {0, 1, 1};
+    const unsigned char has[] = {1, 1, 1};
+    BatchLayout lay;
+    batch_layout(planes.data(), ids, has, 0, 3, 3584, 512, lay);
+    CHECK(lay.consumed == 3 && lay.descs.size() == 3 && lay.tables.size() == 2 && lay.total == 15u * 540 + 2 * 8u * 270);
+    CHECK(lay.descs[0].pitch_in == 7696 && lay.descs[1].first == 8100 && lay.descs[2].first == 8100 + 2160 && lay.descs[2].table == 512);
+    for (uint32_t w0 : {0u, 8099u, 8100u, 10259u, 10260u, 12419u})
+    {
+      const BatchWhere at = batch_locate(lay.descs.data(), 3, lay.uniform, lay.pp, lay.first8, w0);
+      CHECK(at.p == (w0 < 8100 ? 0u : (w0 < 10260 ? 1u : 2u)) && at.tile < lay.descs[at.p].tiles && at.row < lay.descs[at.p].rows);
+    }
   }
   puts("batch plan ok");
   return 0;

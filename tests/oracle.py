@@ -38,6 +38,7 @@ def oracle():
             getattr(lib, n).argtypes = [vp, vp, sz, sz, f32p, sz, sz, sz, sz]
         for n in ("orc_fwd_u8_i16", "orc_inv_i16_u8"):
             getattr(lib, n).argtypes = [vp, vp, sz, sz, f32p, ctypes.c_int, sz, sz, sz, sz]
+        lib.orc_roundtrip_u8.argtypes = [vp, vp, sz, sz, f32p, ctypes.c_int, sz, sz, sz, sz]
         for n in ("orc_fwd_f32", "orc_inv_f32", "orc_fwd_f64ref"):
             getattr(lib, n).argtypes = [vp, vp, sz, sz, sz, sz, sz, sz]
         lib.orc_zigzag_table.argtypes = [vp]
@@ -168,6 +169,25 @@ def u8_i16(mode, src, W, H, lut=None, level_shift=True):
         out = np.zeros((H, W), dtype=np.uint8)
         rc = oracle().orc_inv_i16_u8(src.ctypes.data, out.ctypes.data, W, W, lp, int(level_shift), W, H, 0, H // 8)
     assert rc == 0, rc
+    return out
+
+
+def roundtrip_u8(src, W, H, lut=None, level_shift=True, by0=0, by1=None, pitch_in=None, pitch_out=None, out=None, threads=1):
+    """uint8 [H, pitch_in] -> uint8 [H, pitch_out]: the fused 8-bit round trip (== u8_i16('inv', u8_i16('fwd', ..)), tested);
+    threads > 1: block-row stripes on host threads (whole large planes)"""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    pin = W if pitch_in is None else pitch_in
+    pout = W if pitch_out is None else pitch_out
+    out = np.zeros((H, pout), dtype=np.uint8) if out is None else out
+    lp = None
+    if lut is not None:
+        keep, lp = _lut(lut)
+    by1 = H // 8 if by1 is None else by1
+    if threads > 1:
+        _par_rows(lambda a, b: oracle().orc_roundtrip_u8(src.ctypes.data, out.ctypes.data, pin, pout, lp, int(level_shift), W, H, by0 + a, by0 + b), by1 - by0, threads)
+    else:
+        rc = oracle().orc_roundtrip_u8(src.ctypes.data, out.ctypes.data, pin, pout, lp, int(level_shift), W, H, by0, by1)
+        assert rc == 0, rc
     return out
 
 

@@ -35,12 +35,18 @@ def test_batch_layout_and_index_arithmetic_under_sanitizers(tmp_path):
 
 
 def test_kernel_and_host_share_the_layout_header():
-    """the kernel's plane lookup is the arithmetic the CPU test walked: one header, no second copy of the descriptor"""
+    """the kernels' plane lookup IS the arithmetic the CPU test walked: one header, no second copy of the descriptor, and the batch kernels
+    call batch_plan.h's batch_plane_of / magic_apply instead of restating them"""
     k = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "mdct_kernels.h")).read()
     assert '#include "batch_plan.h"' in k and "struct BatchDesc" not in k
     hdr = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "batch_plan.h")).read()
     code = "\n".join(l.split("//")[0] for l in hdr.splitlines())
-    assert "hip" not in code.lower()  # builds with plain g++
+    assert "#include <hip" not in code and "hipError" not in code  # builds with plain g++ (the sanitizer test above does)
+    assert "MDCT_HD uint32_t batch_plane_of(" in hdr and "MDCT_HD uint32_t magic_apply(" in hdr
+    kern = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "mdct_kernels.hip")).read()
+    assert "batch_plane_of(w, n, uniform" in kern and kern.count("magic_apply(") >= 1
+    assert "magic_quot" not in kern and "__umulhi" not in kern  # no device-side restatement of the division or of the search
+    assert kern.count("batch_tile(blockIdx.x)") == 2  # k_i16_batch and k_u8_batch
     api_src = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "mdct_api.hip")).read()
     assert "mdct::batch_layout(" in api_src
 
