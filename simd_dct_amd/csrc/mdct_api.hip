@@ -664,7 +664,8 @@ static int fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_
     // scalar tiers (mdct_kernels.hip: encode_block_pk): nm.y = the bias 127/255 of :245 / :362, bias = (255, 0.5 - 2^-25)
     a.pk = mdct::PkConstsArg{{c.a, c.f}, {c.c, c.d}, {c.b, c.e}, {c.n, scalar ? 127.0f / 255.0f : (q32 ? c.magic23 + 128.0f : c.magic23)},
                              {c.d, c.a}, {c.f, c.d}, {c.f, c.c}, {c.c, c.a},
-                             {scalar ? 255.0f : 1.f / (float)0xFF, scalar ? nextafterf(0.5f, 0.0f) : 127.0f}};
+                             {scalar ? 255.0f : 1.f / (float)0xFF, scalar ? nextafterf(0.5f, 0.0f) : 127.0f},
+                             {1.f / 255.f, (float)(1.0 / 255.0 - (double)(1.f / 255.f))}}; // (c, c2): 0x3b808081, 0xaf7efeff
   }
   a.pitch = pitch_in;
   a.sizeX = sizeX;

@@ -63,6 +63,7 @@ struct PkConstsArg
   float af[2], cd[2], be[2], nm[2];
   float da[2], fd[2], fc[2], ca[2]; // scalar tiers (K_TRUE): (Cd,Ca) (Cf,Cd) (Cf,Cc) (Cc,Ca)
   float bias[2];                    // SSE tiers: (1/255, 127.0f); scalar tiers: (255.0f, pred(0.5)), with nm = (Cn, 127/255)
+  float div[2];                     // scalar tiers: (rn(1/255), rn(1/255 - rn(1/255))): px / 255.f without the division (mdct_kernels.hip)
 };
 
 struct U8Args

@@ -151,6 +151,7 @@ struct PkConsts
   f32x2 af, cd, be, nm; // (Ca,Cf) (Cc,Cd) (Cb,Ce) (Cn, rounding constant)
   f32x2 da, fd, fc, ca; // K_TRUE only: (Cd,Ca) (Cf,Cd) (Cf,Cc) (Cc,Ca)
   f32x2 bias;           // SSE tiers: (1/255, 127.0f);  scalar tiers: (255.0f, pred(0.5)) and nm = (Cn, 127/255)
+  f32x2 div;            // scalar tiers: (c, c2) = (rn(1/255), rn(1/255 - c)), see encode_block_pk
 };
 static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernels.h) is the kernel-argument image of PkConsts");
 
@@ -458,21 +459,14 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
   }
 }
 
-// Scalar tiers: the table of the 256 quotients px / 255.f lives in LDS and every lane looks up 64 of them.  With ONE copy of the
-// table a wave's 64 lookups of one instruction hit random entries, i.e. random banks: 3.6 conflict cycles per active LDS cycle
-// (profiles/r03_pmc_raw.txt), and the BLOCK layout's kernel stayed at 37 us when its vector work fell from 962 to 738 instructions.
-// kDivTabCopies = 32: entry e of copy k at dword e * 32 + k -- lane l reads copy l & 31, so the 32 lanes an LDS cycle serves sit in 32
-// different banks whatever they look up.  32 KiB per workgroup; the STEREO layout (17 KiB of output staging besides) keeps one copy.
 #ifndef MDCT_BLOCK_STAGE
 #define MDCT_BLOCK_STAGE 1
 #endif
-#ifndef MDCT_DIVTAB_COPIES_BLOCK
-#define MDCT_DIVTAB_COPIES_BLOCK 1
-#endif
-#ifndef MDCT_DIVTAB_COPIES_STEREO
-#define MDCT_DIVTAB_COPIES_STEREO 1
-#endif
-constexpr int kDivTabCopies(int layout) { return layout == MDCT_LAYOUT_BLOCK ? MDCT_DIVTAB_COPIES_BLOCK : MDCT_DIVTAB_COPIES_STEREO; }
+// Scalar tiers: the reference divides every pixel by 255 (`px / 255.f`, simd_dct.cpp:222, :343).  For a byte x the correctly rounded
+// quotient is, bit for bit,  fma(x, c, rn(x * c2))  with c = rn(1/255) and c2 = rn(1/255 - c): checked for all 256 values in exact
+// rational arithmetic (tools/check_div255_forms.py, tests/test_div255_forms.py; plain x * c is wrong for 126 of them).  Two packed
+// operations per pixel pair.  Rounds 2-4 kept the 256 quotients in an LDS table per workgroup: 64 random ds_read_b32 per lane, ~3
+// bank-conflict cycles per LDS cycle (profiles/r04_pmc_raw.txt), a barrier, and LDS that capped the occupancy.
 // B2..B5 on packed fp32.  The first pass runs "horizontally" over the 8 lines of the block (rows for the
 // encq tiers, :347-358 / :1608-1636; columns for the stereo tiers, which transpose first, :961-1004 /
 // :225-241), leaving the pairs (0,4)(2,6)(1,3)(5,7) of first-pass coefficients side by side; the second
@@ -481,7 +475,7 @@ constexpr int kDivTabCopies(int layout) { return layout == MDCT_LAYOUT_BLOCK ? M
 // first*8 + second: u*8+v for the encq tiers (:362, :1651), v*8+u for the stereo tiers.  `qt` holds the
 // multipliers in that pair order, (m*4+j)*2 + {0,1} (mdct_api.hip).  Same bits as encode_block.
 template <int PROFILE, int LAYOUT, bool SAFE>
-__device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (&rows)[8], const QuantTable &qt, const float *px_div255, uint32_t (&out)[64])
+__device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (&rows)[8], const QuantTable &qt, uint32_t (&out)[64])
 {
   constexpr int K1D = PROFILE == MDCT_PROFILE_REF_SSE ? K_SSE : K_TRUE;
   constexpr bool COLS_FIRST = LAYOUT == MDCT_LAYOUT_STEREO;
@@ -489,20 +483,7 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
   auto px = [&](auto r_, auto c_) {
     constexpr int r = decltype(r_)::value, c = decltype(c_)::value;
     const uint32_t w = c < 4 ? rows[r].x : rows[r].y;
-    if constexpr (PROFILE == MDCT_PROFILE_REF_SCALAR)
-    { // px / 255.f (:222, :343), one of 256 values (see kernel)
-      if constexpr (kDivTabCopies(LAYOUT) == 1)
-        return px_div255[(w >> (8 * (c & 3))) & 0xFF];
-      else
-      { // entry e of the lane's own copy at byte (e << 7) + (lane & 31) * 4: a shift that lands byte c's bits on bits 7..14, then one
-        // v_and_or with the lane's offset (px_div255 arrives already offset by the lane)
-        constexpr int sh = 8 * (c & 3) - 7;
-        const uint32_t moved = sh < 0 ? w << 7 : w >> sh;
-        return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(px_div255) + (moved & 0x7F80u));
-      }
-    }
-    else
-      return ubyte_to_float<(c & 3)>(w);
+    return ubyte_to_float<(c & 3)>(w);
   };
   f32x2 P[4][8];
   auto line = [&](auto i_) {
@@ -521,6 +502,18 @@ __device__ __forceinline__ void encode_block_pk(const PkConsts &K, const uint2 (
     if constexpr (PROFILE == MDCT_PROFILE_REF_SSE)
     { // px * (1.0f / 255.0f), :949
       a01 = a01 * K.bias.xx; a23 = a23 * K.bias.xx; a45 = a45 * K.bias.xx; a67 = a67 * K.bias.xx;
+    }
+    else
+    { // px / 255.f, :222 / :343: q = fma(x, c, rn(x * c2)) on both halves (see above)
+      auto div255 = [&](f32x2 x) {
+        f32x2 q;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+            "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+            : "=&v"(q)
+            : "v"(x), "s"(K.div));
+        return q;
+      };
+      a01 = div255(a01); a23 = div255(a23); a45 = div255(a45); a67 = div255(a67);
     }
     dct8_h<K1D>(K, a01, a23, a45, a67, P[0][i], P[1][i], P[2][i], P[3][i]);
   };
@@ -775,8 +768,10 @@ __global__ __launch_bounds__(64, MDCT_Q32_MINW) void k_q32_tile(U8Args a)
 #else
 // (round 4, tiled kernels, profiles/r04_exp_scalar_waves.log: stereo/SSE 31.9-32.0 us steered to 3 against 33.9 unsteered, 33.4 at 5, 47.6 at 6;
 // stereo/scalar 35.5 at 4 or 5, 37-38 at 3, 46 at 6; encq/scalar 31.4-31.8 unsteered, 32.3-33.6 steered)
-constexpr int u8_waves_lo(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 4 : (layout == MDCT_LAYOUT_STEREO ? (profile == MDCT_PROFILE_REF_SCALAR ? 4 : 3) : 1); }
-constexpr int u8_waves_hi(int profile, int layout) { return layout == MDCT_LAYOUT_BLOCK_SSE ? 4 : (layout == MDCT_LAYOUT_STEREO ? (profile == MDCT_PROFILE_REF_SCALAR ? 4 : 3) : 8); }
+// (round 5, the scalar tiers without their LDS quotient table, profiles/r05_exp_u8_tier_waves.log: encq/scalar 32.6 us unsteered (74 VGPRs: 6 waves),
+// 31.0 at 3, 30.6 at 4, 31.2 at 5; stereo/scalar 30.6-30.9 at 4, 31.7 at 3, 31.3 at 5)
+constexpr int u8_waves_lo(int profile, int layout) { return layout == MDCT_LAYOUT_STEREO ? (profile == MDCT_PROFILE_REF_SCALAR ? 4 : 3) : 4; }
+constexpr int u8_waves_hi(int profile, int layout) { return u8_waves_lo(profile, layout); }
 #define MDCT_U8_ATTR __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(u8_waves_lo(PROFILE, LAYOUT), u8_waves_hi(PROFILE, LAYOUT))))
 #endif
 // TILED: 2-D grid for launches whose workgroups each lie in one row of blocks (sizeX % 2048 == 0): blockIdx.y = row of
@@ -809,33 +804,6 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
   else
     by = a.by0 + row;
 
-  // scalar tiers: the 256 possible values of px / 255.f, each computed ONCE per workgroup with
-  // the same IEEE division the reference performs per pixel (one thread per value, kWG == 256)
-  const float *px_div255 = nullptr;
-  if constexpr (PROFILE == MDCT_PROFILE_REF_SCALAR)
-  {
-    static_assert(kWG == 256, "one table entry per thread");
-    constexpr int COPIES = kDivTabCopies(LAYOUT);
-    static_assert(COPIES == 1 || COPIES == 32, "one copy, or one per lane of a half wave");
-    __shared__ __attribute__((aligned(16))) float div_tab[256 * COPIES];
-    const float quot = (float)threadIdx.x / 255.f;
-    if constexpr (COPIES == 1)
-    {
-      div_tab[threadIdx.x] = quot;
-      px_div255 = div_tab;
-    }
-    else
-    {
-      typedef float f32x4_l __attribute__((ext_vector_type(4)));
-      const f32x4_l q4 = {quot, quot, quot, quot};
-#pragma unroll
-      for (int k = 0; k < COPIES / 4; k++)
-        reinterpret_cast<f32x4_l *>(div_tab + threadIdx.x * COPIES)[k] = q4;
-      px_div255 = div_tab + (threadIdx.x & 31);
-    }
-    wg_sync();
-  }
-
   uint32_t q[64];
   if (valid)
   {
@@ -855,7 +823,7 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
         src += (size_t)eye * a.eye_offset;
       load_block_rows(src, a.pitch, rows);
     }
-    encode_block_pk<PROFILE, LAYOUT, SAFE>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, px_div255, q);
+    encode_block_pk<PROFILE, LAYOUT, SAFE>(reinterpret_cast<const PkConsts &>(a.pk), rows, a.qt, q);
   }
 
   if constexpr (LAYOUT == MDCT_LAYOUT_STEREO)
@@ -1582,10 +1550,13 @@ __device__ __forceinline__ void u8_roundtrip_rows(const DctConsts &C, const f32x
 }
 
 #ifndef MDCT_U8B_WAVES
-#define MDCT_U8B_WAVES 3
+#define MDCT_U8B_WAVES 4 // measured 2..6 on the 8K 4:2:0 frame: 27.2 / 26.2 / 25.6 / 25.9 / 25.7 us (profiles/r05_exp_u8_waves.log): bound by vector issue, not occupancy
 #endif
 #ifndef MDCT_U8B_WAVES_SMALL
 #define MDCT_U8B_WAVES_SMALL 4
+#endif
+#ifndef MDCT_U8B_PRIO
+#define MDCT_U8B_PRIO true
 #endif
 // GENERAL = false: every plane's table is tame (mdct_api.hip: u8_table_is_tame): no saturations, FIN_SATPK
 template <bool GENERAL, bool SMALL>
@@ -1596,7 +1567,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT
     return;
   const size_t pin = t.pitch_in(), pout = t.pitch_out();
   const f32x2 shift_magic = {a.px[0], a.px[1]}, lo_hi = {a.px[2], a.px[3]};
-  u8_roundtrip_rows<GENERAL, GENERAL ? FIN_CLAMP : FIN_SATPK, true>(a.consts, shift_magic, lo_hi, (const uint8_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.tile * 512,
+  u8_roundtrip_rows<GENERAL, GENERAL ? FIN_CLAMP : FIN_SATPK, MDCT_U8B_PRIO>(a.consts, shift_magic, lo_hi, (const uint8_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.tile * 512,
                                                                      (uint8_t *)t.to() + (size_t)t.row * 8 * pout + (size_t)t.tile * 512, pin, pout, threadIdx.x * 8, t.tables);
 }
 
