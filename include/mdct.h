@@ -112,11 +112,14 @@ int mdct_fwd_quant_u8_pitched(const uint8_t *from, uint8_t *to, size_t pitch_in,
  *   roundtrip: fwd -> (quantise -> dequantise when lut) -> inv, fused, one pass over HBM;
  *              without a table it returns the input bit-exactly.
  * Rows must be 16-byte aligned (pitch*sizeof(elem) % 16 == 0, base 16-byte aligned).
- * Tables: the FIRST call that sees a table (per device, per distinct content) parks its multipliers in device memory
- * with one blocking 512-byte copy -- the kernel argument segment is cold in every cache on every launch, device memory
- * is not; later calls with that table find it there (up to 256 tables per device, never evicted).  A table first seen
- * while `stream` is capturing, or beyond the 256, travels in the kernel arguments instead: same results, and nothing is
- * allocated, copied or synchronised inside a capture. */
+ * Tables: a table's multipliers are parked in device memory, where they stay hot in L2 across launches (the kernel argument
+ * segment is cold in every cache on every launch).  First sight of a table (per device, per distinct content) enqueues a one-wave
+ * upload kernel on `stream` right before the launch -- asynchronous and stream-ordered like the launch itself: no host block, no
+ * synchronisation, no staging buffer.  Up to 256 tables per device stay resident, the least recently used one is evicted (its upload
+ * waits, on the device, for the launches that still read the old content; other streams that meet a table whose upload is in flight
+ * wait for it with hipStreamWaitEvent).  While `stream` is capturing, tables travel in the kernel arguments and the cache is not
+ * touched -- a replayed graph must not depend on what a slot holds later: same results, nothing allocated, copied or synchronised
+ * inside a capture.  mdct_table_cache_stats (below) counts what happened. */
 int mdct_fwd_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
                  size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
 int mdct_inv_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut,
@@ -346,6 +349,19 @@ int mdct_allgather_rows(mdct_comm *comm, void *buf, size_t row_bytes, size_t n_r
 /* Stereo coefficient-planar output of a sizeX x sizeY call sharded by mdct_shard_rows(sizeY / 16, ...):
  * 64 strided pieces per rank, gathered as 64 collectives inside one RCCL group. */
 int mdct_allgather_stereo(mdct_comm *comm, uint8_t *buf, size_t sizeX, size_t sizeY, void *stream);
+
+/* Diagnostics of the calling thread's current device's table cache (see "Tables" above), cumulative since the process started;
+ * writes min(n, MDCT_TABLE_STAT_COUNT) counters (host function, no device work). */
+enum
+{
+  MDCT_TABLE_STAT_HITS = 0,           /* launches that found their table resident */
+  MDCT_TABLE_STAT_UPLOADS = 1,        /* first sights: upload kernel enqueued on the caller's stream */
+  MDCT_TABLE_STAT_EVICTIONS = 2,      /* uploads that replaced the least recently used table */
+  MDCT_TABLE_STAT_FROM_ARGUMENTS = 3, /* tables that travelled in the kernel arguments instead (capturing stream, no free slot, failure) */
+  MDCT_TABLE_STAT_STREAM_WAITS = 4,   /* hipStreamWaitEvent on another stream's upload still in flight */
+  MDCT_TABLE_STAT_COUNT = 5
+};
+int mdct_table_cache_stats(uint64_t *stats, int n);
 
 /* Measured-roofline helper for bench tools: a read-N/write-N 16 B/lane stream copy on
  * the same stream (what "HBM roofline" means on this box). */

@@ -566,6 +566,13 @@ def prepare_roundtrip_u8(src, dst, sizeX, sizeY, lut=None, level_shift=True, str
     return Prepared(_lib.load().mdct_roundtrip_u8, args, (keep, src, dst))
 
 
+def table_cache_stats():
+    """mdct_table_cache_stats of the current device: dict of the MDCT_TABLE_STAT_* counters"""
+    a = (ctypes.c_uint64 * 5)()
+    _check(_lib.load().mdct_table_cache_stats(a, 5))
+    return dict(zip(("hits", "uploads", "evictions", "from_arguments", "stream_waits"), [int(v) for v in a]))
+
+
 def prepare_stream_copy(src, dst, nbytes, stream=None):
     lib = _lib.load()
     return Prepared(lib.mdct_stream_copy, (ctypes.c_void_p(_ptr(src)), ctypes.c_void_p(_ptr(dst)), ctypes.c_size_t(nbytes), _stream(stream)), (src, dst))

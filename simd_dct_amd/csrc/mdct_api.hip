@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include "mdct.h"
@@ -201,19 +202,47 @@ static bool lut_bounded(const float *lut)
 // ---- table cache: quantiser tables parked in device memory -------------------------------------------------------
 // A kernel's argument segment is written afresh by the host for every launch, so tables passed by value are cold in every
 // cache each time; the same 512 bytes in device memory stay hot in L2 across launches (8192^2 round trip with a table: 46.4 ->
-// 44.8 us, the 8K 4:2:0 frame 36.9-38.0 -> 35.7).  Per device: kTableSlots immutable slots, filled on first sight of a table
-// (one blocking 512-byte copy, once per distinct table and order), never evicted -- a slot may be referenced by launches in
-// flight on any stream and by captured graphs for as long as the process lives.  When a table cannot be parked (first seen
-// while the stream is capturing, cache full, allocation failed) the caller falls back to the tables in its arguments: the
-// results are identical either way.
+// 44.8 us, the 8K 4:2:0 frame 36.9-38.0 -> 35.7).  Round 5: everything about the cache is asynchronous and stream-ordered --
+//   first sight   a one-wave upload kernel carries the 512 bytes in ITS argument segment and writes them into a slot, enqueued on the
+//                 caller's stream right before the launch that reads the slot: no host block, no staging buffer whose lifetime
+//                 anybody has to track (round 4 did a blocking hipMemcpy here)
+//   another stream meets a slot whose upload has not finished: hipStreamWaitEvent on the slot's `ready` event
+//   capacity      kTableSlots per device, least recently used evicted.  A hit costs no HIP call at all: a slot only remembers WHICH streams
+//                 have read it since its upload (table_release).  The evicting upload fences them when it happens: an event recorded
+//                 on each of those streams there and then -- behind everything they have queued, the readers included -- which the
+//                 uploading stream waits for on the device.  (Round 5's first cut left an event behind every launch instead: the
+//                 marker between back-to-back kernels cost a 3840x2160 plane 8 -> 17 us.)  A stream that cannot be fenced any more
+//                 (destroyed with work in flight) keeps its slots from being victims; so does a call between acquire and release.
+//   capture       a capturing stream never touches the cache, not even for a table that is parked: a replayed graph would read the
+//                 slot at any later time, after any number of evictions.  Its tables travel in the kernel arguments (same results).
+// When nothing can be parked (capture, allocation failure, every slot held) the caller works from its arguments.
 constexpr int kTableSlots = 256;
+constexpr int kSlotStreams = 4; // reader streams remembered per slot; a slot read by more is fenced against every stream the cache has seen
+constexpr int kKnownStreams = 64;
+struct TableSlot
+{
+  mdct::OwnTables host;        // what the slot holds
+  uint64_t hash = 0, tick = 0; // tick: last acquire (LRU)
+  int pins = 0;                // acquired, not yet released
+  bool used = false, ready_done = false;
+  hipStream_t ready_stream = nullptr;
+  hipEvent_t ready = nullptr;  // recorded behind the upload kernel
+  hipStream_t readers[kSlotStreams] = {};
+  int n_readers = 0;           // kSlotStreams + 1: more than that
+};
 struct TableCache
 {
   std::mutex mu;
   mdct::OwnTables *dev = nullptr;
   bool failed = false;
-  std::vector<mdct::OwnTables> host; // what each filled slot holds
-  std::vector<uint64_t> hash;        // ... and a hash of it: the lookup compares 8 bytes per slot, then one table
+  uint64_t tick = 0;
+  std::vector<TableSlot> slots;
+  std::unordered_multimap<uint64_t, int> index; // content hash -> slot
+  hipStream_t known[kKnownStreams] = {};        // every stream that has read a parked table (for slots with many readers)
+  int n_known = 0;
+  bool known_overflow = false;
+  hipEvent_t fence = nullptr;                   // re-recorded for every fence: hipStreamWaitEvent takes the event's state at the call
+  uint64_t stat[MDCT_TABLE_STAT_COUNT] = {};
 };
 
 uint64_t table_hash(const mdct::OwnTables &tb)
@@ -238,35 +267,205 @@ bool stream_is_capturing(hipStream_t s)
   return st != hipStreamCaptureStatusNone;
 }
 
-// device address of `tb` in the cache of `device`, or nullptr
-const mdct::OwnTables *parked_tables(int device, const mdct::OwnTables &tb, hipStream_t stream)
+// allocation and event creation must not disturb a capture another thread has open in global mode
+struct RelaxedCaptureMode
+{
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  RelaxedCaptureMode() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+  ~RelaxedCaptureMode() { (void)hipThreadExchangeStreamCaptureMode(&mode); }
+};
+
+bool make_event(hipEvent_t *ev)
+{
+  if (*ev)
+    return true;
+  RelaxedCaptureMode relaxed;
+  if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess)
+  {
+    (void)hipGetLastError();
+    *ev = nullptr;
+    return false;
+  }
+  return true;
+}
+
+struct TableRef
+{ // a parked table held by a call between table_acquire and table_release; dev == nullptr: not parked, read the kernel arguments
+  int device = -1, slot = -1;
+  const mdct::OwnTables *dev = nullptr;
+};
+
+// `stream` must wait (on the device) for everything that still reads or writes the slot: its upload, and the launches of other
+// streams that read it -- fenced by an event recorded on each such stream now.  false: some reader cannot be fenced, not a victim.
+bool slot_quiesce_for(TableCache &c, TableSlot &sl, hipStream_t stream)
+{
+  if (!sl.used)
+    return true;
+  if (!sl.ready_done && sl.ready_stream != stream && hipStreamWaitEvent(stream, sl.ready, 0) != hipSuccess)
+    return false;
+  const bool many = sl.n_readers > kSlotStreams;
+  if (many && c.known_overflow)
+    return false;
+  const hipStream_t *set = many ? c.known : sl.readers;
+  const int n = many ? c.n_known : sl.n_readers;
+  for (int i = 0; i < n; i++)
+  {
+    if (set[i] == stream)
+      continue; // in order on the stream itself
+    if (!make_event(&c.fence) || hipEventRecord(c.fence, set[i]) != hipSuccess || hipStreamWaitEvent(stream, c.fence, 0) != hipSuccess)
+      return false; // (a stream destroyed with work in flight cannot be fenced)
+  }
+  return true;
+}
+
+TableRef table_acquire(int device, const mdct::OwnTables &tb, hipStream_t stream)
 {
   TableCache &c = g_tables[device];
   std::lock_guard<std::mutex> lk(c.mu);
-  const uint64_t h = table_hash(tb);
-  for (size_t k = 0; k < c.host.size(); k++)
-    if (c.hash[k] == h && memcmp(&c.host[k], &tb, sizeof(tb)) == 0)
-      return c.dev + k;
-  if (c.failed || c.host.size() >= (size_t)kTableSlots || stream_is_capturing(stream))
-    return nullptr;
-  // allocation and copy must not disturb a capture another thread has open in global mode
-  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
-  (void)hipThreadExchangeStreamCaptureMode(&mode);
-  hipError_t e = hipSuccess;
-  if (!c.dev)
-    e = hipMalloc(reinterpret_cast<void **>(&c.dev), kTableSlots * sizeof(mdct::OwnTables));
-  if (e == hipSuccess)
-    e = hipMemcpy(c.dev + c.host.size(), &tb, sizeof(tb), hipMemcpyHostToDevice);
-  (void)hipThreadExchangeStreamCaptureMode(&mode);
-  if (e != hipSuccess)
+  if (c.failed)
+    return TableRef();
+  if (stream_is_capturing(stream))
   {
-    (void)hipGetLastError();
-    c.failed = true; // keep working from the arguments
-    return nullptr;
+    c.stat[MDCT_TABLE_STAT_FROM_ARGUMENTS]++;
+    return TableRef();
   }
-  c.host.push_back(tb);
-  c.hash.push_back(h);
-  return c.dev + (c.host.size() - 1);
+  const uint64_t h = table_hash(tb);
+  const auto range = c.index.equal_range(h);
+  for (auto it = range.first; it != range.second; ++it)
+  {
+    TableSlot &sl = c.slots[it->second];
+    if (memcmp(&sl.host, &tb, sizeof(tb)) != 0)
+      continue;
+    if (!sl.ready_done && sl.ready_stream != stream)
+    { // uploaded on another stream: done by now, or this stream waits for it (on the device)
+      if (hipEventQuery(sl.ready) == hipSuccess)
+        sl.ready_done = true;
+      else
+      {
+        (void)hipGetLastError();
+        if (hipStreamWaitEvent(stream, sl.ready, 0) != hipSuccess)
+        {
+          (void)hipGetLastError();
+          c.stat[MDCT_TABLE_STAT_FROM_ARGUMENTS]++;
+          return TableRef();
+        }
+        c.stat[MDCT_TABLE_STAT_STREAM_WAITS]++;
+      }
+    }
+    sl.tick = ++c.tick;
+    sl.pins++;
+    c.stat[MDCT_TABLE_STAT_HITS]++;
+    return TableRef{device, it->second, c.dev + it->second};
+  }
+  // first sight: a free slot, or the least recently used one nobody holds
+  if (!c.dev)
+  {
+    RelaxedCaptureMode relaxed;
+    if (hipMalloc(reinterpret_cast<void **>(&c.dev), kTableSlots * sizeof(mdct::OwnTables)) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      c.dev = nullptr;
+      c.failed = true; // keep working from the arguments
+      return TableRef();
+    }
+    c.slots.reserve(kTableSlots);
+  }
+  int k = -1;
+  if (c.slots.size() < (size_t)kTableSlots)
+  {
+    c.slots.emplace_back();
+    k = (int)c.slots.size() - 1;
+    if (!make_event(&c.slots[k].ready))
+      k = -2;
+  }
+  else
+  { // the least recently used slot that nobody holds and whose readers can be fenced (a few tries: fencing enqueues waits on `stream`)
+    uint64_t after = 0;
+    for (int tries = 0; tries < 4 && k < 0; tries++)
+    {
+      int v = -1;
+      for (int i = 0; i < kTableSlots; i++)
+        if (c.slots[i].pins == 0 && c.slots[i].tick > after && (v < 0 || c.slots[i].tick < c.slots[v].tick))
+          v = i;
+      if (v < 0)
+        break;
+      after = c.slots[v].tick;
+      if (slot_quiesce_for(c, c.slots[v], stream))
+        k = v;
+      else
+        (void)hipGetLastError();
+    }
+  }
+  if (k < 0 || mdct::launch_park_table(tb, c.dev + k, stream) != hipSuccess)
+  { // nothing was overwritten: every slot keeps what it held
+    (void)hipGetLastError();
+    c.stat[MDCT_TABLE_STAT_FROM_ARGUMENTS]++;
+    if (k >= 0 && !c.slots[k].used)
+      c.slots.pop_back();
+    else if (k == -2)
+      c.slots.pop_back();
+    return TableRef();
+  }
+  TableSlot &sl = c.slots[k];
+  bool upload_done = false;
+  if (hipEventRecord(sl.ready, stream) != hipSuccess)
+  { // the upload is enqueued but other streams could not be told when it ends: the one error path that waits for it
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(stream);
+    upload_done = true;
+  }
+  if (sl.used)
+  {
+    const auto old = c.index.equal_range(sl.hash);
+    for (auto it = old.first; it != old.second; ++it)
+      if (it->second == k)
+      {
+        c.index.erase(it);
+        break;
+      }
+    c.stat[MDCT_TABLE_STAT_EVICTIONS]++;
+  }
+  sl.n_readers = 0; // the upload is ordered behind all of them
+  sl.host = tb;
+  sl.hash = h;
+  sl.used = true;
+  sl.ready_done = upload_done;
+  sl.ready_stream = stream;
+  sl.tick = ++c.tick;
+  sl.pins = 1;
+  c.index.emplace(h, k);
+  c.stat[MDCT_TABLE_STAT_UPLOADS]++;
+  return TableRef{device, k, c.dev + k};
+}
+
+// after the launch(es) that read the slot were enqueued on `stream` (launched = false: nothing was enqueued, just let go).
+// No HIP call: the slot and the cache only remember the stream.
+void table_release(const TableRef &r, hipStream_t stream, bool launched = true)
+{
+  if (!r.dev)
+    return;
+  TableCache &c = g_tables[r.device];
+  std::lock_guard<std::mutex> lk(c.mu);
+  TableSlot &sl = c.slots[r.slot];
+  sl.pins--;
+  if (!launched || sl.n_readers > kSlotStreams)
+    return;
+  for (int i = 0; i < sl.n_readers; i++)
+    if (sl.readers[i] == stream)
+      return;
+  if (sl.n_readers < kSlotStreams)
+    sl.readers[sl.n_readers] = stream;
+  sl.n_readers++;
+  bool seen = false;
+  for (int i = 0; i < c.n_known && !seen; i++)
+    seen = c.known[i] == stream;
+  if (!seen)
+  {
+    if (c.n_known < kKnownStreams)
+      c.known[c.n_known++] = stream;
+    else
+      c.known_overflow = true; // slots with many readers stop being victims: 64 streams sharing tables is not this cache's case
+  }
 }
 
 int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
@@ -289,8 +488,10 @@ int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t 
     return r;
   if ((r = make_own_tables(lut, a.tb, mode == mdct::MODE_ROUNDTRIP)))
     return r;
-  a.tb_dev = (lut || mode != mdct::MODE_ROUNDTRIP) ? parked_tables(di->device, a.tb, (hipStream_t)stream) : nullptr; // (no table, round trip: no multipliers read)
+  const TableRef parked = (lut || mode != mdct::MODE_ROUNDTRIP) ? table_acquire(di->device, a.tb, (hipStream_t)stream) : TableRef(); // (no table, round trip: no multipliers read)
+  a.tb_dev = parked.dev;
   const hipError_t e = mdct::launch_i16(a, mode, lut != nullptr, (hipStream_t)stream, lut_bounded(lut));
+  table_release(parked, (hipStream_t)stream, e == hipSuccess);
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "i16 kernel launch");
 }
 
@@ -553,21 +754,23 @@ int run_batch(int mode, const Plane *planes, int n, int level_shift, void *strea
     for (size_t k = 0; k < lay.tables.size(); k++)
       memcpy(l.args.blob + k * sizeof(mdct::OwnTables), &in.tables[lay.tables[k]], sizeof(mdct::OwnTables));
     // the chunk's tables from the device's table cache when all of them are parked there (descriptors: always in the arguments)
-    std::vector<const mdct::OwnTables *> parked(lay.tables.size());
+    std::vector<TableRef> parked(lay.tables.size());
     bool all_parked = !lay.tables.empty();
     for (size_t k = 0; k < lay.tables.size() && all_parked; k++)
-      all_parked = (parked[k] = parked_tables(di->device, in.tables[lay.tables[k]], (hipStream_t)stream)) != nullptr;
+      all_parked = (parked[k] = table_acquire(di->device, in.tables[lay.tables[k]], (hipStream_t)stream)).dev != nullptr;
     if (all_parked)
     {
-      const mdct::OwnTables *base = parked[0];
+      const mdct::OwnTables *base = parked[0].dev;
       for (size_t k = 1; k < parked.size(); k++)
-        base = parked[k] < base ? parked[k] : base;
+        base = parked[k].dev < base ? parked[k].dev : base;
       l.args.tables = base;
       for (mdct::BatchDesc &d : lay.descs)
-        d.table = (uint32_t)((parked[d.table / sizeof(mdct::OwnTables)] - base) * sizeof(mdct::OwnTables));
+        d.table = (uint32_t)((parked[d.table / sizeof(mdct::OwnTables)].dev - base) * sizeof(mdct::OwnTables));
     }
     memcpy(l.args.blob + l.args.head.table_bytes, lay.descs.data(), lay.descs.size() * sizeof(mdct::BatchDesc));
     const hipError_t e = launch_batch(l, mode, (hipStream_t)stream);
+    for (const TableRef &r : parked)
+      table_release(r, (hipStream_t)stream, all_parked && e == hipSuccess); // (an upload that was enqueued for nothing is harmless)
     if (e != hipSuccess)
       return hip_fail(e, "plane batch launch");
   }
@@ -996,6 +1199,20 @@ int mdct_batch_destroy(mdct_batch *b)
     e = hipFree(b->dev);
   delete b;
   return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "hipFree");
+}
+
+int mdct_table_cache_stats(uint64_t *stats, int n)
+{
+  if (stats == nullptr || n < 0)
+    return fail(MDCT_INVALID_PARAMETER, "null stats");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+    return fail(MDCT_NOT_SUPPORTED, "no current HIP device");
+  TableCache &c = g_tables[dev];
+  std::lock_guard<std::mutex> lk(c.mu);
+  for (int i = 0; i < n; i++)
+    stats[i] = i < MDCT_TABLE_STAT_COUNT ? c.stat[i] : 0;
+  return MDCT_SUCCESS;
 }
 
 int mdct_stream_copy(const void *from, void *to, size_t bytes, void *stream)

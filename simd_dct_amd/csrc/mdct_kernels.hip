@@ -2133,6 +2133,14 @@ __device__ __forceinline__ void f32_tile_body(const F32Args &a)
   }
 }
 
+// Parks one quantiser table in device memory (mdct_api.hip: the table cache): the 512 bytes arrive in the argument segment and one
+// wave writes them to the slot, 8 bytes per lane -- an upload that is ordered on the stream like any launch and needs no host buffer.
+__global__ __launch_bounds__(64) void k_park_table(OwnTables tb, OwnTables *slot)
+{
+  static_assert(sizeof(OwnTables) == 64 * sizeof(uint2), "one uint2 per lane");
+  reinterpret_cast<uint2 *>(slot)[threadIdx.x] = reinterpret_cast<const uint2 *>(&tb)[threadIdx.x];
+}
+
 // read-N / write-N stream copy, 8 x 16 B per lane, non-temporal: the box's measured HBM roofline
 // (tools/membench: this shape is the fastest of those tried, ~6.2 TB/s).
 constexpr int kCopyUnroll = 8;
@@ -2317,6 +2325,12 @@ hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, bool general, hip
     hipLaunchKernelGGL((k_u8_batch<false, true>), g, b, 0, s, a);
   else
     hipLaunchKernelGGL((k_u8_batch<false, false>), g, b, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_park_table(const OwnTables &tb, OwnTables *slot, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_park_table, dim3(1), dim3(64), 0, s, tb, slot);
   return hipGetLastError();
 }
 

@@ -296,9 +296,9 @@ def test_config4_256_separately_allocated_planes_forward_in_one_call(cuda):
 
 @gpu
 def test_table_cache_first_sight_under_capture_and_beyond_its_capacity(cuda):
-    """Tables are parked in device memory on first sight (mdct_api.hip: table cache) -- except when that first sight happens inside a
-    stream capture, or when the cache's 256 slots are taken: then the tables travel in the kernel arguments.  Same bytes either way:
-    a table never seen before used first under capture (single-plane call and batch), then 300 more distinct tables."""
+    """Tables are parked in device memory on first sight (mdct_api.hip: table cache; tests/test_table_cache.py) -- except inside a stream
+    capture, where they travel in the kernel arguments; beyond the cache's 256 slots the least recently used table is evicted.  Same
+    bytes either way: a table never seen before used first under capture (single-plane call and batch), then 300 more distinct tables."""
     import oracle as O
 
     torch = cuda
@@ -334,7 +334,7 @@ def test_table_cache_first_sight_under_capture_and_beyond_its_capacity(cuda):
 @gpu
 def test_two_host_threads_park_new_tables_and_run_batches_concurrently(cuda):
     """the table cache is shared by all host threads of a device: two threads, each on its own stream, keep introducing tables nobody has
-    seen (first-sight copies under the cache's lock) while launching single-plane calls and plane batches with them; every result is
+    seen (first-sight uploads under the cache's lock) while launching single-plane calls and plane batches with them; every result is
     the oracle's"""
     import threading
 
