@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W = H = 8192
 NSETS = 4
-PRECONDITION = 1000  # untimed launches (~50 ms) before warmup, see main()
+PRECONDITION = int(os.environ.get("MDCT_BENCH_PRECONDITION", "1000"))  # untimed launches (~50 ms) before warmup, see main()
 ALG_BYTES_PER_PX = 4  # int16 in + int16 out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -264,23 +264,42 @@ def main():
     for i in range(args.warmup):
         step(i)
 
+    # The timed region: barrier + synchronize, EXACTLY K steps, synchronize + barrier; each rank clocks its own K steps and the
+    # job's time is the MAX over ranks.  `value` stays on the wall clock.  So that K = 20 (0.9 ms) gives the figure K = 2000 gives,
+    # nothing but the K launches sits between the two clock reads: the stream events are recorded around them (start before t0),
+    # the end of the last kernel is seen by POLLING the stop event (mdct_timer_wait_spin: a blocking wait pays tens of
+    # microseconds of interrupt wake-up -- round 4's 7 % at K = 20), after which torch.cuda.synchronize() returns at once.
+    stream_arg = M.api._stream()  # torch's current stream, resolved once
+    lib = M.api._lib.load()
     barrier()
+    lib.mdct_timer_start(timer._t, stream_arg)
     t0 = time.perf_counter()
-    timer.start()
     for i in range(args.steps):
         step(i)
-    timer.stop()
-    barrier()
+    lib.mdct_timer_stop(timer._t, stream_arg)
+    timer.wait_spin()  # the stop event sits behind the K-th launch on the launch stream: when it has completed, the K steps have
     wall = time.perf_counter() - t0
-    kernel_ms = timer.elapsed_ms() / args.steps  # HIP events on the launch stream, avg per launch
+    torch.cuda.synchronize()  # (returns 7-70 us later although nothing is pending: profiles/r05_exp_timed_region.log)
     if dist is not None:
-        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = t.tolist()
+        dist.barrier()
+        torch.cuda.synchronize()
+    kernel_ms = timer.elapsed_ms() / args.steps  # HIP events on the launch stream, avg per launch
+    per_rank_mpx = None
+    rccl_ranks_seen = None
+    if dist is not None:
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        mine = torch.tensor([wall, kernel_ms, 1.0], dtype=torch.float64, device=dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)  # over RCCL: every rank's own clock, and a head count of the ranks that really took part
+        per_rank_mpx = [round(W * H * args.steps / float(e[0]) / 1e6, 1) for e in every]
+        rccl_ranks_seen = int(round(sum(float(e[2]) for e in every)))
+        wall = max(float(e[0]) for e in every)
+        kernel_ms = max(float(e[1]) for e in every)
 
     log(f"timed region done: {wall / args.steps * 1e3:.4f} ms/step")
     px_per_step = W * H
     value = world * px_per_step * args.steps / wall / 1e6
+    value_hip_events = world * px_per_step / (kernel_ms * 1e-3) / 1e6  # the same K steps by the stream's own clock
     achieved = px_per_step * ALG_BYTES_PER_PX / (kernel_ms * 1e-3) / 1e9
 
     extras, allgather = {}, None
@@ -399,6 +418,49 @@ def main():
             del frames, calls3, dev3, pr3, fw3, four, two
         except Exception as e:
             extras["config3_420_roundtrip_one_call"] = {"error": str(e)[:200]}
+        # configs[2] as SURVEY.md 8(d) states it: the same frame as 8-bit planes, u8 in -> u8 out (2 algorithmic bytes per pixel = 99,532,800 B),
+        # forward -> quantise -> dequantise -> inverse in ONE launch of k_u8_batch
+        try:
+            NF8 = 6  # 99.5 MB per frame: six rotate well past the 256 MB Infinity Cache
+            frames8 = []
+            for f in range(NF8):
+                pl = []
+                for (w, h, so, tab) in synth.CONFIG3_PLANES:
+                    a = synth.plane_u8_torch(w, h, "photo", seed=synth.SEED + so + 10 * f)
+                    pl.append((a, torch.zeros_like(a), w, h, synth.JPEG_LUMA if tab == "luma" else synth.JPEG_CHROMA))
+                frames8.append(pl)
+            fpx = sum(w * h for (w, h, _, _) in synth.CONFIG3_PLANES)
+            dev8 = [M.Batch("roundtrip_u8", f) for f in frames8]
+            pr8 = [b.prepared() for b in dev8]
+            r = rate(lambda i: pr8[i % NF8](), 2 * fpx, n=600, warm=1500)
+            torch.cuda.synchronize()
+            want = own_sha.get("config3_420_u8", {})
+            keys = [f"roundtrip_u8__{w}x{h}__seed+{so}__{tab}" for (w, h, so, tab) in synth.CONFIG3_PLANES]
+            r["sha256_equals_cpu_checker"] = all(k in want and sha_of(frames8[0][j][1]) == want[k] for j, k in enumerate(keys)) if want else "no committed hashes"
+            r["launches_per_call"] = dev8[0].launches
+            r["Mpx_s"] = round(fpx / (r["ms"] * 1e-3) / 1e6, 0)
+            kept8 = [t[1].clone() for t in frames8[0]]
+            for t in frames8[0]:
+                t[1].zero_()
+            ar8 = [M.prepare_u8_batch(f) for f in frames8]
+            r["kernel_argument_form"] = rate(lambda i: ar8[i % NF8](), 2 * fpx, n=600, warm=600)
+            torch.cuda.synchronize()
+            r["kernel_argument_form_equals_device_table_form"] = all(torch.equal(a, t[1]) for a, t in zip(kept8, frames8[0]))
+            four8 = M.Batch("roundtrip_u8", [pl for f in frames8[:4] for pl in f])
+            run48 = four8.prepared()
+            r["four_frames_per_call_ms_per_frame"] = round(rate(lambda i: run48(), 8 * fpx, n=200, warm=300)["ms"] / 4, 4)
+            # what it replaces: the two calls it fuses (3 + 3 bytes per pixel through an int16 plane), Y plane only
+            yw, yh = synth.CONFIG3_PLANES[0][0], synth.CONFIG3_PLANES[0][1]
+            coef8 = torch.empty((yh, yw), dtype=torch.int16, device="cuda")
+            f8 = [M.prepare_u8_i16("fwd", frames8[i][0][0], coef8, yw, yh, lut=synth.JPEG_LUMA) for i in range(NF8)]
+            i8 = [M.prepare_u8_i16("inv", coef8, frames8[i][0][1], yw, yh, lut=synth.JPEG_LUMA) for i in range(NF8)]
+            y1 = [M.prepare_roundtrip_u8(frames8[i][0][0], frames8[i][0][1], yw, yh, lut=synth.JPEG_LUMA) for i in range(NF8)]
+            r["y_plane_two_calls_ms"] = round(rate(lambda i: (f8[i % NF8](), i8[i % NF8]()), 6 * yw * yh, n=300, warm=300)["ms"], 4)
+            r["y_plane_fused_ms"] = round(rate(lambda i: y1[i % NF8](), 2 * yw * yh, n=300, warm=300)["ms"], 4)
+            extras["config3_420_u8_roundtrip_one_call"] = r
+            del frames8, dev8, pr8, ar8, four8, run48, coef8, f8, i8, y1, kept8
+        except Exception as e:
+            extras["config3_420_u8_roundtrip_one_call"] = {"error": str(e)[:200]}
         # configs[4]: float32 DCT-II on the 8192x8192 plane (8 algorithmic bytes per pixel)
         try:
             fsrc = [srcs[i].to(torch.float32) for i in range(2)]  # plane set 0 = float(int16 photo plane, seed SEED): the committed hash
@@ -531,7 +593,8 @@ def main():
         line = {
             "metric": "Mpixels/s 8x8 fwd+inv int16 DCT, 8192x8192 plane",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "kernel_ms": round(kernel_ms, 4), "value_hip_events": round(value_hip_events, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "io_dtype": "int16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: single 8192x8192 int16 plane per GPU, forward+inverse 8x8 DCT fused in one kernel",
                        "plane": [W, H], "io": "int16", "planes_per_step_per_gpu": 1, "rotating_plane_sets": NSETS, "untimed_preconditioning_launches": PRECONDITION,
@@ -541,6 +604,10 @@ def main():
                          "algorithmic_bytes_per_launch": px_per_step * ALG_BYTES_PER_PX, "avg_launch_ms": round(kernel_ms, 4)},
             "bit_exact_roundtrip_verified": verified,
         }
+        if dist is not None:  # one process per GPU: who took part, and each rank's own rate (the driver computes the efficiency, not this file)
+            line["rccl_ranks_seen"] = rccl_ranks_seen
+            line["per_rank_Mpx_s"] = per_rank_mpx
+            line["backend"] = "rccl" if args.backend == "nccl" else "gloo (rehearsal)"
         traffic = {}
         tr = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr):
@@ -582,13 +649,26 @@ def main():
             if "GBps" in c3:
                 fpx3 = sum(w * h for (w, h, _, _) in synth.CONFIG3_PLANES)
                 line["roofline_config3_420"] = own_block(c3, "mdct::k_i16_batch<MODE_ROUNDTRIP, every plane its table, no saturations>", 4 * fpx3,
-                                                         "BASELINE.json configs[2]: Y 7680x4320 + Cb/Cr 3840x2160, Annex-K tables, fused fwd+inv, ONE call (mdct_roundtrip_i16_planes) = one launch",
+                                                         "the configs[2] frame held as int16 planes (4 B/px; rounds 2-4 measured configs[2] in this form; the 8-bit form SURVEY.md 8(d) specifies is roofline_config3_420_u8): "
+                                                         "Y 7680x4320 + Cb/Cr 3840x2160, Annex-K tables, fused fwd+inv, ONE call (mdct_roundtrip_i16_planes) = one launch",
                                                          "k_i16_batch_420_bytes_per_launch")
                 line["roofline_config3_420"]["Mpx_s"] = c3.get("Mpx_s")
                 line["roofline_config3_420"]["device_table_form_ms"] = c3.get("device_table_form", {}).get("ms")
                 line["roofline_config3_420"]["forward_only_batch_ms"] = c3.get("forward_only_batch", {}).get("ms")
                 line["roofline_config3_420"]["four_frames_per_call_ms_per_frame"] = c3.get("four_frames_per_call_ms_per_frame")
                 line["roofline_config3_420"]["two_streams_ms_per_frame"] = c3.get("two_streams_ms_per_frame")
+            c3u = extras.get("config3_420_u8_roundtrip_one_call", {})
+            if "GBps" in c3u:
+                fpx3 = sum(w * h for (w, h, _, _) in synth.CONFIG3_PLANES)
+                blk = own_block(c3u, "mdct::k_u8_batch<tame tables: no saturations, v_sat_pk_u8_i16 output stage>", 2 * fpx3,
+                                "BASELINE.json configs[2] as SURVEY.md 8(d) defines it: Y 7680x4320 + Cb/Cr 3840x2160 8-bit planes in, 8-bit planes out, Annex-K tables, "
+                                "forward -> quantise -> dequantise -> inverse fused, ONE call (mdct_batch_run of mdct_batch_create_u8) = one launch",
+                                "k_u8_batch_420_bytes_per_launch")
+                blk["bound"] = "vector issue (the bytes alone would take 99.5 MB / measured copy rate; valu_floor_ms below), DESIGN.md 4.2b"
+                blk["parity"] = "unpinned by the reference (it has no inverse); pinned by the CPU checker's composition orc_fwd_u8_i16 -> orc_inv_i16_u8 and equal to the two-call path on the device (tests/test_u8_roundtrip.py)"
+                for k in ("Mpx_s", "launches_per_call", "kernel_argument_form", "kernel_argument_form_equals_device_table_form", "four_frames_per_call_ms_per_frame", "y_plane_two_calls_ms", "y_plane_fused_ms"):
+                    blk[k] = c3u.get(k)
+                line["roofline_config3_420_u8"] = blk
             c5 = extras.get("config5_f32_fwd", {})
             if "GBps" in c5:
                 line["roofline_f32"] = own_block(c5, "mdct::k_f32_tile<MODE_FWD>", 8 * W * H, "BASELINE.json configs[4]: float32 DCT-II, 8192x8192 plane (mdct_fwd_f32)", "k_f32_tile_fwd_bytes_per_launch")
@@ -730,6 +810,8 @@ def main():
                          "seconds_per_batch": {"compute_only": round(tc, 5), "gather_only": round(tg, 5), "pipelined": round(tp, 5)},
                          "Mpx_s_whole_batch_pipelined": round(batch_px / tp / 1e6, 0), "Mpx_s_compute_only": round(batch_px / tc / 1e6, 0),
                          "busbw_GBps_gather_only": round((world - 1) / world * out_bytes / tg / 1e9, 1),
+                         "xgmi_ceiling_GBps_per_gpu": 7 * 153, "busbw_frac_of_xgmi_ceiling": round((world - 1) / world * out_bytes / tg / 1e9 / (7 * 153), 3),
+                         "rccl_ranks_seen": rccl_ranks_seen,
                          "gathered_checksums_match_owners": bool(gathered_ok)}
             del src4, gbuf
         except Exception as e:

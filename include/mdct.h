@@ -295,7 +295,8 @@ int mdct_jpeg_pack_rows_counted(const uint8_t *segments, const uint32_t *seg_byt
  * for the next one, also for replays of a captured launch and for another number of rows.  Calls that share a row_work must
  * not overlap (same stream, or ordered by events); concurrent calls take one row_work each.
  * Up to 16384 rows every row adds up the lengths of all rows before it in the same launch; taller planes take two launches
- * internally (the fused coder, then the counted packing), same bytes, same arguments.
+ * internally (the fused coder, then the counted packing), same bytes, same arguments -- they use row_work only as scratch that they
+ * leave zeroed and neither consult nor set the failure word below (their launches have no cross-row wait that could time out).
  * FAILURE INDICATOR: row_offsets[by1 - by0] == UINT64_MAX.  Should a row not hear from all of its predecessors within ~1 s (cannot
  * happen while rows are dispatched in order), it sets a sticky word in row_work, the launch ends with UINT64_MAX there, and so does
  * every later call on the same row_work (without coding anything) until the caller zeroes row_work again.  A total above
@@ -376,6 +377,9 @@ int mdct_timer_start(mdct_timer *t, void *stream);
 int mdct_timer_stop(mdct_timer *t, void *stream);
 /* blocks until the stop event has completed; returns elapsed milliseconds (< 0 on error) */
 double mdct_timer_elapsed_ms(mdct_timer *t);
+/* waits for the stop event by POLLING it (hipEventQuery in a loop on the calling thread): returns within a microsecond or two of the
+ * event, where a blocking wait pays the interrupt wake-up (tens of microseconds -- 7 % of a 20-launch timed region) */
+int mdct_timer_wait_spin(mdct_timer *t);
 int mdct_stream_synchronize(void *stream);
 
 #ifdef __cplusplus

@@ -107,6 +107,7 @@ SIGNATURES = {
     "mdct_timer_start": (c_int, [c_void_p, c_void_p]),
     "mdct_timer_stop": (c_int, [c_void_p, c_void_p]),
     "mdct_timer_elapsed_ms": (ctypes.c_double, [c_void_p]),
+    "mdct_timer_wait_spin": (c_int, [c_void_p]),
     "mdct_stream_synchronize": (c_int, [c_void_p]),
     "mdct_shim_set_max_simd": (None, [c_int]),
     "mdct_shim_get_max_simd": (c_int, []),

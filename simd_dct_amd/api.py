@@ -593,6 +593,10 @@ class Timer:
     def stop(self, stream=None):
         _check(self._lib.mdct_timer_stop(self._t, _stream(stream)))
 
+    def wait_spin(self):
+        """poll the stop event until it has completed (no interrupt wake-up latency)"""
+        _check(self._lib.mdct_timer_wait_spin(self._t))
+
     def elapsed_ms(self):
         ms = self._lib.mdct_timer_elapsed_ms(self._t)
         if ms < 0:

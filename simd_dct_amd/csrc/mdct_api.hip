@@ -1291,6 +1291,20 @@ double mdct_timer_elapsed_ms(mdct_timer *t)
   return (double)ms;
 }
 
+int mdct_timer_wait_spin(mdct_timer *t)
+{
+  if (!t)
+    return fail(MDCT_INVALID_PARAMETER, "null timer");
+  for (;;)
+  {
+    const hipError_t e = hipEventQuery(t->t1);
+    if (e == hipSuccess)
+      return MDCT_SUCCESS;
+    if (e != hipErrorNotReady)
+      return hip_fail(e, "hipEventQuery");
+  }
+}
+
 int mdct_stream_synchronize(void *stream)
 {
   const hipError_t e = hipStreamSynchronize((hipStream_t)stream);

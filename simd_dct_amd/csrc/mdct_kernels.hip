@@ -1940,9 +1940,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
       if (!ok)
         __hip_atomic_fetch_or(a.work + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sticky: this launch and every later one fail visibly
       a.row_off[r] = ok ? base : ~0ull;
-      if (!marker)
-      { // the last row has waited for every other row, so any row that gave up has set work[1] by now
-        const bool failed = !ok || chain_failed(a.work);
+      if (marker)
+        chain_row_decided(a.work); // AFTER the failure bit: the last row reads the verdicts of all rows, not just their lengths
+      else
+      { // the last row: every other row has published (chain_base) -- now wait until every one of them has also DECIDED, so that a row which
+        // gave up between publishing and setting the failure bit cannot be missed; then fold the verdict into row_off[n_rows]
+        const bool failed = !ok || !chain_all_decided(a.work, a.n_rows - 1);
         if (!failed)
           chain_next_epoch(a.work, tag); // (a failed launch keeps its epoch: its stragglers must not look like the next launch's rows)
         a.row_off[a.n_rows] = failed ? ~0ull : base + len;

@@ -240,8 +240,8 @@ struct PackRow
 // segment; the LAST row, once it has seen every other row's tag, opens the next epoch -- at that point every row of this launch
 // has read the epoch long ago, and rows still waiting compare the tags with their own copy of it.
 // Failure: a row whose predecessors do not all publish within kChainDeadlineTicks (ONE deadline for the whole wait, on the constant
-// 100 MHz clock) sets work[1] and writes no scan.  The last row publishes row_off[n_rows] = UINT64_MAX when work[1] is set -- it waits
-// for every row, so it finishes after any row that gave up -- and does NOT open the next epoch; every later launch on the same work
+// 100 MHz clock) sets bit 0 of work[1] and writes no scan.  The last row publishes row_off[n_rows] = UINT64_MAX when that bit is set -- it waits
+// until every other row has DECIDED (chain_row_decided below), not merely published -- and does NOT open the next epoch; every later launch on the same work
 // array sees work[1] at its start, writes UINT64_MAX and does nothing else, until the caller zeroes the array again.
 // row_off[n_rows] == UINT64_MAX is thus the one failure indicator of a launch (include/mdct.h).
 // Forward progress rests on in-order dispatch: a row only ever waits for rows with smaller workgroup indices, which the hardware has
@@ -254,7 +254,7 @@ __device__ __forceinline__ uint32_t chain_epoch_tag(const unsigned long long *wo
   const uint32_t tag = (uint32_t)__hip_atomic_load(work, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   return tag ? tag : 1u; // 0 is what a slot of the zeroed work array holds
 }
-__device__ __forceinline__ bool chain_failed(const unsigned long long *work) { return __hip_atomic_load(work + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
+__device__ __forceinline__ bool chain_failed(const unsigned long long *work) { return (__hip_atomic_load(work + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) != 0; } // (bits 1..: rows of the running launch that have decided)
 
 __device__ __forceinline__ void chain_publish(unsigned long long *work, uint32_t r, uint32_t tag, uint32_t len)
 {
@@ -292,6 +292,33 @@ __device__ __forceinline__ unsigned long long chain_base(const unsigned long lon
   const unsigned long long base = wg_sum256(s, wave_sum);
   ok = wg_sum256(bad, wave_sum) == 0;
   return base;
+}
+
+// work[1] = failure bit (bit 0, sticky) + the number of rows of the running launch that have decided, times two.  A row adds 2 once its
+// own verdict is in work[1] (after its fetch_or, if it gave up); the last row waits for n_rows - 1 of them, reads the bit, and -- when the
+// launch is good -- leaves the word zero for the next launch.  A failed launch leaves it non-zero: chain_failed() for every later one.
+__device__ __forceinline__ void chain_row_decided(unsigned long long *work) { __hip_atomic_fetch_add(work + 1, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the last row, one thread: true = every other row decided and none gave up (work[1] is zero again); false = failure bit set / deadline
+__device__ __forceinline__ bool chain_all_decided(unsigned long long *work, uint32_t others)
+{
+  const unsigned long long t0 = wall_clock64();
+  for (uint32_t spins = 0;; spins++)
+  {
+    const unsigned long long v = __hip_atomic_load(work + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v & 1)
+      return false;
+    if ((v >> 1) >= others)
+    {
+      __hip_atomic_store(work + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    if ((spins & 63) == 63 && wall_clock64() - t0 > kChainDeadlineTicks)
+    {
+      __hip_atomic_fetch_or(work + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
 }
 
 // the last row, one thread, after chain_base

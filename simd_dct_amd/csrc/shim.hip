@@ -63,43 +63,60 @@ struct HipDev
   size_t sizeX = 0, sizeY = 0;
   int layout = 0, profile = 0;
 
+  typedef hipEvent_t event_t;
   void bind_thread() { (void)hipSetDevice(device); }
   bool stream_wait(hipStream_t s) { return hipStreamSynchronize(s) == hipSuccess; }
+  bool event_record(hipEvent_t &e, hipStream_t s) { return hipEventRecord(e, s) == hipSuccess; }
+  bool stream_wait_event(hipStream_t s, hipEvent_t &e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess; }
+  bool event_wait(hipEvent_t &e) { return hipEventSynchronize(e) == hipSuccess; }
   bool h2d_async(uint8_t *dev, const uint8_t *host, size_t n, hipStream_t s) { return hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, s) == hipSuccess; }
   bool d2h_async(uint8_t *host, const uint8_t *dev, size_t n, hipStream_t s) { return hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, s) == hipSuccess; }
   int launch(size_t r0, size_t r1, hipStream_t s) { return mdct_fwd_quant_u8(d_in, d_out, sizeX, lut, sizeX, sizeY, r0, r1, layout, profile, s); }
 };
 
+constexpr int kSlots = mdct_host::kPipeSlots;
 struct Staging
 {
   uint8_t *in = nullptr, *out = nullptr; // HBM mirrors of the caller's planes
   size_t in_cap = 0, out_cap = 0;
-  // chunk pipeline for host pointers: two pinned bounce buffers per direction, two streams
-  uint8_t *pin_in[2] = {nullptr, nullptr}, *pin_out[2] = {nullptr, nullptr};
+  // chunk pipeline for host pointers (shim_host.h: StripPipeline): kSlots pinned bounce buffers per direction, one stream per stage
+  // (copies in, kernels, copies out), an event per slot and stage
+  uint8_t *pin_in[kSlots] = {}, *pin_out[kSlots] = {};
   size_t pin_cap = 0;
-  hipStream_t stream[2] = {nullptr, nullptr};
+  hipStream_t stream[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t e_in[kSlots] = {}, e_k[kSlots] = {}, e_out[kSlots] = {};
   int device = -1;
   HipDev hip;
-  mdct_host::CopyPool<HipDev> pool;
-  std::atomic<int> in_latch[2] = {{0}, {0}}, out_latch[2] = {{0}, {0}}; // outstanding helper jobs per pipeline slot
+  mdct_host::CopyPool<HipDev> pool_in, pool_out;
+  std::atomic<int> in_latch[kSlots] = {}, out_latch[kSlots] = {}; // outstanding helper jobs per pipeline slot
 
   void release()
   {
-    pool.shutdown(); // before its streams and buffers go
+    pool_in.shutdown(); // before their streams, events and buffers go
+    pool_out.shutdown();
     // errors are ignored on purpose: at process exit the runtime may already be shutting down
     if (in)
       (void)hipFree(in);
     if (out)
       (void)hipFree(out);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < kSlots; i++)
     {
       if (pin_in[i])
         (void)hipHostFree(pin_in[i]);
       if (pin_out[i])
         (void)hipHostFree(pin_out[i]);
+      for (hipEvent_t *e : {&e_in[i], &e_k[i], &e_out[i]})
+      {
+        if (*e)
+          (void)hipEventDestroy(*e);
+        *e = nullptr;
+      }
+      pin_in[i] = pin_out[i] = nullptr;
+    }
+    for (int i = 0; i < 3; i++)
+    {
       if (stream[i])
         (void)hipStreamDestroy(stream[i]);
-      pin_in[i] = pin_out[i] = nullptr;
       stream[i] = nullptr;
     }
     (void)hipGetLastError();
@@ -114,12 +131,20 @@ thread_local Staging tl_stage;
 
 bool reserve_pipeline(Staging &s, size_t chunk_bytes)
 {
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 3; i++)
     if (!s.stream[i] && hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking) != hipSuccess)
       return false;
+  for (int i = 0; i < kSlots; i++)
+    for (hipEvent_t *e : {&s.e_in[i], &s.e_k[i], &s.e_out[i]})
+      if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
+      {
+        *e = nullptr;
+        (void)hipGetLastError();
+        return false;
+      }
   if (s.pin_cap >= chunk_bytes)
     return true;
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < kSlots; i++)
   {
     if (s.pin_in[i])
       (void)hipHostFree(s.pin_in[i]);
@@ -128,7 +153,7 @@ bool reserve_pipeline(Staging &s, size_t chunk_bytes)
     s.pin_in[i] = s.pin_out[i] = nullptr;
   }
   s.pin_cap = 0;
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < kSlots; i++)
     if (hipHostMalloc((void **)&s.pin_in[i], chunk_bytes, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&s.pin_out[i], chunk_bytes, hipHostMallocDefault) != hipSuccess)
     {
       (void)hipGetLastError();
@@ -178,10 +203,10 @@ bool is_device_ptr(const void *p) { return classify(p) == PTR_DEVICE; }
 using mdct_host::ceil_div;
 using mdct_host::ref_range; // simd_dct.cpp:2243-2261, :375-387
 
-// both pipeline streams idle before an error return: no copy may still target the caller's memory
+// all pipeline streams idle before an error return: no copy may still target the caller's memory
 simdDctResult pipeline_failed(Staging &st)
 {
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 3; i++)
     if (st.stream[i])
       (void)hipStreamSynchronize(st.stream[i]);
   (void)hipGetLastError();
@@ -222,18 +247,24 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
   const size_t total = sizeX * sizeY;
   const size_t strip = 8 * sizeX; // bytes per block row, input and output alike
 
-  // Both pointers on the host and a strip layout: chunked pipeline.  Block-row strips of
-  // ~4 MiB ping-pong over two internal streams, so strip k's kernel and device->host copy
-  // overlap strip k+1's host->device copy (PCIe is full duplex); the caller's pageable memory
-  // is touched only by plain memcpy to/from pinned bounce buffers.  A host-pointer call is
-  // synchronous by nature (the output must be in host memory on return) and its operands are
-  // not produced by any stream, so it does not involve the thread's configured stream.
+  // Both pointers on the host and a strip layout: chunked pipeline (shim_host.h: StripPipeline).  Block-row strips of up to 4 MiB
+  // travel through three internal streams -- copies in, kernels, copies out -- four chunks in flight, so that both directions of
+  // the link stay busy at once (PCIe is full duplex); the caller's pageable memory is touched only by plain memcpy to/from pinned
+  // bounce buffers.  A host-pointer call is synchronous by nature (the output must be in host memory on return) and its operands
+  // are not produced by any stream, so it does not involve the thread's configured stream.
   if (!dev_in && !dev_out && (layout == MDCT_LAYOUT_Q32 || layout == MDCT_LAYOUT_BLOCK))
   {
     const bool pinned_in = classify(pFrom) == PTR_PINNED, pinned_out = classify(pTo) == PTR_PINNED;
-    size_t rows_per_chunk = ((size_t)4 << 20) / strip;
+    // chunks of at most 4 MiB, and at least eight of them when the call is large enough (fill and drain cost one chunk per stage)
+    const size_t bytes = (b1 - b0) * strip;
+    size_t chunk = bytes / 8;
+    chunk = chunk > ((size_t)4 << 20) ? ((size_t)4 << 20) : (chunk < ((size_t)1 << 20) ? ((size_t)1 << 20) : chunk);
+    size_t rows_per_chunk = chunk / strip;
     rows_per_chunk = rows_per_chunk < 1 ? 1 : rows_per_chunk;
-    if (reserve(st.in, st.in_cap, total) && reserve(st.out, st.out_cap, total) && reserve_pipeline(st, rows_per_chunk * strip))
+    // (the mirrors need to reach the last processed row only: the reference's top-half loop, and the sizeY = 2H call form that turns
+    // it into a whole-plane call, touch half of the sizeX * sizeY bytes their shape describes)
+    const size_t reach = b1 * strip;
+    if (reserve(st.in, st.in_cap, reach) && reserve(st.out, st.out_cap, reach) && reserve_pipeline(st, rows_per_chunk * strip > ((size_t)4 << 20) ? rows_per_chunk * strip : ((size_t)4 << 20)))
     {
       st.hip.device = dev;
       st.hip.d_in = st.in;
@@ -243,8 +274,8 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
       st.hip.sizeY = sizeY;
       st.hip.layout = layout;
       st.hip.profile = profile;
-      mdct_host::StripPipeline<HipDev> pl{&st.hip, &st.pool, pFrom, pTo, st.in, st.out, {st.pin_in[0], st.pin_in[1]}, {st.pin_out[0], st.pin_out[1]},
-                                          {st.stream[0], st.stream[1]}, st.in_latch, st.out_latch, strip, rows_per_chunk, pinned_in, pinned_out, true};
+      mdct_host::StripPipeline<HipDev> pl{&st.hip, &st.pool_in, &st.pool_out, pFrom, pTo, st.in, st.out, st.pin_in, st.pin_out, st.stream[0], st.stream[1], st.stream[2],
+                                          st.e_in, st.e_k, st.e_out, st.in_latch, st.out_latch, strip, rows_per_chunk, pinned_in, pinned_out, true};
       const int r = pl.run(b0, b1); // shim_host.h
       if (r == mdct_host::PIPELINE_FAILED)
         return pipeline_failed(st);
@@ -397,7 +428,8 @@ int mdct_shim_warmup(size_t plane_bytes)
   if (!reserve(st.in, st.in_cap, need) || !reserve(st.out, st.out_cap, need) || !reserve_pipeline(st, (size_t)4 << 20))
     return MDCT_NOT_SUPPORTED;
   st.hip.device = dev;
-  (void)st.pool.start(&st.hip); // without helpers the pipeline still works
+  (void)st.pool_in.start(&st.hip, 2); // without helpers the pipeline still works
+  (void)st.pool_out.start(&st.hip, 3);
   // one small launch of each product: the first launch from a code object loads it
   float lut[64];
   for (int i = 0; i < 64; i++)

@@ -1,14 +1,18 @@
 // shim_host.h -- the HOST-ONLY logic of the drop-in shim (csrc/shim.hip), free of any HIP type so that it also builds
 // with plain g++: the reference's row-range arithmetic, the tier choice from the reference's CPU-flag globals, the
-// helper-thread copy pool and the chunked two-slot strip pipeline that serves host-pointer calls.  shim.hip
+// helper-thread copy pools and the chunked strip pipeline (one stream per stage, four slots) that serves host-pointer calls.  shim.hip
 // instantiates the templates with the HIP runtime as back end; tests/shim_host_driver.cpp instantiates them with
 // worker-thread "streams" over plain memory and runs them under -fsanitize=thread and -fsanitize=address,undefined
 // (the GPU pool cannot run sanitizers).
 //
 // Back end contract (`Dev`):
 //   typedef ... stream_t;                                        copyable handle, value-initialisable to "none"
+//   typedef ... event_t;                                         a point in a stream's order; owned by the caller of the pipeline
 //   void bind_thread();                                          called once by every helper thread before it works
 //   bool stream_wait(stream_t);                                  block until everything queued on the stream is done
+//   bool event_record(event_t &, stream_t);                      (re-)record the event behind everything queued on the stream so far
+//   bool stream_wait_event(stream_t, event_t &);                 later work on the stream starts after the event's last record (no host block)
+//   bool event_wait(event_t &);                                  block the calling host thread until the event's last record is reached
 //   bool h2d_async(uint8_t *dev, const uint8_t *host, size_t n, stream_t);
 //   bool d2h_async(uint8_t *host, const uint8_t *dev, size_t n, stream_t);
 //   int  launch(size_t row0, size_t row1, stream_t);             block rows [row0, row1) dev-in -> dev-out; 0 = ok
@@ -65,20 +69,22 @@ inline int level_from_flags(int set_level, const bool *sse2, const bool *ssse3, 
   return LEVEL_AVX2;
 }
 
-// The host pipeline's extra hands.  Copying between the caller's pageable memory and the pinned bounce buffers is what
-// bounds a host-pointer call: one core sustains ~15 GB/s of memcpy, PCIe moves ~26 GB/s each way at once.  Three helper
-// threads per calling thread (started on first use, joined when the thread's staging is released) take (a) half of every
-// chunk's input copy and (b) the output copies -- wait for the chunk's stream, then pinned -> caller memory, in two halves
-// -- while the calling thread copies the next chunk's input.  A latch per pipeline slot and direction says when a
-// slot's buffers are free again.
+// The host pipeline's extra hands.  Copying between the caller's pageable memory and the pinned bounce buffers must keep up with
+// a link that moves ~48 GB/s each way at once (tools/pcie_bench, profiles/r05_pcie_bench.log) while one core sustains ~27-30 GB/s of
+// memcpy: helper threads per calling thread (started on first use, joined when the thread's staging is released) take shares of
+// every chunk's input copy (one pool) and the output copies -- wait for the chunk's device->host copy, then pinned -> caller memory,
+// in two halves -- (another pool: an output job blocks its thread on an event, an input share must never queue behind it).
+// A latch per pipeline slot and direction says when a slot's buffers are free again.
 template <class Dev>
 struct CopyPool
 {
   typedef typename Dev::stream_t stream_t;
+  typedef typename Dev::event_t event_t;
   struct Job
   {
     bool has_stream;   // wait for `stream` first
     stream_t stream;
+    event_t *event;    // (or) wait for this event first; may be null
     uint8_t *dst;
     const uint8_t *src;
     size_t len;        // 0: nothing to copy (the data was DMA'd straight into pinned caller memory)
@@ -86,7 +92,7 @@ struct CopyPool
   };
   enum { kThreads = 3 };
   std::thread th[kThreads];
-  int started = 0;
+  int started = 0, wanted = kThreads;
   std::mutex m;
   std::condition_variable cv_job, cv_done;
   std::deque<Job> q;
@@ -108,7 +114,7 @@ struct CopyPool
         j = q.front();
         q.pop_front();
       }
-      const bool ok = !j.has_stream || dev->stream_wait(j.stream);
+      const bool ok = (!j.has_stream || dev->stream_wait(j.stream)) && (!j.event || dev->event_wait(*j.event));
       if (ok && j.len)
         memcpy(j.dst, j.src, j.len);
       if (!ok)
@@ -120,9 +126,10 @@ struct CopyPool
       cv_done.notify_all();
     }
   }
-  bool start(Dev *d)
+  bool start(Dev *d, int threads = kThreads)
   {
-    if (started == kThreads)
+    wanted = threads < 1 ? 1 : (threads > kThreads ? (int)kThreads : threads);
+    if (started == wanted)
     {
       dev = d;
       return true;
@@ -133,7 +140,7 @@ struct CopyPool
     stop = false;
     try
     {
-      for (; started < kThreads; started++)
+      for (; started < wanted; started++)
         th[started] = std::thread([this] { run(); });
     }
     catch (...)
@@ -174,101 +181,120 @@ struct CopyPool
 };
 
 enum { PIPELINE_OK = 0, PIPELINE_FAILED = -1 }; // a positive return is the status of a failed launch
+enum { kPipeSlots = 4 };                        // chunks in flight per direction
 
-// What a two-slot strip pipeline works with: the caller's host planes, the device mirrors of both planes, two pinned
-// bounce buffers per direction, two streams, one latch per slot and direction.
+// What the strip pipeline works with: the caller's host planes, the device mirrors of both planes, kPipeSlots pinned bounce
+// buffers per direction, ONE STREAM PER STAGE (host->device copies, kernels, device->host copies) with an event per slot and stage
+// between them, one latch per slot and direction.
+//
+// Round 5 (profiles/r05_pcie_bench.log, 32 MiB each way on this box): the link moves 47.9 GB/s each way when both directions run
+// at once (0.70 ms), but only 27-32 GB/s in the pattern rounds 2-4 used -- two streams, each carrying its chunk's copy in, kernel
+// and copy out one after the other -- and two slots per direction meant two chunks per (copy in + DMA in + kernel + DMA out + copy
+// out) latency, ~26 GB/s, whatever the link could do.  Now every stage has its own stream, so each DMA engine sees its copies back
+// to back, and four slots keep all five stages busy.
 template <class Dev>
 struct StripPipeline
 {
   typedef typename Dev::stream_t stream_t;
+  typedef typename Dev::event_t event_t;
   Dev *dev;
-  CopyPool<Dev> *pool;
+  CopyPool<Dev> *pool_in, *pool_out;
   const uint8_t *from; // caller's input plane (host)
   uint8_t *to;         // caller's output plane (host)
   uint8_t *d_in, *d_out;
-  uint8_t *pin_in[2], *pin_out[2];
-  stream_t stream[2];
-  std::atomic<int> *in_latch, *out_latch; // [2] each
+  uint8_t *const *pin_in, *const *pin_out; // [kPipeSlots] each
+  stream_t s_in, s_k, s_out;
+  event_t *e_in, *e_k, *e_out;             // [kPipeSlots] each
+  std::atomic<int> *in_latch, *out_latch;  // [kPipeSlots] each
   size_t strip;          // bytes per block row, input and output alike
   size_t rows_per_chunk;
   bool pinned_in, pinned_out; // caller memory is DMA-able in place: no bounce buffer, no memcpy
   bool use_helpers;
 
-  // Block rows [b0, b1): strips of rows_per_chunk rows ping-pong over the two slots, so strip k's kernel and
-  // device->host copy overlap strip k+1's host->device copy; the caller's pageable memory is touched only by plain
-  // memcpy to/from the bounce buffers.  On every exit path -- success, a failed copy, a failed launch -- every job
-  // handed to the helpers has finished and (failure paths) both streams are idle: nothing still targets the
-  // caller's memory or the bounce buffers when this returns.
+  // Block rows [b0, b1) in chunks of rows_per_chunk rows; chunk c uses slot c % kPipeSlots of either direction:
+  //   caller -> pin_in[slot]         the calling thread and two helpers, a third each (after the slot's previous DMA in has left it)
+  //   pin_in[slot] -> device         s_in;  e_in[slot] behind it
+  //   kernel                         s_k, after e_in[slot];  e_k[slot] behind it
+  //   device -> pin_out[slot]        s_out, after e_k[slot] and after the helpers have emptied the slot;  e_out[slot] behind it
+  //   pin_out[slot] -> caller        two helpers, half each, after e_out[slot]
+  // On every exit path -- success, a failed copy, a failed launch -- every job handed to the helpers has finished and all three
+  // streams are idle: nothing still targets the caller's memory or the bounce buffers when this returns.
   int run(size_t b0, size_t b1)
   {
     const size_t nchunks = ceil_div(b1 - b0, rows_per_chunk);
-    const bool helpers = use_helpers && nchunks > 1 && !(pinned_in && pinned_out) && pool->start(dev);
+    const bool helpers = use_helpers && nchunks > 1 && !(pinned_in && pinned_out) && pool_in->start(dev, 2) && pool_out->start(dev, 3);
     if (helpers)
-      pool->failed = false;
-    auto chunk_rows = [&](size_t c, size_t *r0, size_t *r1) {
-      *r0 = b0 + c * rows_per_chunk;
-      *r1 = *r0 + rows_per_chunk < b1 ? *r0 + rows_per_chunk : b1;
-    };
-    auto drain = [&](size_t c) { // chunk c has left both bounce buffers of its slot; its output is with the caller
-      const int sl = (int)(c & 1);
-      if (helpers)
-      {
-        pool->wait(out_latch[sl]);
-        return !pool->failed.load();
-      }
-      size_t r0, r1;
-      chunk_rows(c, &r0, &r1);
-      if (!dev->stream_wait(stream[sl]))
-        return false;
-      if (!pinned_out)
-        memcpy(to + r0 * strip, pin_out[sl], (r1 - r0) * strip);
-      return true;
-    };
+    {
+      pool_in->failed = false;
+      pool_out->failed = false;
+    }
     auto abandon = [&]() { // every job handed to the helpers finishes before the buffers are reused or freed
       if (helpers)
-        for (int sl = 0; sl < 2; sl++)
+        for (int sl = 0; sl < kPipeSlots; sl++)
         {
-          pool->wait(in_latch[sl]);
-          pool->wait(out_latch[sl]);
+          pool_in->wait(in_latch[sl]);
+          pool_out->wait(out_latch[sl]);
         }
-      for (int sl = 0; sl < 2; sl++)
-        (void)dev->stream_wait(stream[sl]);
+      (void)dev->stream_wait(s_in);
+      (void)dev->stream_wait(s_k);
+      (void)dev->stream_wait(s_out);
       return (int)PIPELINE_FAILED;
     };
     int r = 0;
     for (size_t c = 0; c < nchunks && r == 0; c++)
     {
-      const int sl = (int)(c & 1);
-      if (c >= 2 && !drain(c - 2))
-        return abandon();
-      size_t r0, r1;
-      chunk_rows(c, &r0, &r1);
+      const int sl = (int)(c % kPipeSlots);
+      const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
       const size_t off = r0 * strip, len = (r1 - r0) * strip;
       const uint8_t *h_in = from + off; // pinned caller memory is DMA'd in place
       if (!pinned_in)
       {
-        const size_t mine = helpers ? (len / 2) & ~(size_t)63 : len; // a helper copies the rest meanwhile
+        if (c >= (size_t)kPipeSlots && !dev->event_wait(e_in[sl])) // chunk c - kPipeSlots has left the bounce buffer
+          return abandon();
+        const size_t third = helpers ? (len / 3) & ~(size_t)63 : 0, mine = len - 2 * third;
         if (helpers)
         {
-          in_latch[sl] = 1;
-          pool->push({false, stream_t(), pin_in[sl] + mine, from + off + mine, len - mine, &in_latch[sl]});
+          in_latch[sl] = 2;
+          pool_in->push({false, stream_t(), nullptr, pin_in[sl] + mine, from + off + mine, third, &in_latch[sl]});
+          pool_in->push({false, stream_t(), nullptr, pin_in[sl] + mine + third, from + off + mine + third, third, &in_latch[sl]});
         }
         memcpy(pin_in[sl], from + off, mine);
         if (helpers)
-          pool->wait(in_latch[sl]);
+          pool_in->wait(in_latch[sl]);
         h_in = pin_in[sl];
       }
-      if (!dev->h2d_async(d_in + off, h_in, len, stream[sl]))
+      if (!dev->h2d_async(d_in + off, h_in, len, s_in) || !dev->event_record(e_in[sl], s_in) || !dev->stream_wait_event(s_k, e_in[sl]))
         return abandon();
-      r = dev->launch(r0, r1, stream[sl]);
-      if (r == 0 && !dev->d2h_async(pinned_out ? to + off : pin_out[sl], d_out + off, len, stream[sl]))
+      r = dev->launch(r0, r1, s_k);
+      if (r != 0)
+        break;
+      if (!dev->event_record(e_k[sl], s_k))
         return abandon();
-      if (helpers)
-      { // queued even when the launch failed: the slot's earlier copies still have to be waited for
-        const size_t out_len = pinned_out || r != 0 ? 0 : len, half = (out_len / 2) & ~(size_t)63;
-        out_latch[sl] = 2;
-        pool->push({true, stream[sl], to + off, pin_out[sl], half, &out_latch[sl]});
-        pool->push({true, stream[sl], to + off + half, pin_out[sl] + half, out_len - half, &out_latch[sl]});
+      if (helpers && !pinned_out && c >= (size_t)kPipeSlots)
+      { // the output bounce buffer of this slot: chunk c - kPipeSlots is with the caller
+        pool_out->wait(out_latch[sl]);
+        if (pool_out->failed.load())
+          return abandon();
+      }
+      if (!dev->stream_wait_event(s_out, e_k[sl]) || !dev->d2h_async(pinned_out ? to + off : pin_out[sl], d_out + off, len, s_out))
+        return abandon();
+      if (!pinned_out)
+      {
+        if (!dev->event_record(e_out[sl], s_out))
+          return abandon();
+        if (helpers)
+        {
+          const size_t half = (len / 2) & ~(size_t)63;
+          out_latch[sl] = 2;
+          pool_out->push({false, stream_t(), &e_out[sl], to + off, pin_out[sl], half, &out_latch[sl]});
+          pool_out->push({false, stream_t(), &e_out[sl], to + off + half, pin_out[sl] + half, len - half, &out_latch[sl]});
+        }
+        else
+        { // without helpers: one chunk at a time on the way out
+          if (!dev->event_wait(e_out[sl]))
+            return abandon();
+          memcpy(to + off, pin_out[sl], len);
+        }
       }
     }
     if (r != 0)
@@ -276,9 +302,16 @@ struct StripPipeline
       (void)abandon();
       return r;
     }
-    for (size_t c = nchunks >= 2 ? nchunks - 2 : 0; c < nchunks; c++)
-      if (!drain(c))
+    if (helpers)
+    {
+      for (int sl = 0; sl < kPipeSlots; sl++)
+        pool_out->wait(out_latch[sl]);
+      if (pool_out->failed.load() || pool_in->failed.load())
         return abandon();
+    }
+    // s_out's last copy is behind every kernel, which is behind every copy in: when s_out is idle, so is the pipeline
+    if (!dev->stream_wait(s_out) || !dev->stream_wait(s_k) || !dev->stream_wait(s_in))
+      return abandon();
     return PIPELINE_OK;
   }
 };

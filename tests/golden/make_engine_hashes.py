@@ -26,6 +26,18 @@ def sha(a):
 
 
 def main():
+    if "--only-u8" in sys.argv:  # add / refresh configs[2]'s 8-bit hashes without recomputing the rest (~10 s)
+        path = os.path.join(HERE, "engine_own_sha256.json")
+        out = json.load(open(path))
+        c3u = {}
+        for (w, h, so, tab) in synth.CONFIG3_PLANES:
+            src = synth.plane_u8_np(w, h, "photo", seed=synth.SEED + so)
+            lut = synth.JPEG_LUMA if tab == "luma" else synth.JPEG_CHROMA
+            c3u[f"roundtrip_u8__{w}x{h}__seed+{so}__{tab}"] = sha(O.roundtrip_u8(src, w, h, lut=lut, level_shift=True, threads=O.host_threads()))
+        out["config3_420_u8"] = c3u
+        json.dump(out, open(path, "w"), indent=1)
+        print(json.dumps(c3u, indent=1))
+        return
     out = {"what": "sha256 of oracle/dct_oracle.c outputs (engine-own arithmetic, DESIGN.md 4.2) for simd_dct_amd.synth planes; inputs: plane_i16 'photo', 8 bit"}
     # configs[2]: fused round trip with the Annex K.1 tables, every plane of the frame
     c3 = {}
@@ -35,6 +47,13 @@ def main():
         c3[f"roundtrip__{w}x{h}__seed+{so}__{tab}"] = sha(O.i16_par("roundtrip", src, w, h, lut=lut))
         c3[f"fwd__{w}x{h}__seed+{so}__{tab}"] = sha(O.i16_par("fwd", src, w, h, lut=lut))
     out["config3_420"] = c3
+    # configs[2] as SURVEY.md 8(d) states it: the same frame as 8-bit planes, u8 in -> u8 out, level shift on (mdct_roundtrip_u8_batch)
+    c3u = {}
+    for (w, h, so, tab) in synth.CONFIG3_PLANES:
+        src = synth.plane_u8_np(w, h, "photo", seed=synth.SEED + so)
+        lut = synth.JPEG_LUMA if tab == "luma" else synth.JPEG_CHROMA
+        c3u[f"roundtrip_u8__{w}x{h}__seed+{so}__{tab}"] = sha(O.roundtrip_u8(src, w, h, lut=lut, level_shift=True, threads=O.host_threads()))
+    out["config3_420_u8"] = c3u
     # configs[3]: forward, no table, 4096^2 planes with seeds SEED + 100 + p; the first and the last of the 256
     c4 = {}
     for p in (0, 1, 255):

@@ -1,5 +1,5 @@
 // shim_host_driver.cpp -- TEST INFRASTRUCTURE: the host-only logic of the drop-in shim (csrc/shim_host.h: ref_range,
-// level_from_flags, CopyPool, StripPipeline) on a back end made of worker-thread "streams" over plain heap memory,
+// level_from_flags, CopyPool, StripPipeline) on a back end made of worker-thread "streams" and sequence-number "events" over plain heap memory,
 // built by tests/test_shim_host.py with -fsanitize=thread and with -fsanitize=address,undefined.  Every buffer is an
 // exact-size heap allocation that is freed the moment the pipeline returns, so a job that outlives its call, a copy
 // past a strip or a race between the helpers and the caller is a sanitizer report.
@@ -78,6 +78,33 @@ struct FakeStream
   }
 };
 
+// an "event": a point in a stream's order.  record = bump the sequence now and mark it reached when the stream gets there; a waiter
+// (host thread or another stream) takes the sequence number at the time of ITS call, like hipEventSynchronize / hipStreamWaitEvent
+struct FakeEvent
+{
+  std::mutex m;
+  std::condition_variable cv;
+  uint64_t recorded = 0, reached = 0;
+  void reach(uint64_t seq)
+  {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      reached = seq > reached ? seq : reached;
+    }
+    cv.notify_all();
+  }
+  void wait_for(uint64_t seq)
+  {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return reached >= seq; });
+  }
+  uint64_t target()
+  {
+    std::lock_guard<std::mutex> lk(m);
+    return recorded;
+  }
+};
+
 static uint8_t kernel_byte(uint8_t in, size_t i) { return (uint8_t)(in * 31u + (uint8_t)(i * 7u) + (uint8_t)(i >> 11)); }
 
 struct FakeDev
@@ -91,10 +118,34 @@ struct FakeDev
   int fail_h2d = -1, fail_d2h = -1, fail_launch = -1, fail_wait = -1;
   std::atomic<int> bound_threads{0};
 
+  typedef FakeEvent event_t;
   void bind_thread() { bound_threads++; }
   bool stream_wait(stream_t s)
   {
     s->sync();
+    return wait_calls++ != fail_wait;
+  }
+  bool event_record(FakeEvent &e, stream_t s)
+  {
+    uint64_t seq;
+    {
+      std::lock_guard<std::mutex> lk(e.m);
+      seq = ++e.recorded;
+    }
+    FakeEvent *pe = &e;
+    s->push([=] { pe->reach(seq); });
+    return true;
+  }
+  bool stream_wait_event(stream_t s, FakeEvent &e)
+  {
+    const uint64_t seq = e.target();
+    FakeEvent *pe = &e;
+    s->push([=] { pe->wait_for(seq); });
+    return true;
+  }
+  bool event_wait(FakeEvent &e)
+  {
+    e.wait_for(e.target());
     return wait_calls++ != fail_wait;
   }
   bool h2d_async(uint8_t *dev, const uint8_t *host, size_t n, stream_t s)
@@ -130,19 +181,23 @@ struct FakeDev
 struct Rig
 {
   size_t strip, rows, rpc;
-  std::unique_ptr<uint8_t[]> d_in, d_out, pin_in[2], pin_out[2];
-  FakeStream streams[2];
+  std::unique_ptr<uint8_t[]> d_in, d_out, pin_in[kPipeSlots], pin_out[kPipeSlots];
+  uint8_t *pin_in_p[kPipeSlots], *pin_out_p[kPipeSlots];
+  FakeStream streams[3];
+  FakeEvent e_in[kPipeSlots], e_k[kPipeSlots], e_out[kPipeSlots];
   FakeDev dev;
-  CopyPool<FakeDev> pool;
-  std::atomic<int> in_latch[2] = {{0}, {0}}, out_latch[2] = {{0}, {0}};
+  CopyPool<FakeDev> pool_in, pool_out;
+  std::atomic<int> in_latch[kPipeSlots] = {}, out_latch[kPipeSlots] = {};
   Rig(size_t strip_, size_t rows_, size_t rpc_) : strip(strip_), rows(rows_), rpc(rpc_)
   {
     d_in.reset(new uint8_t[strip * rows]);
     d_out.reset(new uint8_t[strip * rows]);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < kPipeSlots; i++)
     {
       pin_in[i].reset(new uint8_t[strip * rpc]);
       pin_out[i].reset(new uint8_t[strip * rpc]);
+      pin_in_p[i] = pin_in[i].get();
+      pin_out_p[i] = pin_out[i].get();
     }
     dev.d_in = d_in.get();
     dev.d_out = d_out.get();
@@ -150,14 +205,17 @@ struct Rig
   }
   int run(const uint8_t *from, uint8_t *to, size_t b0, size_t b1, bool helpers, bool pinned_in, bool pinned_out)
   {
-    StripPipeline<FakeDev> pl{&dev, &pool, from, to, d_in.get(), d_out.get(), {pin_in[0].get(), pin_in[1].get()}, {pin_out[0].get(), pin_out[1].get()},
-                              {&streams[0], &streams[1]}, in_latch, out_latch, strip, rpc, pinned_in, pinned_out, helpers};
+    StripPipeline<FakeDev> pl{&dev, &pool_in, &pool_out, from, to, d_in.get(), d_out.get(), pin_in_p, pin_out_p, &streams[0], &streams[1], &streams[2],
+                              e_in, e_k, e_out, in_latch, out_latch, strip, rpc, pinned_in, pinned_out, helpers};
     return pl.run(b0, b1);
   }
   bool quiescent()
   {
-    std::lock_guard<std::mutex> lk(pool.m);
-    return pool.q.empty() && in_latch[0] == 0 && in_latch[1] == 0 && out_latch[0] == 0 && out_latch[1] == 0;
+    std::lock_guard<std::mutex> a(pool_in.m), b(pool_out.m);
+    bool q = pool_in.q.empty() && pool_out.q.empty();
+    for (int i = 0; i < kPipeSlots; i++)
+      q = q && in_latch[i] == 0 && out_latch[i] == 0;
+    return q;
   }
 };
 
@@ -190,7 +248,7 @@ static void check_rows(const std::vector<uint8_t> &in, const uint8_t *out, size_
 static void test_single_caller()
 {
   const size_t strip = 1024;
-  for (size_t rows : {1, 2, 3, 7, 16})
+  for (size_t rows : {1, 2, 3, 7, 16, 29})
     for (size_t rpc : {1, 2, 3})
       for (int helpers = 0; helpers < 2; helpers++)
         for (int pins = 0; pins < 4; pins++)
@@ -238,11 +296,11 @@ static void test_four_callers()
 // buffers are freed right after the call, so a straggler would be a use-after-free / race report
 static void test_failures()
 {
-  const size_t strip = 2048, rows = 9, rpc = 2;
+  const size_t strip = 2048, rows = 13, rpc = 2; // 7 chunks: the slots are reused
   const std::vector<uint8_t> in = make_plane(strip * rows, 5);
   for (int helpers = 0; helpers < 2; helpers++)
     for (int kind = 0; kind < 4; kind++)
-      for (int at = 0; at < 5; at++)
+      for (int at = 0; at < 7; at++)
       {
         std::unique_ptr<uint8_t[]> out(new uint8_t[strip * rows]);
         memset(out.get(), 0x11, strip * rows);
@@ -255,14 +313,13 @@ static void test_failures()
           if (kind == 3) rig.dev.fail_wait = at;
           r = rig.run(in.data(), out.get(), 0, rows, helpers, false, false);
           CHECK(rig.quiescent());
+          for (FakeStream &st : rig.streams)
           {
-            std::lock_guard<std::mutex> a(rig.streams[0].m), b(rig.streams[1].m);
-            CHECK(rig.streams[0].q.empty() && rig.streams[1].q.empty() && !rig.streams[0].busy && !rig.streams[1].busy);
+            std::lock_guard<std::mutex> a(st.m);
+            CHECK(st.q.empty() && !st.busy);
           }
           if (kind == 2)
             CHECK(r == 2);
-          else if (kind == 3 && at >= (helpers ? 10 : 5)) // (never: at < 5 always lands on a wait that exists)
-            CHECK(r == PIPELINE_OK);
           else
             CHECK(r == PIPELINE_FAILED || r == PIPELINE_OK); // a failing wait during abandon()'s own drain does not change a success
         } // rig and its buffers are gone
@@ -284,7 +341,7 @@ static void test_exit_with_jobs_queued()
       CopyPool<FakeDev> pool;
       CHECK(pool.start(&dev));
       for (int i = 0; i < 64; i++)
-        pool.push({(i & 1) != 0, &s, dst.data() + i * 1024, src.data() + i * 1024, 1024, &latch});
+        pool.push({(i & 1) != 0, &s, nullptr, dst.data() + i * 1024, src.data() + i * 1024, 1024, &latch});
     } // ~CopyPool with most of the 64 jobs still queued
     CHECK(latch == 0 && dst == src);
     CHECK(dev.bound_threads == CopyPool<FakeDev>::kThreads);

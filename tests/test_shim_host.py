@@ -2,7 +2,7 @@
 
 csrc/shim_host.h is the host-only part of csrc/shim.hip -- the reference's row-range arithmetic (simd_dct.cpp:2243-2261,
 :375-387), the tier choice from its CPU-flag globals (:78-85, :100-105, :120-127), the helper-thread CopyPool and the
-chunked two-slot strip pipeline behind host-pointer calls.  tests/shim_host_driver.cpp runs it on worker-thread
+chunked strip pipeline (one stream per stage, four slots) behind host-pointer calls.  tests/shim_host_driver.cpp runs it on worker-thread
 "streams" over exact-size heap buffers: 4 callers x multi-chunk on disjoint ranges of the same planes, every early-error
 path (failed copy / launch / stream wait at every chunk, buffers freed the moment the call returns), a thread that exits
 with jobs queued -- under ThreadSanitizer and under AddressSanitizer + UBSan."""
@@ -35,7 +35,7 @@ def test_shim_host_logic_under_sanitizers(tmp_path, sanitizer):
 def test_shim_hip_uses_the_host_header():
     """the product's shim really is built on the code the sanitizers ran: no second copy of the pool or the range arithmetic"""
     src = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "shim.hip")).read()
-    assert '#include "shim_host.h"' in src and "mdct_host::StripPipeline<HipDev>" in src and "mdct_host::CopyPool<HipDev>" in src
+    assert '#include "shim_host.h"' in src and "mdct_host::StripPipeline<HipDev>" in src and "mdct_host::CopyPool<HipDev> pool_in, pool_out" in src
     assert "struct CopyPool" not in src and "void ref_range(" not in src
     hdr = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "shim_host.h")).read()
     code = "\n".join(l.split("//")[0] for l in hdr.splitlines())  # comments aside, nothing of the HIP runtime: it builds with plain g++
