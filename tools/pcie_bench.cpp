@@ -110,6 +110,35 @@ int main(int argc, char **argv)
       printf("pinned, one stream per direction, %zu MiB pieces, out(k) behind in(k) by an event: %6.1f GB/s each way (%.3f ms)\n", piece >> 20, gb / t, t * 1e3);
     }
   }
+  // two streams per direction, pieces alternating between them: does the engine's per-copy set-up overlap the previous copy?
+  {
+    hipStream_t si[2] = {s0, nullptr}, so[2] = {s1, nullptr};
+    CK(hipStreamCreateWithFlags(&si[1], hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&so[1], hipStreamNonBlocking));
+    std::vector<hipEvent_t> ev(n >> 20);
+    for (auto &e : ev)
+      CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (size_t piece : {(size_t)2 << 20, (size_t)4 << 20})
+    {
+      auto dep = [&] {
+        for (size_t o = 0, k = 0; o < n; o += piece, k++)
+        {
+          CK(hipMemcpyAsync(d_a + o, p_a + o, piece, hipMemcpyHostToDevice, si[k & 1]));
+          CK(hipEventRecord(ev[k], si[k & 1]));
+          CK(hipStreamWaitEvent(so[k & 1], ev[k], 0));
+          CK(hipMemcpyAsync(p_b + o, d_a + o, piece, hipMemcpyDeviceToHost, so[k & 1]));
+        }
+        for (int i = 0; i < 2; i++)
+        {
+          CK(hipStreamSynchronize(si[i]));
+          CK(hipStreamSynchronize(so[i]));
+        }
+      };
+      dep();
+      const double t = best_of(10, dep);
+      printf("pinned, TWO streams per direction, %zu MiB pieces alternating, out(k) behind in(k): %6.1f GB/s each way (%.3f ms)\n", piece >> 20, gb / t, t * 1e3);
+    }
+  }
   // the same from PAGEABLE memory, one host thread per direction (hipMemcpyAsync on pageable memory occupies its calling thread)
   for (size_t piece : {(size_t)1 << 20, (size_t)2 << 20, (size_t)4 << 20, (size_t)8 << 20, n})
   {
