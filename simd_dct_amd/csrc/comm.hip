@@ -175,6 +175,11 @@ static int gather_pieces(mdct_comm *comm, uint8_t *buf, size_t n_planes, size_t 
     return no_rccl();
   hipStream_t s = (hipStream_t)stream;
   ncclResult_t e = ncclSuccess;
+  // MDCT_FORCE_RAGGED_GATHER=1 (diagnostics): take the grouped-broadcast form even for equal shards -- on a one-GPU box that is the only way
+  // the form ragged shards use ever meets the real RCCL (tests/test_comm.py); same bytes either way
+  const char *force = getenv("MDCT_FORCE_RAGGED_GATHER");
+  if (force && force[0] == '1')
+    equal = false;
   const bool grouped = n_planes > 1 || !equal;
   if (grouped && (e = r->GroupStart()) != ncclSuccess)
     return nccl_fail(r, e, "ncclGroupStart");

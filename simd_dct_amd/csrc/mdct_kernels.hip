@@ -43,7 +43,7 @@ enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2 }; // the reference's three 1-D kernels 
 // ---------------------------------------------------------------------------------------
 // Engine-own 1-D kernels (int16 / float32 paths; no reference counterpart): the scaled
 // Arai-Agui-Nakajima butterfly, 5 mul + 29 add per 8 points instead of 28 + 28.  Measured
-// on MI355X (tools/valubench, tools/exp_roundtrip): these kernels are bound by VALU ISSUE,
+// on MI355X (tools/valubench, tools/experiments/exp_roundtrip): these kernels are bound by VALU ISSUE,
 // v_add/v_mul_f32 issue at ~2-3 cycles per wave64, v_fma_f32 and v_pk_*_f32 at ~4-5, so
 // neither fusing nor packing buys anything -- only fewer operations do.  The scale factors
 // live in 64-entry tables applied where a multiply exists anyway (quantise / dequantise),
@@ -178,7 +178,7 @@ static_assert(sizeof(PkConsts) == sizeof(PkConstsArg), "PkConstsArg (mdct_kernel
 // statement that reads a VGPR written by the asm statement IMMEDIATELY before it the compiler inserts a wait state
 // (it cannot see inside and assumes the gfx940 dst_sel forwarding hazard): 64-76 s_nop per wave in the order the
 // formulas are usually written in.  The operations are therefore emitted so that none consumes its predecessor's
-// result (the textbook order and the statement-per-operation forms of the other passes: tools/pk_forms_textbook.h, for A/B runs).
+// result (the textbook order and the statement-per-operation forms of the other passes: tools/experiments/pk_forms_textbook.h, for A/B runs).
 template <int K1D>
 __device__ __forceinline__ void dct8_h(const PkConsts &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o13, f32x2 &o57)
 {

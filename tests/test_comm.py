@@ -98,6 +98,45 @@ def test_one_rank_rccl_through_the_cabi():
 
 
 @pytest.mark.gpu
+def test_one_rank_rccl_ragged_form_and_stereo_pieces(monkeypatch):
+    """The form ragged shards take -- every rank broadcasts its piece in place inside one RCCL group -- and the stereo layout's 64 grouped
+    pieces, through the REAL RCCL (one rank is all this box has; MDCT_FORCE_RAGGED_GATHER=1 selects the form, which world = 1 alone
+    never would): the symbols resolve, the calls are accepted with the arguments csrc/comm.hip passes, the buffer comes back intact.
+    (With several ranks the same code runs against tests/fake_rccl.c: tests/test_comm_multirank.py, world 2 / 3 / 8 incl. empty ranks.)"""
+    torch = pytest.importorskip("torch")
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    api.init(0)
+    comm = api.Comm(0, 1, api.comm_unique_id())
+    try:
+        monkeypatch.setenv("MDCT_FORCE_RAGGED_GATHER", "1")
+        W, H = 1024, 200  # 25 block rows: no multiple of anything
+        s16 = synth.plane_i16_np(W, H, "photo", seed=3)
+        d16 = torch.zeros((H, W), dtype=torch.int16, device="cuda")
+        api.fwd_i16(torch.from_numpy(s16).cuda(), d16, W, H)
+        want = d16.clone()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        for _ in range(3):
+            comm.allgather_rows(d16, 8 * W * 2, H // 8, stream=stream)  # grouped ncclBroadcast, root 0, in place
+        stream.synchronize()
+        assert torch.equal(d16, want) and np.array_equal(d16.cpu().numpy(), O.i16("fwd", s16, W, H))
+        Ws, Hs = 512, 208  # 13 stereo block rows
+        img = synth.plane_u8_np(Ws, Hs, "photo", seed=4)
+        lut8 = (api.QUANTIZE_BASE * np.float32(8)).astype(np.float32)
+        st = torch.zeros(Ws * Hs, dtype=torch.uint8, device="cuda")
+        api.fwd_quant_u8(torch.from_numpy(img).cuda(), st, lut8, Ws, Hs, 0, Hs // 16, layout=api.LAYOUT_STEREO, profile=api.PROFILE_REF_SSE)
+        for forced in ("1", "0"):  # 64 grouped broadcasts, then 64 grouped all-gathers
+            monkeypatch.setenv("MDCT_FORCE_RAGGED_GATHER", forced)
+            comm.allgather_stereo(st, Ws, Hs, stream=stream)
+            stream.synchronize()
+            rc, want8 = O.run_behaviour("stereo_sse", img, lut8, Ws, Hs, 0, Hs)
+            assert np.array_equal(st.cpu().numpy(), want8), forced
+    finally:
+        comm.close()
+
+
+@pytest.mark.gpu
 def test_cxx_cli_one_process_per_gpu(tmp_path):
     """tools/simd_dct_cli --gpus N: C++ host code, one forked process per GPU, the reference's own
     startY/endY shard hook, RCCL all-gather through the C-ABI; rank 0's gathered output is the oracle's"""

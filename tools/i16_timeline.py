@@ -1,4 +1,4 @@
-"""Analyse gpurun_out/i16_timeline.bin (tools/exp_u8_r3 timeline_i16): entry / stores issued / stores acknowledged per wave of the
+"""Analyse gpurun_out/i16_timeline.bin (tools/experiments/exp_u8_r3 timeline_i16): entry / stores issued / stores acknowledged per wave of the
 fused int16 round trip.  Prints the kernel span, per-SIMD wave counts and finish times, the life of a wave, how many waves
 are resident per SIMD over time and the rate at which waves complete over the kernel (fill, steady state, drain)."""
 import sys

@@ -1,4 +1,4 @@
-"""Analyse gpurun_out/q32_timeline.bin (tools/exp_u8_r3 timeline): per-wave phase stamps of the q32 kernel.
+"""Analyse gpurun_out/q32_timeline.bin (tools/experiments/exp_u8_r3 timeline): per-wave phase stamps of the q32 kernel.
 Phases: load = entry -> rows arrived; compute = -> transform done + bytes staged; store = -> stores issued; ack = -> acknowledged.
 Prints the distribution of each phase, the kernel span, and per SIMD how many of its resident waves are in the compute
 phase over time (the VALU has work only while that number is > 0; it saturates at about 3)."""
