@@ -315,6 +315,23 @@ def main():
             ms = timer.elapsed_ms() / n
             return {"ms": round(ms, 4), "GBps": round(bytes_per_launch / (ms * 1e-3) / 1e9, 1)}
 
+        side = torch.cuda.Stream()
+        probe_buf = torch.zeros(16, dtype=torch.int64, device="cuda")
+
+        def clock_under(fn, ms_per_launch, n=400):
+            """shader clock (GHz) the chip holds while `fn` runs back to back: mdct_clock_probe on a second stream beside n launches"""
+            try:
+                for i in range(60):
+                    fn(i)
+                M.clock_probe(probe_buf, max(1000, int(ms_per_launch * 1e5 * (n - 120) * 0.5)), waves=8, stream=side)
+                for i in range(60, n):
+                    fn(i)
+                torch.cuda.synchronize()
+                pr = probe_buf.cpu().numpy().reshape(8, 2)
+                return round(float((pr[:, 0] / (pr[:, 1] * 10.0)).mean()), 3)
+            except Exception:
+                return None
+
         nbytes = W * H * 2
         def prepared(make):
             calls = [make(i) for i in range(NSETS)]
@@ -356,7 +373,9 @@ def main():
                 lut = (M.QUANTIZE_BASE * np.float32(scale)).astype(np.float32)
                 for d in u8d:
                     d.zero_()
-                r = rate(prepared(lambda i: M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, rows, layout=layout, profile=profile)), 2 * W * H, n=500, warm=1500)
+                call = prepared(lambda i: M.prepare_fwd_quant_u8(u8s[i], u8d[i], lut, W, H, 0, rows, layout=layout, profile=profile))
+                r = rate(call, 2 * W * H, n=500, warm=1500)
+                r["clock_GHz"] = clock_under(call, r["ms"])
                 r["Mpx_s"] = round(W * H / (r["ms"] * 1e-3) / 1e6, 0)
                 r["kernel"], r["reference"] = kernel, refline
                 torch.cuda.synchronize()
@@ -388,6 +407,7 @@ def main():
             fpx = sum(w * h for (w, h, _, _) in synth.CONFIG3_PLANES)
             calls3 = [M.prepare_roundtrip_i16_planes(f) for f in frames]
             r = rate(lambda i: calls3[i % NSETS](), 4 * fpx, n=500, warm=1500)
+            r["clock_GHz"] = clock_under(lambda i: calls3[i % NSETS](), r["ms"])
             torch.cuda.synchronize()
             want = own_sha.get("config3_420", {})
             keys = [f"roundtrip__{w}x{h}__seed+{so}__{tab}" for (w, h, so, tab) in synth.CONFIG3_PLANES]
@@ -433,6 +453,7 @@ def main():
             dev8 = [M.Batch("roundtrip_u8", f) for f in frames8]
             pr8 = [b.prepared() for b in dev8]
             r = rate(lambda i: pr8[i % NF8](), 2 * fpx, n=600, warm=1500)
+            r["clock_GHz"] = clock_under(lambda i: pr8[i % NF8](), r["ms"])
             torch.cuda.synchronize()
             want = own_sha.get("config3_420_u8", {})
             keys = [f"roundtrip_u8__{w}x{h}__seed+{so}__{tab}" for (w, h, so, tab) in synth.CONFIG3_PLANES]
@@ -614,34 +635,67 @@ def main():
             try:
                 traffic = json.load(open(tr))
                 line["roofline"]["traffic"] = traffic.get("k_i16_roundtrip_bytes_per_launch")
-                line["roofline"]["traffic_source"] = "profiles/traffic.json (PMC passes of an earlier run of the same kernel, not counters of this run): " + traffic.get("source", "")
+                line["roofline"]["traffic_round"] = traffic.get("traffic_round")
+                line["roofline"]["traffic_source"] = "profiles/traffic.json (separate PMC passes of the same kernel on the same build, tools/profile_round5.sh; not counters of this run): " + traffic.get("source", "")
             except Exception:
                 pass
         if extras:
             line["extras"] = extras
             copy = extras.get("stream_copy_roofline", {}).get("GBps")
 
-            def u8_block(q, traffic_key=None):
+            try:
+                isa = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_classes.json")))["kernels"]
+                costs = json.load(open(os.path.join(ROOT, "profiles", "valu_issue_costs.json")))
+            except Exception:
+                isa, costs = {}, {}
+            pmc = traffic.get("kernels", {})
+
+            def valu(isa_name, waves, avg_ms, clock_ghz, pmc_key):
+                """the vector-ISSUE floor of a kernel: its static instruction mix (one wave's straight-line stream, profiles/r05_isa_classes.json) priced
+                at the issue cycles measured per class (profiles/valu_issue_costs.json) and at the clock the chip held under THIS kernel in THIS run"""
+                k = isa.get(isa_name)
+                if not k or not costs or not clock_ghz or not avg_ms:
+                    return None
+                cyc = sum(k[c] * costs["cycles"][c] for c in ("plain", "packed", "other"))
+                floor_ms = waves * cyc / (1024 * clock_ghz * 1e9) * 1e3
+                return {"insts_per_wave_static": {c: k[c] for c in ("plain", "packed", "other")}, "valu_insts_per_wave_static": k["valu"],
+                        "valu_insts_per_wave": pmc.get(pmc_key, {}).get("valu_insts_per_wave"), "waves_per_launch": waves,
+                        "issue_cycles_per_wave": round(cyc, 0), "issue_cycles_per_instruction": costs["cycles"], "clock_GHz_under_this_kernel": clock_ghz,
+                        "valu_floor_ms": round(floor_ms, 4), "frac_of_valu_floor": round(floor_ms / avg_ms, 3), "simds": 1024,
+                        "how": "valu_floor_ms = waves x sum(class count x measured issue cycles) / (1024 SIMDs x measured clock); counts: tools/isa_classes.py (static; "
+                               "valu_insts_per_wave is the PMC's SQ_INSTS_VALU / SQ_WAVES of tools/profile_round5.sh), cycles: tools/valubench2, clock: mdct_clock_probe beside the timed kernel"}
+
+            ISA_NAME = {"k_q32_avx": "mdct::k_q32_tile(mdct::U8Args)", "k_stereo_sse": "void mdct::k_fwd_quant_u8<1, 1, false, true>(mdct::U8Args)",
+                        "k_stereo_scalar": "void mdct::k_fwd_quant_u8<2, 1, false, true>(mdct::U8Args)", "k_encq_sse": "void mdct::k_fwd_quant_u8<1, 3, false, true>(mdct::U8Args)",
+                        "k_encq_scalar": "void mdct::k_fwd_quant_u8<2, 2, false, true>(mdct::U8Args)", "k_u8_batch_420": "void mdct::k_u8_batch<false, false>(mdct::BatchArgs)",
+                        "k_i16_batch_420": "void mdct::k_i16_batch<2, 1, false, false>(mdct::BatchArgs)", "k_i16_roundtrip": "void mdct::k_i16_tile<2, false, true, 2>(mdct::I16Args)"}
+
+            def u8_block(q, key=None):
                 # the reference's own products on the same plane size: 2 algorithmic bytes per pixel (SURVEY.md 8d)
                 if not q or "GBps" not in q:
                     return q
-                return {"bound": "hbm (co-limited by un-fusable fp32 VALU work, DESIGN.md 4.1)", "kernel": q["kernel"], "reference": q["reference"],
+                traffic_key = key + "_bytes_per_launch" if key else None
+                v = valu(ISA_NAME.get(key), (W // 8) * (H // 8) // 64, q["ms"], q.get("clock_GHz"), key)
+                return {"bound": "vector issue at the clock the chip holds under this kernel (valu.frac_of_valu_floor); the bytes alone would take algorithmic_bytes / measured copy rate",
+                        "valu": v, "traffic_round": traffic.get("traffic_round"), "kernel": q["kernel"], "reference": q["reference"],
                         "achieved": q["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(q["GBps"] / HBM_PEAK_GBPS, 4),
                         "frac_of_measured_copy": round(q["GBps"] / copy, 3) if copy else None,
                         "algorithmic_bytes_per_launch": 2 * W * H, "avg_launch_ms": q["ms"], "Mpx_s": q.get("Mpx_s"),
                         "traffic": traffic.get(traffic_key) if traffic_key else None,
-                        "traffic_source": ("profiles/traffic.json: " + traffic.get("source_u8", traffic.get("source", ""))) if traffic_key and traffic.get(traffic_key) else None,
+                        "traffic_source": ("profiles/traffic.json: " + traffic.get("source", "")) if traffic_key and traffic.get(traffic_key) else None,
                         "bit_exact_vs_reference": q.get("sha256_equals_real_reference"),
                         "verified_by": "SHA-256 of the whole output plane of the timed call == tests/golden/ref_vectors.json (bytes of the real reference)"}
 
             def own_block(q, kernel, alg_bytes, what, traffic_key=None, verified_key="sha256_equals_cpu_checker"):
+                # (traffic_key: "<kernel key>_bytes_per_launch" of profiles/traffic.json)
                 # engine-own kernels (no reference counterpart: "parity unpinned" by the reference, pinned by the CPU checker)
                 if not q or "GBps" not in q:
                     return q
                 return {"bound": "hbm", "kernel": kernel, "what": what, "achieved": q["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(q["GBps"] / HBM_PEAK_GBPS, 4),
                         "frac_of_measured_copy": round(q["GBps"] / copy, 3) if copy else None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": q["ms"],
                         "traffic": traffic.get(traffic_key) if traffic_key else None,
-                        "traffic_source": ("profiles/traffic.json: " + traffic.get("source_r04", traffic.get("source", ""))) if traffic_key and traffic.get(traffic_key) else None,
+                        "traffic_round": traffic.get("traffic_round"),
+                        "traffic_source": ("profiles/traffic.json: " + traffic.get("source", "")) if traffic_key and traffic.get(traffic_key) else None,
                         "bit_exact_vs_cpu_checker": q.get(verified_key),
                         "verified_by": "SHA-256 of the device output of the timed launches == tests/golden/engine_own_sha256.json (output of oracle/dct_oracle.c for the same synthetic planes)"}
 
@@ -653,6 +707,8 @@ def main():
                                                          "Y 7680x4320 + Cb/Cr 3840x2160, Annex-K tables, fused fwd+inv, ONE call (mdct_roundtrip_i16_planes) = one launch",
                                                          "k_i16_batch_420_bytes_per_launch")
                 line["roofline_config3_420"]["Mpx_s"] = c3.get("Mpx_s")
+                tiles3 = sum(((w // 8 + 63) // 64) * (h // 8) for (w, h, _, _) in synth.CONFIG3_PLANES)
+                line["roofline_config3_420"]["valu"] = valu(ISA_NAME["k_i16_batch_420"], tiles3, c3["ms"], c3.get("clock_GHz"), "k_i16_batch_420")
                 line["roofline_config3_420"]["device_table_form_ms"] = c3.get("device_table_form", {}).get("ms")
                 line["roofline_config3_420"]["forward_only_batch_ms"] = c3.get("forward_only_batch", {}).get("ms")
                 line["roofline_config3_420"]["four_frames_per_call_ms_per_frame"] = c3.get("four_frames_per_call_ms_per_frame")
@@ -664,7 +720,9 @@ def main():
                                 "BASELINE.json configs[2] as SURVEY.md 8(d) defines it: Y 7680x4320 + Cb/Cr 3840x2160 8-bit planes in, 8-bit planes out, Annex-K tables, "
                                 "forward -> quantise -> dequantise -> inverse fused, ONE call (mdct_batch_run of mdct_batch_create_u8) = one launch",
                                 "k_u8_batch_420_bytes_per_launch")
-                blk["bound"] = "vector issue (the bytes alone would take 99.5 MB / measured copy rate; valu_floor_ms below), DESIGN.md 4.2b"
+                blk["bound"] = "vector issue at the clock the chip holds under this kernel (valu.frac_of_valu_floor); the bytes alone would take 99.5 MB / measured copy rate, DESIGN.md 4.2b"
+                tiles3 = sum(((w // 8 + 63) // 64) * (h // 8) for (w, h, _, _) in synth.CONFIG3_PLANES)
+                blk["valu"] = valu(ISA_NAME["k_u8_batch_420"], tiles3, c3u["ms"], c3u.get("clock_GHz"), "k_u8_batch_420")
                 blk["parity"] = "unpinned by the reference (it has no inverse); pinned by the CPU checker's composition orc_fwd_u8_i16 -> orc_inv_i16_u8 and equal to the two-call path on the device (tests/test_u8_roundtrip.py)"
                 for k in ("Mpx_s", "launches_per_call", "kernel_argument_form", "kernel_argument_form_equals_device_table_form", "four_frames_per_call_ms_per_frame", "y_plane_two_calls_ms", "y_plane_fused_ms"):
                     blk[k] = c3u.get(k)
@@ -691,13 +749,13 @@ def main():
                         blk[k] = {"ms": c4[k]["ms"], "GBps": c4[k]["GBps"], "frac": round(c4[k]["GBps"] / HBM_PEAK_GBPS, 4)}
                 line["roofline_config4_one_gpu"] = blk
             if "GBps" in extras.get("fwd_quant_u8_q32", {}):
-                line["roofline_u8"] = u8_block(extras["fwd_quant_u8_q32"], "k_q32_avx_bytes_per_launch")
+                line["roofline_u8"] = u8_block(extras["fwd_quant_u8_q32"], "k_q32_avx")
             if "GBps" in extras.get("fwd_quant_u8_stereo_sse", {}):
-                line["roofline_stereo"] = u8_block(extras["fwd_quant_u8_stereo_sse"], "k_stereo_sse_bytes_per_launch")
-                line["roofline_stereo"]["scalar_tier"] = u8_block(extras.get("fwd_quant_u8_stereo_scalar"), "k_stereo_scalar_bytes_per_launch")
+                line["roofline_stereo"] = u8_block(extras["fwd_quant_u8_stereo_sse"], "k_stereo_sse")
+                line["roofline_stereo"]["scalar_tier"] = u8_block(extras.get("fwd_quant_u8_stereo_scalar"), "k_stereo_scalar")
             if "GBps" in extras.get("fwd_quant_u8_encq_sse", {}):
-                line["roofline_encq"] = u8_block(extras["fwd_quant_u8_encq_sse"], "k_encq_sse_bytes_per_launch")
-                line["roofline_encq"]["scalar_tier"] = u8_block(extras.get("fwd_quant_u8_encq_scalar"), "k_encq_scalar_bytes_per_launch")
+                line["roofline_encq"] = u8_block(extras["fwd_quant_u8_encq_sse"], "k_encq_sse")
+                line["roofline_encq"]["scalar_tier"] = u8_block(extras.get("fwd_quant_u8_encq_scalar"), "k_encq_scalar")
                 # the SSE encq tier writes only half of every block pair (simd_dct.cpp:1662-1676): `frac` above charges the layout's
                 # nominal 2 B/px; on the bytes the tier really moves (1 B/px in + 0.5 B/px out + the one spill) it is lower
                 moved = W * H + W * H // 2 + 64

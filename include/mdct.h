@@ -364,6 +364,11 @@ enum
 };
 int mdct_table_cache_stats(uint64_t *stats, int n);
 
+/* Shader-clock probe (diagnostics): `waves` one-wave workgroups each spin for `ticks_100MHz` ticks of the constant 100 MHz counter and write
+ * (shader cycles elapsed, ticks elapsed) to out[2 * w], out[2 * w + 1] (device memory, 16 * waves bytes).  Launched on a second stream
+ * beside a workload it reports the clock the chip holds under that workload: cycles * 100 / ticks MHz.  ticks_100MHz <= 10^7 (0.1 s). */
+int mdct_clock_probe(uint64_t *out, uint32_t ticks_100MHz, uint32_t waves, void *stream);
+
 /* Measured-roofline helper for bench tools: a read-N/write-N 16 B/lane stream copy on
  * the same stream (what "HBM roofline" means on this box). */
 int mdct_stream_copy(const void *from, void *to, size_t bytes, void *stream);

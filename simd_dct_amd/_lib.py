@@ -101,6 +101,7 @@ SIGNATURES = {
     "mdct_allgather_rows": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mdct_allgather_stereo": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mdct_table_cache_stats": (c_int, [ctypes.POINTER(ctypes.c_uint64), c_int]),
+    "mdct_clock_probe": (c_int, [c_void_p, ctypes.c_uint32, ctypes.c_uint32, c_void_p]),
     "mdct_stream_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdct_timer_create": (c_void_p, []),
     "mdct_timer_destroy": (None, [c_void_p]),

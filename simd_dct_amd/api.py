@@ -573,6 +573,11 @@ def table_cache_stats():
     return dict(zip(("hits", "uploads", "evictions", "from_arguments", "stream_waits"), [int(v) for v in a]))
 
 
+def clock_probe(out, ticks_100MHz, waves=8, stream=None):
+    """mdct_clock_probe: `out` = int64 device tensor of 2 * waves entries (shader cycles, 100 MHz ticks) per wave"""
+    _check(_lib.load().mdct_clock_probe(_ptr(out), int(ticks_100MHz), int(waves), _stream(stream)))
+
+
 def prepare_stream_copy(src, dst, nbytes, stream=None):
     lib = _lib.load()
     return Prepared(lib.mdct_stream_copy, (ctypes.c_void_p(_ptr(src)), ctypes.c_void_p(_ptr(dst)), ctypes.c_size_t(nbytes), _stream(stream)), (src, dst))

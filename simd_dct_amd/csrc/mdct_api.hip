@@ -1215,6 +1215,18 @@ int mdct_table_cache_stats(uint64_t *stats, int n)
   return MDCT_SUCCESS;
 }
 
+int mdct_clock_probe(uint64_t *out, uint32_t ticks_100MHz, uint32_t waves, void *stream)
+{
+  if (out == nullptr || waves == 0 || waves > 65536 || ticks_100MHz == 0 || ticks_100MHz > 10000000u)
+    return fail(MDCT_INVALID_PARAMETER, "clock probe: null output, 0 or more than 65536 waves, or more than 10^7 ticks");
+  const mdct_device_info *di;
+  const int r = current(&di);
+  if (r)
+    return r;
+  const hipError_t e = mdct::launch_clock_probe(reinterpret_cast<unsigned long long *>(out), ticks_100MHz, waves, (hipStream_t)stream);
+  return e == hipSuccess ? MDCT_SUCCESS : hip_fail(e, "clock probe launch");
+}
+
 int mdct_stream_copy(const void *from, void *to, size_t bytes, void *stream)
 {
   if (from == nullptr || to == nullptr)

@@ -197,6 +197,7 @@ hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s, boo
 hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, bool clamp, uint32_t n_rows, hipStream_t s);
 hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s);
 hipError_t launch_park_table(const OwnTables &tb, OwnTables *slot, hipStream_t s); // table cache upload (mdct_api.hip)
+hipError_t launch_clock_probe(unsigned long long *out, unsigned int ticks, unsigned int waves, hipStream_t s); // diagnostics
 hipError_t launch_stream_copy(const void *from, void *to, size_t bytes, int cus, hipStream_t s);
 
 } // namespace mdct

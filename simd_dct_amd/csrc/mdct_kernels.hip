@@ -1113,9 +1113,10 @@ static_assert(offsetof(DctConsts, c707) == 0 && offsetof(DctConsts, c382) == 4 &
 #define MDCT_LOHI "op_sel:[0,1] op_sel_hi:[0,1]" // src0.lo with src1.hi, for both halves
 #define MDCT_HILO "op_sel:[1,0] op_sel_hi:[1,0]"
 #define MDCT_SUMDIFF "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" // (a.lo + a.hi, a.lo - a.hi) when both sources are a
+#define MDCT_XSEL " op_sel:[0,1] op_sel_hi:[1,0]"              // lo = a.lo (+) b.hi, hi = a.hi (+) b.lo (MDCT_X inside a block)
 
 // forward, one line in natural pairs (p0,p1)(p2,p3)(p4,p5)(p6,p7) -> (y0,y4) (y2,y6) (y5,y3) (y1,y7)
-__device__ __forceinline__ void aan_fwd_h(const AanPk &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o53, f32x2 &o17)
+__device__ __forceinline__ void aan_fwd_h_stmt(const AanPk &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o53, f32x2 &o17)
 {
   f32x2 t01, t23, t76, t54, e01, e32, w, o, z13, z24, z1113;
   MDCT_PKA(t01, a01, a67, MDCT_X);                   // (t0, t1) = (p0+p7, p1+p6)
@@ -1141,7 +1142,7 @@ __device__ __forceinline__ void aan_fwd_h(const AanPk &K, f32x2 a01, f32x2 a23, 
 }
 
 // forward down a pair of columns, in place (direct image of aan_fwd8)
-__device__ __forceinline__ void aan_fwd_v(const AanPk &K, f32x2 (&p)[8])
+__device__ __forceinline__ void aan_fwd_v_stmt(const AanPk &K, f32x2 (&p)[8])
 {
   f32x2 t0, t7, t1, t6, t2, t5, t3, t4, e10, e13, e11, e12, z1, o10, o11, o12, z5, z2, z4, z3, z11, z13;
   MDCT_PKA(t0, p[0], p[7], ""); MDCT_PKA(t7, p[0], p[7], MDCT_NEG_B); MDCT_PKA(t1, p[1], p[6], ""); MDCT_PKA(t6, p[1], p[6], MDCT_NEG_B);
@@ -1161,7 +1162,7 @@ __device__ __forceinline__ void aan_fwd_v(const AanPk &K, f32x2 (&p)[8])
 }
 
 // inverse down a pair of columns, in place (direct image of aan_inv8)
-__device__ __forceinline__ void aan_inv_v(const AanPk &K, f32x2 (&p)[8])
+__device__ __forceinline__ void aan_inv_v_stmt(const AanPk &K, f32x2 (&p)[8])
 {
   f32x2 e10, e11, e13, e12, t0, t3, t1, t2, z13, z10, z11, z12, t7, o11, z5, o10, o12, t6, t5, t4, m;
   MDCT_PKA(e10, p[0], p[4], ""); MDCT_PKA(e11, p[0], p[4], MDCT_NEG_B);
@@ -1182,7 +1183,7 @@ __device__ __forceinline__ void aan_inv_v(const AanPk &K, f32x2 (&p)[8])
 }
 
 // inverse, one line given as (c0,c4) (c2,c6) (c5,c3) (c1,c7) -> (x0,x7) (x1,x6) (x2,x5) (x4,x3)
-__device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, f32x2 i53, f32x2 i17, f32x2 &o07, f32x2 &o16, f32x2 &o25, f32x2 &o43)
+__device__ __forceinline__ void aan_inv_h_stmt(const AanPk &K, f32x2 i04, f32x2 i26, f32x2 i53, f32x2 i17, f32x2 &o07, f32x2 &o16, f32x2 &o25, f32x2 &o43)
 {
   f32x2 e, f, t03, t12, z3, z1, td, u, v;
   MDCT_PKA(e, i04, i04, MDCT_SUMDIFF);                    // (e10, e11) = (c0+c4, c0-c4)
@@ -1206,6 +1207,222 @@ __device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, 
   MDCT_PKA(o43, t03, v, MDCT_HILO " neg_hi:[0,1]");     // (t3+t4, t3-t4)
 }
 
+
+// ---------------------------------------------------------------------------------------
+// The same four passes as ASM BLOCKS (round 5).  One asm statement per operation costs wait states the hardware does not need: for an asm
+// statement that reads a VGPR written by the asm statement right before it the compiler inserts an s_nop (it cannot see inside and assumes
+// the gfx940 dst_sel forwarding hazard, which a v_pk_*_f32 does not have) -- 97 of them per wave in k_u8_batch, 60-70 in the int16 round
+// trip, each an issue slot.  The column passes are pure packed sequences: one block of 34 instructions each, registers allocated by hand,
+// results left in a PERMUTATION of the input registers (renaming is free for the caller).  The row passes keep their 6 / 12 unpaired scalar
+// operations as compiler-visible code (an inline-asm operand cannot name half of a register pair) between two blocks of packed operations.
+// Same operations, same operands, same order of operands in every subtraction as the _stmt forms above (MDCT_AAN_BLOCKS=0 builds those).
+// ---------------------------------------------------------------------------------------
+#ifndef MDCT_AAN_BLOCKS
+#define MDCT_AAN_BLOCKS 1
+#endif
+#define MDCT_SUB " neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define MDCT_KLO " op_sel:[0,0] op_sel_hi:[1,0]\n\t" // times the constant pair's low half, both halves
+#define MDCT_KHI " op_sel:[0,1] op_sel_hi:[1,1]\n\t" // times its high half
+
+__device__ __forceinline__ void aan_fwd_v(const AanPk &K, f32x2 (&p)[8])
+{
+#if !MDCT_AAN_BLOCKS
+  aan_fwd_v_stmt(K, p);
+#else
+  f32x2 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3], r4 = p[4], r5 = p[5], r6 = p[6], r7 = p[7], T;
+  asm("v_pk_add_f32 %8, %0, %7\n\t"            /* T  = t0 = p0 + p7 */
+      "v_pk_add_f32 %7, %0, %7" MDCT_SUB       /* r7 = t7 = p0 - p7 */
+      "v_pk_add_f32 %0, %1, %6\n\t"            /* r0 = t1 */
+      "v_pk_add_f32 %6, %1, %6" MDCT_SUB       /* r6 = t6 */
+      "v_pk_add_f32 %1, %2, %5\n\t"            /* r1 = t2 */
+      "v_pk_add_f32 %5, %2, %5" MDCT_SUB       /* r5 = t5 */
+      "v_pk_add_f32 %2, %3, %4\n\t"            /* r2 = t3 */
+      "v_pk_add_f32 %4, %3, %4" MDCT_SUB       /* r4 = t4 */
+      "v_pk_add_f32 %3, %8, %2\n\t"            /* r3 = e10 = t0 + t3 */
+      "v_pk_add_f32 %2, %8, %2" MDCT_SUB       /* r2 = e13 = t0 - t3 */
+      "v_pk_add_f32 %8, %0, %1\n\t"            /* T  = e11 = t1 + t2 */
+      "v_pk_add_f32 %1, %0, %1" MDCT_SUB       /* r1 = e12 = t1 - t2 */
+      "v_pk_add_f32 %0, %3, %8\n\t"            /* r0 = out0 = e10 + e11 */
+      "v_pk_add_f32 %8, %3, %8" MDCT_SUB       /* T  = out4 = e10 - e11 */
+      "v_pk_add_f32 %3, %1, %2\n\t"            /* r3 = e12 + e13 */
+      "v_pk_add_f32 %1, %4, %5\n\t"            /* r1 = o10 = t4 + t5            (e12 is dead) */
+      "v_pk_mul_f32 %3, %3, %9" MDCT_KLO       /* r3 = z1 = (e12 + e13) c707 */
+      "v_pk_add_f32 %4, %5, %6\n\t"            /* r4 = o11 = t5 + t6 */
+      "v_pk_add_f32 %5, %6, %7\n\t"            /* r5 = o12 = t6 + t7 */
+      "v_pk_add_f32 %6, %2, %3" MDCT_SUB       /* r6 = out6 = e13 - z1 */
+      "v_pk_add_f32 %2, %2, %3\n\t"            /* r2 = out2 = e13 + z1 */
+      "v_pk_add_f32 %3, %1, %5" MDCT_SUB       /* r3 = o10 - o12 */
+      "v_pk_mul_f32 %4, %4, %9" MDCT_KLO       /* r4 = z3 = o11 c707 */
+      "v_pk_mul_f32 %3, %3, %9" MDCT_KHI       /* r3 = z5 = (o10 - o12) c382 */
+      "v_pk_mul_f32 %1, %1, %10" MDCT_KLO      /* r1 = c541 o10 */
+      "v_pk_mul_f32 %5, %5, %10" MDCT_KHI      /* r5 = c1306 o12 */
+      "v_pk_add_f32 %1, %1, %3\n\t"            /* r1 = z2 */
+      "v_pk_add_f32 %5, %5, %3\n\t"            /* r5 = z4 */
+      "v_pk_add_f32 %3, %7, %4\n\t"            /* r3 = z11 = t7 + z3 */
+      "v_pk_add_f32 %7, %7, %4" MDCT_SUB       /* r7 = z13 = t7 - z3 */
+      "v_pk_add_f32 %4, %7, %1\n\t"            /* r4 = out5 = z13 + z2 */
+      "v_pk_add_f32 %7, %7, %1" MDCT_SUB       /* r7 = out3 = z13 - z2 */
+      "v_pk_add_f32 %1, %3, %5\n\t"            /* r1 = out1 = z11 + z4 */
+      "v_pk_add_f32 %3, %3, %5 neg_lo:[0,1] neg_hi:[0,1]" /* r3 = out7 = z11 - z4 */
+      : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "=&v"(T)
+      : "s"(K.c707_382), "s"(K.c541_1306));
+  p[0] = r0; p[1] = r1; p[2] = r2; p[3] = r7; p[4] = T; p[5] = r4; p[6] = r6; p[7] = r3;
+#endif
+}
+
+__device__ __forceinline__ void aan_inv_v(const AanPk &K, f32x2 (&p)[8])
+{
+#if !MDCT_AAN_BLOCKS
+  aan_inv_v_stmt(K, p);
+#else
+  f32x2 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3], r4 = p[4], r5 = p[5], r6 = p[6], r7 = p[7], T;
+  asm("v_pk_add_f32 %8, %0, %4\n\t"            /* T  = e10 = p0 + p4 */
+      "v_pk_add_f32 %4, %0, %4" MDCT_SUB       /* r4 = e11 = p0 - p4 */
+      "v_pk_add_f32 %0, %2, %6\n\t"            /* r0 = e13 = p2 + p6 */
+      "v_pk_add_f32 %6, %2, %6" MDCT_SUB       /* r6 = p2 - p6 */
+      "v_pk_add_f32 %2, %5, %3\n\t"            /* r2 = z13 = p5 + p3 */
+      "v_pk_add_f32 %3, %5, %3" MDCT_SUB       /* r3 = z10 = p5 - p3 */
+      "v_pk_mul_f32 %6, %6, %9" MDCT_KLO       /* r6 = (p2 - p6) c1414 */
+      "v_pk_add_f32 %5, %1, %7\n\t"            /* r5 = z11 = p1 + p7 */
+      "v_pk_add_f32 %7, %1, %7" MDCT_SUB       /* r7 = z12 = p1 - p7 */
+      "v_pk_add_f32 %6, %6, %0" MDCT_SUB       /* r6 = e12 = (p2 - p6) c1414 - e13 */
+      "v_pk_add_f32 %1, %5, %2\n\t"            /* r1 = t7 = z11 + z13 */
+      "v_pk_add_f32 %5, %5, %2" MDCT_SUB       /* r5 = z11 - z13 */
+      "v_pk_add_f32 %2, %3, %7\n\t"            /* r2 = z10 + z12 */
+      "v_pk_mul_f32 %5, %5, %9" MDCT_KLO       /* r5 = o11 = (z11 - z13) c1414 */
+      "v_pk_mul_f32 %2, %2, %9" MDCT_KHI       /* r2 = z5 = (z10 + z12) c1847 */
+      "v_pk_mul_f32 %7, %7, %10" MDCT_KLO      /* r7 = c1082 z12 */
+      "v_pk_mul_f32 %3, %3, %10" MDCT_KHI      /* r3 = c2613 z10 */
+      "v_pk_add_f32 %7, %7, %2" MDCT_SUB       /* r7 = o10 = c1082 z12 - z5 */
+      "v_pk_add_f32 %3, %2, %3" MDCT_SUB       /* r3 = o12 = z5 - c2613 z10 */
+      "v_pk_add_f32 %2, %8, %0\n\t"            /* r2 = t0 = e10 + e13 */
+      "v_pk_add_f32 %0, %8, %0" MDCT_SUB       /* r0 = t3 = e10 - e13 */
+      "v_pk_add_f32 %3, %3, %1" MDCT_SUB       /* r3 = t6 = o12 - t7 */
+      "v_pk_add_f32 %8, %4, %6\n\t"            /* T  = t1 = e11 + e12 */
+      "v_pk_add_f32 %6, %4, %6" MDCT_SUB       /* r6 = t2 = e11 - e12 */
+      "v_pk_add_f32 %5, %5, %3" MDCT_SUB       /* r5 = t5 = o11 - t6 */
+      "v_pk_add_f32 %4, %2, %1\n\t"            /* r4 = out0 = t0 + t7 */
+      "v_pk_add_f32 %2, %2, %1" MDCT_SUB       /* r2 = out7 = t0 - t7 */
+      "v_pk_add_f32 %7, %7, %5\n\t"            /* r7 = t4 = o10 + t5 */
+      "v_pk_add_f32 %1, %8, %3\n\t"            /* r1 = out1 = t1 + t6 */
+      "v_pk_add_f32 %8, %8, %3" MDCT_SUB       /* T  = out6 = t1 - t6 */
+      "v_pk_add_f32 %3, %6, %5\n\t"            /* r3 = out2 = t2 + t5 */
+      "v_pk_add_f32 %6, %6, %5" MDCT_SUB       /* r6 = out5 = t2 - t5 */
+      "v_pk_add_f32 %5, %0, %7\n\t"            /* r5 = out4 = t3 + t4 */
+      "v_pk_add_f32 %0, %0, %7 neg_lo:[0,1] neg_hi:[0,1]" /* r0 = out3 = t3 - t4 */
+      : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "=&v"(T)
+      : "s"(K.c1414_1847), "s"(K.c1082_2613));
+  p[0] = r4; p[1] = r1; p[2] = r3; p[3] = r0; p[4] = r5; p[5] = r6; p[6] = T; p[7] = r2;
+#endif
+}
+
+// forward, one line in natural pairs (p0,p1)(p2,p3)(p4,p5)(p6,p7) -> (y0,y4) (y2,y6) (y5,y3) (y1,y7)
+__device__ __forceinline__ void aan_fwd_h(const AanPk &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o53, f32x2 &o17)
+{
+#if !MDCT_AAN_BLOCKS
+  aan_fwd_h_stmt(K, a01, a23, a45, a67, o04, o26, o53, o17);
+#else
+  f32x2 T0, T1;
+  asm("v_pk_add_f32 %4, %0, %3" MDCT_XSEL "\n\t"                               /* T0 = (t0, t1) = (p0+p7, p1+p6) */
+      "v_pk_add_f32 %5, %1, %2" MDCT_XSEL "\n\t"                               /* T1 = (t2, t3) = (p2+p5, p3+p4) */
+      "v_pk_add_f32 %0, %0, %3" MDCT_XSEL " neg_lo:[0,1] neg_hi:[0,1]\n\t"     /* A  = (t7, t6) = (p0-p7, p1-p6) */
+      "v_pk_add_f32 %1, %1, %2" MDCT_XSEL " neg_lo:[0,1] neg_hi:[0,1]\n\t"     /* B  = (t5, t4) = (p2-p5, p3-p4) */
+      "v_pk_add_f32 %2, %4, %5" MDCT_XSEL "\n\t"                               /* C  = (e10, e11) = (t0+t3, t1+t2) */
+      "v_pk_add_f32 %3, %4, %5" MDCT_XSEL " neg_lo:[0,1] neg_hi:[0,1]\n\t"     /* D  = (e13, e12) = (t0-t3, t1-t2) */
+      "v_pk_add_f32 %4, %2, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]"      /* T0 = (e10+e11, e10-e11) */
+      : "+v"(a01), "+v"(a23), "+v"(a45), "+v"(a67), "=&v"(T0), "=&v"(T1));
+  const f32x2 t76 = a01, t54 = a23, e32 = a67;
+  o04 = T0;
+  f32x2 w, o, z5;
+  w.x = e32.y + e32.x;                               // e12 + e13
+  w.y = t54.x + t76.y;                               // o11 = t5 + t6
+  o.x = t54.y + t54.x;                               // o10 = t4 + t5
+  o.y = t76.y + t76.x;                               // o12 = t6 + t7
+  z5.x = (o.x - o.y) * K.c707_382.y;                 // z5 = (o10 - o12) * c382
+  z5.y = z5.x;
+  f32x2 T;
+  asm("v_pk_mul_f32 %0, %0, %8 op_sel:[0,0] op_sel_hi:[1,0]\n\t"              /* w  = (z1, z3) = (e12+e13, o11) c707 */
+      "v_pk_mul_f32 %1, %1, %9 op_sel:[0,0] op_sel_hi:[1,1]\n\t"              /* o  = (c541 o10, c1306 o12) */
+      "v_pk_add_f32 %1, %1, %7 op_sel:[0,0] op_sel_hi:[1,0]\n\t"              /* o  = (z2, z4) = (.. + z5, .. + z5) */
+      "v_pk_add_f32 %2, %5, %0 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t" /* T  = (z11, z13) = (t7+z3, t7-z3) */
+      "v_pk_add_f32 %3, %6, %0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t" /* o26 = (e13+z1, e13-z1) */
+      "v_pk_add_f32 %4, %2, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]\n\t" /* o53 = (z13+z2, z13-z2) */
+      "v_pk_add_f32 %2, %2, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]"     /* T -> o17 = (z11+z4, z11-z4) */
+      : "+v"(w), "+v"(o), "=&v"(T), "=&v"(o26), "=&v"(o53)
+      : "v"(t76), "v"(e32), "v"(z5), "s"(K.c707_382), "s"(K.c541_1306));
+  o17 = T;
+#endif
+}
+
+// inverse, one line given as (c0,c4) (c2,c6) (c5,c3) (c1,c7) -> (x0,x7) (x1,x6) (x2,x5) (x4,x3)
+__device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, f32x2 i53, f32x2 i17, f32x2 &o07, f32x2 &o16, f32x2 &o25, f32x2 &o43)
+{
+#if !MDCT_AAN_BLOCKS
+  aan_inv_h_stmt(K, i04, i26, i53, i17, o07, o16, o25, o43);
+#else
+  f32x2 td;
+  asm("v_pk_add_f32 %0, %0, %0 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"  /* e  = (e10, e11) = (c0+c4, c0-c4) */
+      "v_pk_add_f32 %1, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"  /* f  = (e13, c2-c6) */
+      "v_pk_add_f32 %2, %2, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"  /* z3 = (z13, z10) = (c5+c3, c5-c3) */
+      "v_pk_add_f32 %3, %3, %3 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"  /* z1 = (z11, z12) = (c1+c7, c1-c7) */
+      "v_pk_add_f32 %4, %3, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]"      /* td = (t7, z11-z13) */
+      : "+v"(i04), "+v"(i26), "+v"(i53), "+v"(i17), "=&v"(td));
+  f32x2 f = i26, u;
+  f.y = (f.y * K.c1414_1847.x) - f.x;                    // e12 = (c2-c6)*sqrt2 - e13
+  const float o11 = td.y * K.c1414_1847.x;
+  const float z5 = (i53.y + i17.y) * K.c1414_1847.y;     // (z10 + z12) * c1847
+  const float o10 = (K.c1082_2613.x * i17.y) - z5;
+  const float o12 = z5 - (K.c1082_2613.y * i53.y);
+  u.x = o12 - td.x;                                      // t6
+  u.y = o11 - u.x;                                       // t5
+  td.y = o10 + u.y;                                      // t4 (o11 is dead: its half of td carries t4 into the block below)
+  f32x2 t03, t12;
+  asm("v_pk_add_f32 %4, %6, %7 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"  /* t03 = (t0, t3) = (e10+e13, e10-e13) */
+      "v_pk_add_f32 %5, %6, %7 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"  /* t12 = (t1, t2) = (e11+e12, e11-e12) */
+      "v_pk_add_f32 %0, %4, %8 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"  /* o07 = (t0+t7, t0-t7) */
+      "v_pk_add_f32 %3, %4, %8 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"  /* o43 = (t3+t4, t3-t4) */
+      "v_pk_add_f32 %1, %5, %9 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"  /* o16 = (t1+t6, t1-t6) */
+      "v_pk_add_f32 %2, %5, %9 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]"      /* o25 = (t2+t5, t2-t5) */
+      : "=&v"(o07), "=&v"(o16), "=&v"(o25), "=&v"(o43), "=&v"(t03), "=&v"(t12)
+      : "v"(i04), "v"(f), "v"(td), "v"(u));
+#endif
+}
+
+// quantise -> dequantise of the eight pairs of one column pair, SAT-free: c = rne(y qf) by the magic add and subtract, z = c dq
+__device__ __forceinline__ void quant_dequant8(const AanPk &K, f32x2 (&p)[8], const f32x2 (&qf)[8], const f32x2 (&dq)[8])
+{
+#define MDCT_Q8(OP, A, B, MOD) OP " %0, %0, " A "0" B MOD OP " %1, %1, " A "1" B MOD OP " %2, %2, " A "2" B MOD OP " %3, %3, " A "3" B MOD OP " %4, %4, " A "4" B MOD OP " %5, %5, " A "5" B MOD OP " %6, %6, " A "6" B MOD OP " %7, %7, " A "7" B MOD
+  asm("v_pk_mul_f32 %0, %0, %8 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %1, %1, %9 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %2, %2, %10 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %3, %3, %11 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %4, %4, %12 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %5, %5, %13 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %6, %6, %14 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %7, %7, %15 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_add_f32 %0, %0, %24" MDCT_KLO "v_pk_add_f32 %1, %1, %24" MDCT_KLO "v_pk_add_f32 %2, %2, %24" MDCT_KLO "v_pk_add_f32 %3, %3, %24" MDCT_KLO
+      "v_pk_add_f32 %4, %4, %24" MDCT_KLO "v_pk_add_f32 %5, %5, %24" MDCT_KLO "v_pk_add_f32 %6, %6, %24" MDCT_KLO "v_pk_add_f32 %7, %7, %24" MDCT_KLO
+      "v_pk_add_f32 %0, %0, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %1, %1, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %2, %2, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %3, %3, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %4, %4, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %5, %5, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %6, %6, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %7, %7, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %0, %0, %16 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %1, %1, %17 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %2, %2, %18 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %3, %3, %19 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %4, %4, %20 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %5, %5, %21 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %6, %6, %22 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %7, %7, %23 op_sel:[0,0] op_sel_hi:[1,1]"
+      : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7])
+      : "s"(qf[0]), "s"(qf[1]), "s"(qf[2]), "s"(qf[3]), "s"(qf[4]), "s"(qf[5]), "s"(qf[6]), "s"(qf[7]), "s"(dq[0]), "s"(dq[1]), "s"(dq[2]), "s"(dq[3]), "s"(dq[4]), "s"(dq[5]),
+        "s"(dq[6]), "s"(dq[7]), "v"(K.magic));
+#undef MDCT_Q8
+}
 
 // Fused round trip on packed fp32: forward rows (h), forward columns (v), [quantise -> dequantise], inverse columns (v),
 // inverse rows (h).  With a table, `tb` holds the multipliers in the pair order of the column pass,
@@ -1234,6 +1451,35 @@ __device__ __forceinline__ kbytes_t const_bytes(const void *p)
   const uint64_t v = (uint64_t)p;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return (kbytes_t)(((uint64_t)hi << 32) | lo);
+}
+
+// c = sat_i16(rne(y * qf)); z = c * dq on the eight pairs of column pair j; tq / td: the pairs' multipliers (scalar loads)
+template <bool SAT>
+__device__ __forceinline__ void quant_dequant_pairs(const AanPk &K, f32x2 (&p)[8], karg_pairs_t tq, karg_pairs_t td)
+{
+  if constexpr (!SAT && MDCT_AAN_BLOCKS)
+  {
+    const f32x2 qf[8] = {tq[0], tq[1], tq[2], tq[3], tq[4], tq[5], tq[6], tq[7]}, dq[8] = {td[0], td[1], td[2], td[3], td[4], td[5], td[6], td[7]};
+    quant_dequant8(K, p, qf, dq);
+  }
+  else
+  {
+#pragma unroll
+    for (int v = 0; v < 8; v++)
+    {
+      const f32x2 qf = tq[v], dq = td[v];
+      f32x2 m;
+      MDCT_PKM(m, p[v], qf, MDCT_K_LH);
+      if constexpr (SAT)
+      {
+        m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
+        m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
+      }
+      MDCT_PKA(m, m, K.magic, MDCT_K_LL);
+      MDCT_PKA(m, m, K.magic, MDCT_K_LL " " MDCT_NEG_B);
+      MDCT_PKM(p[v], m, dq, MDCT_K_LH);
+    }
+  }
 }
 
 // (A wave that walks 2 / 4 / 8 consecutive tiles and issues the next tile's row loads between the row pass and the column pass,
@@ -1267,21 +1513,7 @@ __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Row
     { // c = sat_i16(rne(y * qf)); z = c * dq  (rne_i16_float), on both halves
       karg_pairs_t tq = (karg_pairs_t)(tbp + offsetof(OwnTables, qf)) + j * 8, td = (karg_pairs_t)(tbp + offsetof(OwnTables, dq)) + j * 8;
       asm volatile("" : "+s"(tq), "+s"(td));
-#pragma unroll
-      for (int v = 0; v < 8; v++)
-      {
-        const f32x2 qf = tq[v], dq = td[v];
-        f32x2 m;
-        MDCT_PKM(m, P[j][v], qf, MDCT_K_LH);
-        if constexpr (SAT)
-        {
-          m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
-          m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
-        }
-        MDCT_PKA(m, m, K.magic, MDCT_K_LL);
-        MDCT_PKA(m, m, K.magic, MDCT_K_LL " " MDCT_NEG_B);
-        MDCT_PKM(P[j][v], m, dq, MDCT_K_LH);
-      }
+      quant_dequant_pairs<SAT>(K, P[j], tq, td);
     }
     aan_inv_v(K, P[j]);
   }
@@ -1497,21 +1729,7 @@ __device__ __forceinline__ void u8_roundtrip_rows(const DctConsts &C, const f32x
       P[0][0].x = P[0][0].x - shift_magic.x; // the level shift is exactly "raw DC minus 64 * 128"
     karg_pairs_t tq = (karg_pairs_t)(tbp + offsetof(OwnTables, qf)) + j * 8, td = (karg_pairs_t)(tbp + offsetof(OwnTables, dq)) + j * 8;
     asm volatile("" : "+s"(tq), "+s"(td)); // two s_load_dwordx16 per j, right where they are used (i16_roundtrip_rows)
-#pragma unroll
-    for (int v = 0; v < 8; v++)
-    {
-      const f32x2 qf = tq[v], dq = td[v];
-      f32x2 m;
-      MDCT_PKM(m, P[j][v], qf, MDCT_K_LH);
-      if constexpr (SAT)
-      {
-        m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
-        m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
-      }
-      MDCT_PKA(m, m, K.magic, MDCT_K_LL);
-      MDCT_PKA(m, m, K.magic, MDCT_K_LL " " MDCT_NEG_B);
-      MDCT_PKM(P[j][v], m, dq, MDCT_K_LH);
-    }
+    quant_dequant_pairs<SAT>(K, P[j], tq, td);
     aan_inv_v(K, P[j]);
   }
   MDCT_PHASE_PRIO(3);
@@ -2144,6 +2362,26 @@ __global__ __launch_bounds__(64) void k_park_table(OwnTables tb, OwnTables *slot
   reinterpret_cast<uint2 *>(slot)[threadIdx.x] = reinterpret_cast<const uint2 *>(&tb)[threadIdx.x];
 }
 
+// Shader-clock probe (diagnostics): one wave per XCD-sized grid slot spins for `ticks` of the constant 100 MHz counter and reports how many
+// shader cycles (s_memtime) passed meanwhile -- launched on a second stream beside a workload it tells at which clock the chip runs that
+// workload (bench.py turns instruction counts and measured issue cycles into a time with it: valu_floor_ms).
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long *out, unsigned int ticks)
+{
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < ticks) // bounded: the 100 MHz counter always advances
+  {
+    __builtin_amdgcn_s_sleep(4);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0)
+  {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
+
 // read-N / write-N stream copy, 8 x 16 B per lane, non-temporal: the box's measured HBM roofline
 // (tools/membench: this shape is the fastest of those tried, ~6.2 TB/s).
 constexpr int kCopyUnroll = 8;
@@ -2328,6 +2566,12 @@ hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, bool general, hip
     hipLaunchKernelGGL((k_u8_batch<false, true>), g, b, 0, s, a);
   else
     hipLaunchKernelGGL((k_u8_batch<false, false>), g, b, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_clock_probe(unsigned long long *out, unsigned int ticks, unsigned int waves, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_clock_probe, dim3(waves), dim3(64), 0, s, out, ticks);
   return hipGetLastError();
 }
 

@@ -583,11 +583,14 @@ def test_cxx_cli_on_the_reference_api(tmp_path):
             assert "sdr_Success" in r.stdout
             # the reference's table (main.cpp:72-73: min / mean clk/byte, min / mean MiB/s) plus GB/s and the roofline shares
             head = next(l for l in r.stdout.splitlines() if l.startswith("mode "))
-            for col in ("min clk/byte", "mean clk/byte (sigma)", "min MiB/s (nominal)", "mean MiB/s", "alg. GB/s", "% of 8 TB/s", "% of measured copy"):
+            for col in ("min clk/byte", "mean clk/byte (sigma)", "min MiB/s (nominal)", "mean MiB/s", "alg. GB/s", "% of 8 TB/s", "% of measured copy", "% of measured link"):
                 assert col in head, (col, head)
             row = [c.strip() for c in next(l for l in r.stdout.splitlines() if l.startswith(mode + " ")).split("|")]
             assert len(row) == len(head.split("|")) and float(row[2]) > 0 and float(row[4].split()[0]) > 0  # clk/byte and ns/byte were measured
-            assert (row[-1] != "-") == bool(extra) and ("measured copy of" in r.stdout) == bool(extra)  # copy roofline: --resident only
+            assert (row[-2] != "-") == bool(extra) and ("measured copy of" in r.stdout) == bool(extra)  # copy roofline: --resident only
+            assert (row[-1] != "-") == (not extra) and ("(measured link," in r.stdout) == (not extra)  # the host <-> HBM link: host pointers only
+            if not extra:
+                assert 0.0 < float(row[-1]) <= 100.0, row  # a host-pointer call cannot beat the link it travels on
             got = np.fromfile(dump, dtype=np.uint8)
             rc, want = O.run_behaviour(beh, img, lut_x(8), W, H, 0, H)
             assert np.array_equal(got, want), (mode, extra)

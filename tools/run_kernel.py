@@ -1,8 +1,20 @@
-"""Launch ONE engine kernel repeatedly on the bench workload (for rocprofv3 --pmc passes):
-    python3 tools/run_kernel.py {roundtrip|fwd|inv|q32|stereo_sse|encq_sse|stereo_scalar|encq_scalar|scan_q32|u8_records|copy|huffman|huffman_k1|px_huffman|px_huffman_k1|
-                                 frame420|batch<N>|f32|roundtrip_lut} [launches]
-    frame420: BASELINE.json configs[2] in one call (k_i16_batch, round trip, Annex-K tables); batch256: configs[3] on one GPU, 256 separately
-    allocated 4096^2 planes forward in one launch (device-table batch); f32: configs[4], k_f32_tile forward"""
+"""Launch engine kernels on the bench workloads -- the target of the rocprofv3 --pmc passes (tools/profile_round5.sh):
+
+    python3 tools/run_kernel.py <name>[,<name>...] | all  [launches = 6]
+
+Every input is built on the HOST (numpy, simd_dct_amd.synth) and uploaded, or replicated on the device with the library's own stream
+copy: no torch kernel runs, so a counter pass costs what the engine's launches cost (round 4 could not finish the 256-plane batch under
+--pmc because torch's input builders ran under the counters too).  torch is used for allocation (torch.empty) and copies only.
+One process can run all kernels in turn (`all`): a counter pass is then ONE rocprofv3 run; tools/pmc_round5.py tells the kernels apart
+by name and grid size.
+
+    roundtrip roundtrip_lut fwd inv copy        8192^2 int16 (k_i16_tile<...>, k_stream_copy)
+    q32 stereo_sse stereo_scalar encq_sse encq_scalar   the reference's five behaviours, 8192^2 (k_q32_tile, k_fwd_quant_u8<...>)
+    f32                                          configs[4]: k_f32_tile forward
+    frame420 frame420_u8                         configs[2]: the 8K 4:2:0 frame as int16 planes (k_i16_batch) / as 8-bit planes (k_u8_batch), one launch
+    batch256                                     configs[3] on one GPU: 256 separately allocated 4096^2 planes, forward, ONE launch (17.2 GB)
+    u8_i16_fwd u8_i16_inv                        k_u8_i16
+    scan_i16 scan_q32 u8_records split420 huffman px_huffman jpeg_scan   the stages either side (8192^2)"""
 import os
 import sys
 
@@ -13,92 +25,169 @@ import torch
 import simd_dct_amd as M
 from simd_dct_amd import synth
 
+ALL = ["copy", "roundtrip", "roundtrip_lut", "fwd", "inv", "q32", "stereo_sse", "stereo_scalar", "encq_sse", "encq_scalar", "f32", "frame420", "frame420_u8", "u8_i16_fwd", "u8_i16_inv",
+       "scan_i16", "scan_q32", "u8_records", "split420", "huffman", "px_huffman", "jpeg_scan", "batch256"]
 which = sys.argv[1] if len(sys.argv) > 1 else "roundtrip"
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+names = ALL if which == "all" else which.split(",")
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 W = H = 8192
 M.init(0)
-srcs = [synth.plane_i16_torch(W, H, "photo", seed=synth.SEED + i) for i in range(4)]
-dsts = [torch.empty_like(s) for s in srcs]
-lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
-u8s = [synth.plane_u8_torch(W, H, "photo", seed=synth.SEED + i) for i in range(4)]
-u8d = [torch.empty(W * H, dtype=torch.uint8, device="cuda") for _ in range(4)]
-if which.startswith("huffman"):
-    # records of quantised coefficients: "huffman" = the dense time_all.py case (22 pairs per block), "huffman_k1" = Annex K.1 table (5 pairs)
-    q = (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32) if which == "huffman" else synth.JPEG_LUMA
-    nblk = (W // 8) * (H // 8)
-    recs = []
-    for s_ in range(2):
-        M.fwd_i16(srcs[s_], dsts[s_], W, H, lut=q)
-        lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
-        rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
-        ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
-        M.zigzag_rle_i16(dsts[s_], W, H, lv, rn, ct)
-        recs.append((lv, rn, ct))
-    hstride = M.huffman_seg_stride(W)
-    hseg = torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda")
-    hnb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    print("pairs per block", float(recs[0][2].float().mean()))
-K1 = synth.JPEG_LUMA
-if which.startswith("px_huffman"):  # the fused pixels -> Huffman rows kernel: dense quality-60 table, or Annex K.1
-    pq = K1 if which.endswith("_k1") else (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32)
-    hstride = M.huffman_seg_stride(W)
-    hseg = torch.empty(((H // 8) * hstride,), dtype=torch.uint8, device="cuda")
-    hnb = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
-    hff = torch.empty((H // 8,), dtype=torch.int32, device="cuda")
+
+
+def up(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()  # host -> device copy, no kernel
+
+
+def empty(shape, dtype):
+    return torch.empty(shape, dtype=dtype, device="cuda")
+
+
+def clone_on_device(t):
+    """a second buffer with the same bytes, made by the library's stream copy (bytes % 16 == 0)"""
+    o = torch.empty_like(t)
+    M.stream_copy(t, o, t.numel() * t.element_size())
+    return o
+
+
+K1, K2 = synth.JPEG_LUMA, synth.JPEG_CHROMA
+lut2000 = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
 lut8 = (M.QUANTIZE_BASE * np.float32(8)).astype(np.float32)
-U8 = {"stereo_sse": (M.LAYOUT_STEREO, M.PROFILE_REF_SSE, H // 16), "encq_sse": (M.LAYOUT_BLOCK_SSE, M.PROFILE_REF_SSE, H // 8),
-      "stereo_scalar": (M.LAYOUT_STEREO, M.PROFILE_REF_SCALAR, H // 16), "encq_scalar": (M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, H // 8)}
-if which in ("scan_q32", "u8_records"):
-    nblk = (W // 8) * (H // 8)
-    lv = torch.empty((nblk, 64), dtype=torch.int16, device="cuda")
-    rn = torch.empty((nblk, 64), dtype=torch.uint8, device="cuda")
-    ct = torch.empty((nblk,), dtype=torch.uint8, device="cuda")
-    q60 = (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32)
-    for s_ in range(4):
-        M.fwd_quant_u8(u8s[s_], u8d[s_], lut, W, H, 0, H // 8)
-if which == "frame420":
-    frames = [[(synth.plane_i16_torch(w, h, "photo", seed=synth.SEED + so + 10 * f), None, w, h, synth.JPEG_LUMA if tab == "luma" else synth.JPEG_CHROMA) for (w, h, so, tab) in synth.CONFIG3_PLANES] for f in range(4)]
-    frames = [[(a, torch.empty_like(a), w, h, l) for (a, _, w, h, l) in f] for f in frames]
-if which.startswith("batch") and which[5:].isdigit():  # batch256 = configs[3] on one GPU; batch32 for counter passes (every torch kernel that
-    del srcs, dsts, u8s, u8d                              # builds an input is slowed by the counters too: 256 planes take minutes under --pmc)
-    nb = int(which[5:])
-    pl = [synth.plane_i16_torch(4096, 4096, "photo", seed=synth.SEED + 100 + p) for p in range(nb)]
-    b256 = M.Batch("fwd", [(a, torch.empty_like(a), 4096, 4096, None) for a in pl])
-    print("planes ready", nb, flush=True)
-if which == "f32":
-    fsrc = [t.to(torch.float32) for t in srcs[:2]]
-    fdst = [torch.empty_like(t) for t in fsrc]
-torch.cuda.synchronize()
-for i in range(n):
-    s = i % 4
-    if which == "roundtrip":
-        M.roundtrip_i16(srcs[s], dsts[s], W, H)
-    elif which == "fwd":
-        M.fwd_i16(srcs[s], dsts[s], W, H)
-    elif which == "inv":
-        M.inv_i16(srcs[s], dsts[s], W, H)
-    elif which == "q32":
-        M.fwd_quant_u8(u8s[s], u8d[s], lut, W, H, 0, H // 8)
-    elif which in U8:
-        M.fwd_quant_u8(u8s[s], u8d[s], lut8, W, H, 0, U8[which][2], layout=U8[which][0], profile=U8[which][1])
-    elif which == "scan_q32":
-        M.zigzag_rle_q32(u8d[s], W, H, lv, rn, ct)
-    elif which == "u8_records":
-        M.fwd_u8_records(u8s[s], W, H, lv, rn, ct, lut=q60)
-    elif which.startswith("px_huffman"):
-        M.fwd_u8_huffman_rows(u8s[s], W, H, hseg, hnb, lut=pq, ff_counts=hff)
-    elif which.startswith("huffman"):
-        M.huffman_rows(*recs[i % 2], W, H, hseg, hnb)
-    elif which == "frame420":
-        M.roundtrip_i16_planes(frames[s])
-    elif which.startswith("batch") and which[5:].isdigit():
-        b256.run()
-    elif which == "f32":
-        M.fwd_f32(fsrc[i % 2], fdst[i % 2], W, H)
-    elif which == "roundtrip_lut":
-        M.roundtrip_i16(srcs[s], dsts[s], W, H, lut=K1)
-    elif which == "copy":
-        M.stream_copy(srcs[s], dsts[s], W * H * 2)
-torch.cuda.synchronize()
-print("done", which, n)
+q60 = (M.QUANTIZE_BASE * np.float32(60)).astype(np.float32)
+_cache = {}
+
+
+def i16_planes():
+    if "i16" not in _cache:
+        a = up(synth.plane_i16_np(W, H, "photo"))
+        _cache["i16"] = ([a, clone_on_device(a)], [empty((H, W), torch.int16) for _ in range(2)])
+    return _cache["i16"]
+
+
+def u8_planes():
+    if "u8" not in _cache:
+        a = up(synth.plane_u8_np(W, H, "photo"))
+        _cache["u8"] = ([a, clone_on_device(a)], [empty((W * H,), torch.uint8) for _ in range(2)])
+    return _cache["u8"]
+
+
+def drop(*keys):
+    for k in keys:
+        _cache.pop(k, None)
+    torch.cuda.empty_cache()
+
+
+def run(name):
+    U8 = {"stereo_sse": (M.LAYOUT_STEREO, M.PROFILE_REF_SSE, H // 16), "encq_sse": (M.LAYOUT_BLOCK_SSE, M.PROFILE_REF_SSE, H // 8),
+          "stereo_scalar": (M.LAYOUT_STEREO, M.PROFILE_REF_SCALAR, H // 16), "encq_scalar": (M.LAYOUT_BLOCK, M.PROFILE_REF_SCALAR, H // 8)}
+    if name in ("roundtrip", "roundtrip_lut", "fwd", "inv", "copy"):
+        s, d = i16_planes()
+        for i in range(n):
+            if name == "roundtrip":
+                M.roundtrip_i16(s[i % 2], d[i % 2], W, H)
+            elif name == "roundtrip_lut":
+                M.roundtrip_i16(s[i % 2], d[i % 2], W, H, lut=K1)
+            elif name == "fwd":
+                M.fwd_i16(s[i % 2], d[i % 2], W, H)
+            elif name == "inv":
+                M.inv_i16(s[i % 2], d[i % 2], W, H)
+            else:
+                M.stream_copy(s[i % 2], d[i % 2], W * H * 2)
+    elif name == "q32" or name in U8:
+        s, d = u8_planes()
+        for i in range(n):
+            if name == "q32":
+                M.fwd_quant_u8(s[i % 2], d[i % 2], lut2000, W, H, 0, H // 8)
+            else:
+                M.fwd_quant_u8(s[i % 2], d[i % 2], lut8, W, H, 0, U8[name][2], layout=U8[name][0], profile=U8[name][1])
+    elif name == "f32":
+        drop("i16", "u8")
+        a = up(synth.plane_i16_np(W, H, "photo").astype(np.float32))
+        o = empty((H, W), torch.float32)
+        for i in range(n):
+            M.fwd_f32(a, o, W, H)
+    elif name in ("frame420", "frame420_u8"):
+        drop("i16", "u8")
+        u8 = name.endswith("_u8")
+        frames = []
+        for f in range(2):
+            pl = []
+            for (w, h, so, tab) in synth.CONFIG3_PLANES:
+                a = up((synth.plane_u8_np if u8 else synth.plane_i16_np)(w, h, "photo", seed=synth.SEED + so + 10 * f))
+                pl.append((a, torch.empty_like(a), w, h, K1 if tab == "luma" else K2))
+            frames.append(pl)
+        b = [M.Batch("roundtrip_u8" if u8 else "roundtrip", f) for f in frames]
+        for i in range(n):
+            b[i % 2].run()
+        torch.cuda.synchronize()
+    elif name == "batch256":
+        drop("i16", "u8")
+        base = [up(synth.plane_i16_np(4096, 4096, "photo", seed=synth.SEED + 100 + p)) for p in range(4)]  # four uploaded planes ...
+        pl = [base[p] if p < 4 else empty((4096, 4096), torch.int16) for p in range(256)]
+        for p in range(4, 256):                                                                              # ... replicated by the library's stream copy
+            M.stream_copy(base[p % 4], pl[p], 4096 * 4096 * 2)
+        out = [empty((4096, 4096), torch.int16) for _ in range(256)]
+        b = M.Batch("fwd", [(a, o, 4096, 4096, None) for a, o in zip(pl, out)])
+        assert b.launches == 1
+        print("256 separately allocated planes ready", flush=True)
+        for i in range(max(2, n // 2)):
+            b.run()
+        torch.cuda.synchronize()
+    elif name in ("u8_i16_fwd", "u8_i16_inv"):
+        s, d = u8_planes()
+        coef = empty((H, W), torch.int16)
+        M.fwd_u8_i16(s[0].view(H, W), coef, W, H, lut=K1)
+        for i in range(n):
+            if name.endswith("fwd"):
+                M.fwd_u8_i16(s[i % 2].view(H, W), coef, W, H, lut=K1)
+            else:
+                M.inv_i16_u8(coef, d[i % 2].view(H, W), W, H, lut=K1)
+    elif name in ("scan_i16", "scan_q32", "u8_records", "huffman", "px_huffman", "jpeg_scan"):
+        nblk = (W // 8) * (H // 8)
+        lv, rn, ct = empty((nblk, 64), torch.int16), empty((nblk, 64), torch.uint8), empty((nblk,), torch.uint8)
+        hstride = M.huffman_seg_stride(W)
+        if name in ("scan_i16", "huffman"):
+            s, d = i16_planes()
+            M.fwd_i16(s[0], d[0], W, H, lut=q60)  # dense quantised coefficients (quality-60 table: ~22 pairs per block)
+            M.zigzag_rle_i16(d[0], W, H, lv, rn, ct)
+            if name == "scan_i16":
+                for i in range(n):
+                    M.zigzag_rle_i16(d[0], W, H, lv, rn, ct)
+            else:
+                hseg, hnb = empty(((H // 8) * hstride,), torch.uint8), empty((H // 8,), torch.int32)
+                for i in range(n):
+                    M.huffman_rows(lv, rn, ct, W, H, hseg, hnb)
+        elif name == "scan_q32":
+            s, d = u8_planes()
+            M.fwd_quant_u8(s[0], d[0], lut2000, W, H, 0, H // 8)
+            for i in range(n):
+                M.zigzag_rle_q32(d[0], W, H, lv, rn, ct)
+        elif name == "u8_records":
+            s, d = u8_planes()
+            for i in range(n):
+                M.fwd_u8_records(s[i % 2].view(H, W), W, H, lv, rn, ct, lut=q60)
+        else:
+            s, d = u8_planes()
+            hseg, hnb, hff = empty(((H // 8) * hstride,), torch.uint8), empty((H // 8,), torch.int32), empty((H // 8,), torch.int32)
+            if name == "px_huffman":
+                for i in range(n):
+                    M.fwd_u8_huffman_rows(s[i % 2].view(H, W), W, H, hseg, hnb, lut=q60, ff_counts=hff)
+            else:
+                work = up(np.zeros(H // 8 + 2, dtype=np.int64))
+                scan, off = empty((W * H // 2,), torch.uint8), empty((H // 8 + 1,), torch.int64)
+                for i in range(n):
+                    M.fwd_u8_jpeg_scan(s[i % 2].view(H, W), W, H, hseg, work, scan, off, lut=K1)
+    elif name == "split420":
+        drop("i16", "u8")
+        rng = np.random.default_rng(1)
+        ycc = up(rng.integers(0, 256, size=(H, W * 3), dtype=np.uint8))
+        y, cb, cr = empty((H, W), torch.int16), empty((H // 2, W // 2), torch.int16), empty((H // 2, W // 2), torch.int16)
+        for i in range(n):
+            M.split420_u8(ycc, W, H, y, cb, cr)
+    else:
+        raise SystemExit(f"unknown kernel name {name!r}; one of {ALL}")
+    torch.cuda.synchronize()
+    print("done", name, flush=True)
+
+
+for nm in names:
+    run(nm)

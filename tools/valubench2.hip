@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/valubench2.hip -o tools/valubench2
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define BODY8(INS) R8(INS) R8(INS) R8(INS) R8(INS) R8(INS) R8(INS) R8(INS) R8(INS)
 
@@ -55,10 +56,64 @@ DEF(k_dpp_mov, D8)
 DEF(k_ds_write_b8, L8)
 DEF(k_ds_write_b32, L32)
 
+// packed fp32 (register pairs): the instructions the u8 tiers and the fused round trips are mostly made of
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define DEFP(NAME, ASMSTR)                                                                     \
+  __global__ __launch_bounds__(256) void NAME(float *out, int iters, unsigned *lds_dummy)      \
+  {                                                                                            \
+    const float t = threadIdx.x;                                                               \
+    f32x2 a0 = {t, t + 8}, a1 = {t + 1, t + 9}, a2 = {t + 2, t + 10}, a3 = {t + 3, t + 11}, a4 = {t + 4, t + 12}, a5 = {t + 5, t + 13}, a6 = {t + 6, t + 14}, a7 = {t + 7, t + 15}; \
+    const f32x2 c = {1.0001f, 0.9999f};                                                        \
+    for (int i = 0; i < iters; i++)                                                            \
+    {                                                                                          \
+      asm volatile(ASMSTR ASMSTR ASMSTR ASMSTR ASMSTR ASMSTR ASMSTR ASMSTR                     \
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c)); \
+    }                                                                                          \
+    const f32x2 s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                     \
+    out[blockIdx.x * 256 + threadIdx.x] = s.x + s.y;                                           \
+    (void)lds_dummy;                                                                           \
+  }
+DEFP(k_pk_add, I8("v_pk_add_f32"))
+DEFP(k_pk_mul, I8("v_pk_mul_f32"))
+DEFP(k_pk_fma, T8("v_pk_fma_f32"))
+#define PX8 "v_pk_add_f32 %0, %0, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %1, %1, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %2, %2, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %3, %3, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n" \
+            "v_pk_add_f32 %4, %4, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %5, %5, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %6, %6, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n v_pk_add_f32 %7, %7, %8 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n"
+DEFP(k_pk_add_opsel, PX8)
+DEF(k_sat_pk_u8_i16, U8("v_sat_pk_u8_i16"))
+DEF(k_cvt_u32_f32, U8("v_cvt_u32_f32"))
+
+// the clock the chip holds while a benchmark kernel runs: one wave spins for `ticks` of the constant 100 MHz counter and reports the
+// shader cycles (s_memtime) that passed meanwhile; launched just before the benchmark kernel on a second stream
+__global__ __launch_bounds__(64) void k_clock(unsigned long long *out, unsigned ticks)
+{
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < ticks)
+  {
+    __builtin_amdgcn_s_sleep(4);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  if (threadIdx.x == 0)
+  {
+    out[0] = __builtin_amdgcn_s_memtime() - c0;
+    out[1] = r1 - r0;
+  }
+}
+
+static int g_waves = 8;
+struct Cost
+{
+  const char *name;
+  double ns, cycles;
+};
+static double g_last_cycles = 0;
+static Cost g_costs[64];
+static int g_ncosts = 0;
+
 template <typename K>
 void run(const char *name, K kern, float *out, int per_body)
 {
-  const int iters = 2048, waves_per_simd = 8;
+  const int iters = 2048, waves_per_simd = g_waves;
   const int grid = 256 * waves_per_simd;
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
@@ -78,7 +133,26 @@ void run(const char *name, K kern, float *out, int per_body)
   }
   const double instr_per_simd = (double)waves_per_simd * iters * per_body;
   const double ns = best * 1e6 / instr_per_simd;
-  printf("%-22s %8.3f ms   %5.2f ns/instr/SIMD  = %5.2f cycles @2.4GHz (%5.2f @2.0GHz)\n", name, best, ns, ns * 2.4, ns * 2.0);
+  // the clock during this kernel: the probe first (it takes one wave slot), then the kernel beside it
+  static hipStream_t s2 = nullptr;
+  static unsigned long long *probe = nullptr;
+  if (!s2)
+  {
+    hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    hipMalloc(&probe, 16);
+  }
+  hipDeviceSynchronize();
+  const unsigned ticks = (unsigned)(best * 1e5 * 0.6); // 60 % of the kernel's duration, in 10 ns ticks
+  hipLaunchKernelGGL(k_clock, dim3(1), dim3(64), 0, s2, probe, ticks > 100 ? ticks : 100);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, out, iters, nullptr);
+  hipDeviceSynchronize();
+  unsigned long long pr[2] = {0, 1};
+  hipMemcpy(pr, probe, 16, hipMemcpyDeviceToHost);
+  const double ghz = (double)pr[0] / ((double)pr[1] * 10.0);
+  printf("%-22s %d waves/SIMD %8.3f ms   %5.2f ns/instr/SIMD  = %5.2f cycles at the measured %.2f GHz\n", name, waves_per_simd, best, ns, ns * ghz, ghz);
+  g_last_cycles = ns * ghz;
+  if (g_waves == 8 && g_ncosts < 64)
+    g_costs[g_ncosts++] = Cost{name, ns, g_last_cycles};
 }
 
 int main()
@@ -89,5 +163,27 @@ int main()
   RUN(k_add); RUN(k_mul); RUN(k_sub); RUN(k_fma); RUN(k_addu32); RUN(k_addu16); RUN(k_med3f); RUN(k_med3i); RUN(k_perm);
   RUN(k_cvt_f32_i32); RUN(k_cvt_f32_i32_sdwa); RUN(k_cvt_f32_ubyte0); RUN(k_cvt_f32_ubyte2); RUN(k_cvt_i32_f32); RUN(k_rndne);
   RUN(k_mov); RUN(k_lshl_or); RUN(k_and_or); RUN(k_bfe); RUN(k_dpp_mov); RUN(k_ds_write_b8); RUN(k_ds_write_b32);
+  RUN(k_pk_add); RUN(k_pk_mul); RUN(k_pk_fma); RUN(k_pk_add_opsel); RUN(k_sat_pk_u8_i16); RUN(k_cvt_u32_f32);
+  // the classes bench.py's vector-issue floor is built from (tools/isa_classes.py sorts a kernel's instructions into them), at the
+  // occupancy the product kernels run at as well
+  for (int w : {4, 3, 2})
+  {
+    g_waves = w;
+    RUN(k_add); RUN(k_pk_add); RUN(k_pk_mul); RUN(k_perm); RUN(k_cvt_f32_ubyte0); RUN(k_med3f);
+  }
+  auto cost = [&](const char *n, bool cyc) {
+    for (int i = 0; i < g_ncosts; i++)
+      if (!strcmp(g_costs[i].name, n))
+        return cyc ? g_costs[i].cycles : g_costs[i].ns;
+    return 0.0;
+  };
+  auto min3 = [](double a, double b, double c) { return a < b ? (a < c ? a : c) : (b < c ? b : c); };
+  // per wave-instruction per SIMD at 8 waves per SIMD, the cheapest member of each class: a FLOOR.  In shader CYCLES (the clock each
+  // benchmark ran at was measured beside it), so that a kernel's floor can be priced at the clock the chip holds under THAT kernel.
+  for (int cyc = 0; cyc < 2; cyc++)
+    printf("VALU_ISSUE_COSTS_%s {\"plain\": %.4f, \"packed\": %.4f, \"other\": %.4f, \"note\": \"8 waves per SIMD, independent chains; plain = v_add/sub/mul_f32, v_mov, v_add_u32; "
+           "packed = v_pk_add/mul/fma_f32; other = converts, v_med3, v_perm, v_rndne, 3-operand integer ops, v_sat_pk_u8_i16\"}\n", cyc ? "CYCLES" : "NS",
+           min3(cost("k_add", cyc), cost("k_mul", cyc), cost("k_mov", cyc)), min3(cost("k_pk_add", cyc), cost("k_pk_mul", cyc), cost("k_pk_add_opsel", cyc)),
+           min3(cost("k_perm", cyc), cost("k_cvt_f32_ubyte0", cyc), cost("k_med3f", cyc)));
   return 0;
 }
