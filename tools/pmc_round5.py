@@ -40,7 +40,7 @@ WANT = {
     "k_u8_records": ("k_u8_records<false, false>", None, 4 * W * H),
     "k_split420": ("k_split420", None, 6 * W * H),
     "k_huffman_rows_q60": ("k_huffman_rows", None, 3 * W * H),
-    "k_px_huffman_rows_q60": ("k_px_huffman_rows<false, 4, false, true>", None, W * H),
+    "k_px_huffman_rows_q60": ("k_px_huffman_rows<false, 4, false, false>", None, W * H),
     "k_px_jpeg_scan_k1": ("k_px_huffman_rows<false, 4, true, false>", None, W * H),
 }
 
