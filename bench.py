@@ -657,9 +657,13 @@ def main():
                 if not k or not costs or not clock_ghz or not avg_ms:
                     return None
                 cyc = sum(k[c] * costs["cycles"][c] for c in ("plain", "packed", "other"))
+                executed = pmc.get(pmc_key, {}).get("valu_insts_per_wave")
+                scaled = bool(executed) and abs(executed - k["valu"]) > 0.02 * k["valu"]
+                if scaled:  # a kernel with a rarely taken branch (the SSE encq tier's spill): the static mix, scaled to the count the PMC saw executed
+                    cyc *= executed / k["valu"]
                 floor_ms = waves * cyc / (1024 * clock_ghz * 1e9) * 1e3
                 return {"insts_per_wave_static": {c: k[c] for c in ("plain", "packed", "other")}, "valu_insts_per_wave_static": k["valu"],
-                        "valu_insts_per_wave": pmc.get(pmc_key, {}).get("valu_insts_per_wave"), "waves_per_launch": waves,
+                        "valu_insts_per_wave": executed, "static_mix_scaled_to_executed_count": scaled, "waves_per_launch": waves,
                         "issue_cycles_per_wave": round(cyc, 0), "issue_cycles_per_instruction": costs["cycles"], "clock_GHz_under_this_kernel": clock_ghz,
                         "valu_floor_ms": round(floor_ms, 4), "frac_of_valu_floor": round(floor_ms / avg_ms, 3), "simds": 1024,
                         "how": "valu_floor_ms = waves x sum(class count x measured issue cycles) / (1024 SIMDs x measured clock); counts: tools/isa_classes.py (static; "

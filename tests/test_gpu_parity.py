@@ -980,6 +980,36 @@ def test_soak_random_differential():
         p = torch.empty((H2, W2), dtype=torch.uint8, device="cuda")
         M.inv_i16_u8(dev(src), p, W2, H2, lut=table, level_shift=bool(it & 1))
         assert np.array_equal(p.cpu().numpy(), O.u8_i16("inv", src, W2, H2, lut=table, level_shift=bool(it & 1)))
+        # the fused 8-bit round trip (round 5): one plane with a row range and pitches, and a batch of 1..6 planes; tame tables (fast build),
+        # wild ones (saturating quantiser, clamping output stage) and none; contents incl. the extremes that saturate the output
+        shift = bool(it & 2)
+        wild = lut_x(float(rng.choice([0.003, 0.02, 3e4]))) if it % 3 == 0 else table
+        px2 = px if it % 5 else (rng.integers(0, 2, (H2, W2)) * 255).astype(np.uint8)
+        rb0 = int(rng.integers(0, H2 // 8))
+        rb1 = int(rng.integers(rb0, H2 // 8 + 1))
+        pin_, pout_ = W2 + int(rng.integers(0, 9)), W2 + int(rng.integers(0, 9))
+        src_p = np.full((H2, pin_), 7, dtype=np.uint8)
+        src_p[:, :W2] = px2
+        got_p = torch.full((H2, pout_), 0xA5, dtype=torch.uint8, device="cuda")
+        M.roundtrip_u8(dev(src_p), got_p, W2, H2, lut=wild, level_shift=shift, by0=rb0, by1=rb1, pitch_in=pin_, pitch_out=pout_)
+        want_p = np.full((H2, pout_), 0xA5, dtype=np.uint8)
+        O.roundtrip_u8(src_p, W2, H2, lut=wild, level_shift=shift, by0=rb0, by1=rb1, pitch_in=pin_, pitch_out=pout_, out=want_p)
+        assert np.array_equal(got_p.cpu().numpy(), want_p), (it, "roundtrip_u8", W2, H2, rb0, rb1, pin_, pout_, shift)
+        nup = int(rng.integers(1, 7))
+        ushapes = [(int(rng.integers(1, 100)) * 8, int(rng.integers(1, 8)) * 8) for _ in range(nup)]
+        utabs = [None if rng.random() < 0.25 else (wild if rng.random() < 0.3 else (lut_x(float(rng.choice([1, 16, 150]))) * rng.uniform(0.3, 3, 64).astype(np.float32)).astype(np.float32)) for _ in range(nup)]
+        usrc = [rng.integers(0, 256, (uh, uw), dtype=np.uint8) for (uw, uh) in ushapes]
+        u_in = [dev(a) for a in usrc]
+        u_out = [torch.full((uh, uw), 0xA5, dtype=torch.uint8, device="cuda") for (uw, uh) in ushapes]
+        udesc = [(a, o, uw, uh, l) for a, o, (uw, uh), l in zip(u_in, u_out, ushapes, utabs)]
+        if it % 4 == 1:
+            ub = M.Batch("roundtrip_u8", udesc, level_shift=shift)
+            ub.run()
+            ub.close()
+        else:
+            M.roundtrip_u8_batch(udesc, level_shift=shift)
+        for a, o, (uw, uh), l in zip(usrc, u_out, ushapes, utabs):
+            assert np.array_equal(o.cpu().numpy(), O.roundtrip_u8(a, uw, uh, lut=l, level_shift=shift)), (it, "u8 batch", uw, uh)
         f = rng.normal(0, 300, (H2, W2)).astype(np.float32)
         fo = torch.empty((H2, W2), dtype=torch.float32, device="cuda")
         M.fwd_f32(dev(f), fo, W2, H2)

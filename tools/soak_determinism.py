@@ -68,6 +68,17 @@ for (W, H) in ((8192, 8192), (4104, 2056 - 2056 % 16), (2048, 7680)):
         del bi, bo, desc, dev_batch
     soak("u8 px -> i16 coef", [o16], lambda: M.fwd_u8_i16(u8, o16, W, H, lut=K1))
     p8 = torch.empty((H, W), dtype=torch.uint8, device="cuda")
+    soak("u8 -> u8 fused round trip + table (k_u8_batch, fast build)", [p8], lambda: M.roundtrip_u8(u8, p8, W, H, lut=K1))
+    soak("u8 -> u8 fused round trip, wild table (general build)", [p8], lambda: M.roundtrip_u8(u8, p8, W, H, lut=np.full(64, 0.02, dtype=np.float32)))
+    if W == 8192:
+        shapes8 = [(7680, 4320), (3840, 2160), (3840, 2160)]
+        ui = [synth.plane_u8_torch(w, h, "photo", seed=30 + k) for k, (w, h) in enumerate(shapes8)]
+        uo = [torch.empty_like(t) for t in ui]
+        udesc = [(a, b, w, h, l) for a, b, (w, h), l in zip(ui, uo, shapes8, (K1, synth.JPEG_CHROMA, synth.JPEG_CHROMA))]
+        soak("8-bit 4:2:0 frame, kernel arguments", uo, lambda: M.roundtrip_u8_batch(udesc))
+        ub = M.Batch("roundtrip_u8", udesc)
+        soak("8-bit 4:2:0 frame, device table", uo, lambda: ub.run())
+        del ui, uo, udesc, ub
     soak("i16 coef -> u8 px", [p8], lambda: M.inv_i16_u8(i16, p8, W, H, lut=K1))
     f32 = i16.float()
     of = torch.empty_like(f32)
