@@ -622,7 +622,9 @@ def main():
                        "parallelism": f"independent planes x{world}" if world > 1 else "single GPU", "device": info["name"]},
             "roofline": {"bound": "hbm", "kernel": "mdct::k_i16_tile<MODE_ROUNDTRIP, no table>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": px_per_step * ALG_BYTES_PER_PX, "avg_launch_ms": round(kernel_ms, 4)},
+                         "algorithmic_bytes_per_launch": px_per_step * ALG_BYTES_PER_PX, "avg_launch_ms": round(kernel_ms, 4),
+                         "parity": "unpinned by the reference (it has no int16 path, no inverse): pinned by the CPU checker's restatement of the engine's own arithmetic, "
+                                   "the double-precision definition, and the bit-exact round-trip identity verified on every plane set of this run"},
             "bit_exact_roundtrip_verified": verified,
         }
         if dist is not None:  # one process per GPU: who took part, and each rank's own rate (the driver computes the efficiency, not this file)
@@ -682,6 +684,7 @@ def main():
                 v = valu(ISA_NAME.get(key), (W // 8) * (H // 8) // 64, q["ms"], q.get("clock_GHz"), key)
                 return {"bound": "vector issue at the clock the chip holds under this kernel (valu.frac_of_valu_floor); the bytes alone would take algorithmic_bytes / measured copy rate",
                         "valu": v, "traffic_round": traffic.get("traffic_round"), "kernel": q["kernel"], "reference": q["reference"],
+                        "parity": "pinned: byte-identical to the real reference built from /root/reference with -O2 -ffp-contract=off (SHA-256 of its output for this plane)",
                         "achieved": q["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(q["GBps"] / HBM_PEAK_GBPS, 4),
                         "frac_of_measured_copy": round(q["GBps"] / copy, 3) if copy else None,
                         "algorithmic_bytes_per_launch": 2 * W * H, "avg_launch_ms": q["ms"], "Mpx_s": q.get("Mpx_s"),
@@ -695,7 +698,8 @@ def main():
                 # engine-own kernels (no reference counterpart: "parity unpinned" by the reference, pinned by the CPU checker)
                 if not q or "GBps" not in q:
                     return q
-                return {"bound": "hbm", "kernel": kernel, "what": what, "achieved": q["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(q["GBps"] / HBM_PEAK_GBPS, 4),
+                return {"bound": "hbm", "kernel": kernel, "what": what, "parity": "unpinned by the reference (no counterpart there); pinned by the CPU checker (oracle/dct_oracle.c)",
+                        "achieved": q["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(q["GBps"] / HBM_PEAK_GBPS, 4),
                         "frac_of_measured_copy": round(q["GBps"] / copy, 3) if copy else None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": q["ms"],
                         "traffic": traffic.get(traffic_key) if traffic_key else None,
                         "traffic_round": traffic.get("traffic_round"),
