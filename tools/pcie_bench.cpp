@@ -6,6 +6,7 @@
 //   hipcc -O2 -std=c++17 tools/pcie_bench.cpp -o tools/pcie_bench && tools/pcie_bench [MiB = 64]
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -159,6 +160,45 @@ int main(int argc, char **argv)
     two();
     const double t = best_of(8, two);
     printf("pageable, one host thread per direction, %3zu MiB pieces, both directions at once: %6.1f GB/s each way (%.3f ms)\n", piece >> 20, gb / t, t * 1e3);
+  }
+  // pageable memory handed straight to hipMemcpyAsync (the runtime pins it on the fly), one host thread per direction, copy out k ordered
+  // behind copy in k by an event the first thread records and the second waits for (host handshake, then hipStreamWaitEvent): what a
+  // pipeline WITHOUT bounce buffers could do for a caller like main.cpp
+  {
+    std::vector<hipEvent_t> ev(n >> 20);
+    for (auto &e : ev)
+      CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (size_t piece : {(size_t)2 << 20, (size_t)4 << 20, (size_t)8 << 20})
+    {
+      auto dep2 = [&] {
+        const size_t cnt = n / piece;
+        std::atomic<size_t> recorded{0};
+        std::thread tin([&] {
+          for (size_t k = 0; k < cnt; k++)
+          {
+            CK(hipMemcpyAsync(d_a + k * piece, m_a + k * piece, piece, hipMemcpyHostToDevice, s0));
+            CK(hipEventRecord(ev[k], s0));
+            recorded.store(k + 1, std::memory_order_release);
+          }
+          CK(hipStreamSynchronize(s0));
+        });
+        std::thread tout([&] {
+          for (size_t k = 0; k < cnt; k++)
+          {
+            while (recorded.load(std::memory_order_acquire) <= k)
+              ;
+            CK(hipStreamWaitEvent(s1, ev[k], 0));
+            CK(hipMemcpyAsync(m_b + k * piece, d_a + k * piece, piece, hipMemcpyDeviceToHost, s1));
+          }
+          CK(hipStreamSynchronize(s1));
+        });
+        tin.join();
+        tout.join();
+      };
+      dep2();
+      const double t = best_of(8, dep2);
+      printf("pageable DIRECT, one host thread per direction, %zu MiB pieces, out(k) behind in(k): %6.1f GB/s each way (%.3f ms)\n", piece >> 20, gb / t, t * 1e3);
+    }
   }
   auto ph2d = [&] { CK(hipMemcpy(d_a, m_a, n, hipMemcpyHostToDevice)); };
   auto pd2h = [&] { CK(hipMemcpy(m_b, d_b, n, hipMemcpyDeviceToHost)); };
