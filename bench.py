@@ -478,8 +478,12 @@ def main():
             y1 = [M.prepare_roundtrip_u8(frames8[i][0][0], frames8[i][0][1], yw, yh, lut=synth.JPEG_LUMA) for i in range(NF8)]
             r["y_plane_two_calls_ms"] = round(rate(lambda i: (f8[i % NF8](), i8[i % NF8]()), 6 * yw * yh, n=300, warm=300)["ms"], 4)
             r["y_plane_fused_ms"] = round(rate(lambda i: y1[i % NF8](), 2 * yw * yh, n=300, warm=300)["ms"], 4)
+            # the same kernel on one 8192x8192 8-bit plane (the bench's plane size; 134,217,728 B)
+            one8 = [M.prepare_roundtrip_u8(u8s[i].view(H, W), u8d[i].view(H, W), W, H, lut=synth.JPEG_LUMA) for i in range(NSETS)]
+            r["plane_8192_ms"] = round(rate(lambda i: one8[i % NSETS](), 2 * W * H, n=300, warm=300)["ms"], 4)
+            r["plane_8192_Mpx_s"] = round(W * H / (r["plane_8192_ms"] * 1e-3) / 1e6, 0)
             extras["config3_420_u8_roundtrip_one_call"] = r
-            del frames8, dev8, pr8, ar8, four8, run48, coef8, f8, i8, y1, kept8
+            del frames8, dev8, pr8, ar8, four8, run48, coef8, f8, i8, y1, kept8, one8
         except Exception as e:
             extras["config3_420_u8_roundtrip_one_call"] = {"error": str(e)[:200]}
         # configs[4]: float32 DCT-II on the 8192x8192 plane (8 algorithmic bytes per pixel)
@@ -732,7 +736,8 @@ def main():
                 tiles3 = sum(((w // 8 + 63) // 64) * (h // 8) for (w, h, _, _) in synth.CONFIG3_PLANES)
                 blk["valu"] = valu(ISA_NAME["k_u8_batch_420"], tiles3, c3u["ms"], c3u.get("clock_GHz"), "k_u8_batch_420")
                 blk["parity"] = "unpinned by the reference (it has no inverse); pinned by the CPU checker's composition orc_fwd_u8_i16 -> orc_inv_i16_u8 and equal to the two-call path on the device (tests/test_u8_roundtrip.py)"
-                for k in ("Mpx_s", "launches_per_call", "kernel_argument_form", "kernel_argument_form_equals_device_table_form", "four_frames_per_call_ms_per_frame", "y_plane_two_calls_ms", "y_plane_fused_ms"):
+                for k in ("Mpx_s", "launches_per_call", "kernel_argument_form", "kernel_argument_form_equals_device_table_form", "four_frames_per_call_ms_per_frame", "y_plane_two_calls_ms", "y_plane_fused_ms",
+                          "plane_8192_ms", "plane_8192_Mpx_s"):
                     blk[k] = c3u.get(k)
                 line["roofline_config3_420_u8"] = blk
             c5 = extras.get("config5_f32_fwd", {})

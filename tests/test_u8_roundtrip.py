@@ -250,6 +250,27 @@ def test_u8_batch_mixed_shapes_and_tables(cuda):
 
 
 @gpu
+def test_u8_batch_empty_lists_and_empty_planes(cuda):
+    """nothing to do is not an error: an empty list, planes without blocks between real ones, an empty row range; nothing is written"""
+    torch = cuda
+    lib = _lib.load()
+    assert api.roundtrip_u8_batch([]) == 0
+    b = api.Batch("roundtrip_u8", [])
+    assert b.launches == 0 and b.run() == 0
+    b.close()
+    src = synth.plane_u8_torch(264, 16, "photo", seed=3)
+    dst = torch.full_like(src, CANARY)
+    none = torch.full((8, 8), CANARY, dtype=torch.uint8, device="cuda")
+    api.roundtrip_u8_batch([(src, none, 0, 16, None, 264, 264), (src, dst, 264, 16, JPEG_LUMA), (src, none, 264, 0, None)])
+    api.roundtrip_u8(src, none, 264, 16, by0=1, by1=1)
+    torch.cuda.synchronize()
+    import oracle as O
+
+    assert (none == CANARY).all() and np.array_equal(dst.cpu().numpy(), O.roundtrip_u8(src.cpu().numpy(), 264, 16, lut=JPEG_LUMA))
+    assert lib.mdct_batch_launches(None) == 0
+
+
+@gpu
 def test_u8_batch_is_graph_capturable(cuda):
     torch = cuda
     shapes = [(1920, 32), (960, 16), (960, 16)]
