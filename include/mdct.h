@@ -193,6 +193,8 @@ int mdct_batch_destroy(mdct_batch *batch);
  * lut == NULL: no quantisation table (the coefficients are still rounded to int16, as the two calls would).
  * Pitches in BYTES; no alignment requirement on the planes (like the reference, simd_dct.cpp:2109); sizeX, sizeY multiples of 8.
  * One 64-block tile of one block row per wave, the last tile of a row may be partial (any sizeX % 8 == 0).
+ * IN PLACE is allowed (to == from with pitch_out == pitch_in; also for mdct_roundtrip_i16 and the round-trip batches): a lane has read
+ * all 64 samples of its block before it stores the first, and no other lane touches that block.
  * mdct_roundtrip_u8: block rows [by0, by1) of one plane.  _batch: any number of separately allocated planes, each with its own
  * table, in one launch -- descriptors and tables by value in the kernel arguments exactly like mdct_roundtrip_i16_batch
  * (no allocation, no synchronisation, capture-safe; Y + Cb + Cr with three tables fit one launch), or device-resident through

@@ -250,6 +250,32 @@ def test_u8_batch_mixed_shapes_and_tables(cuda):
 
 
 @gpu
+def test_round_trips_in_place(cuda):
+    """to == from (include/mdct.h): the 8-bit and the int16 fused round trips, single plane and batch, give the bytes of the out-of-place call"""
+    torch = cuda
+    for (W, H) in ((1032, 72), (512, 8)):
+        src8 = synth.plane_u8_torch(W, H, "noise", seed=5)
+        want8 = torch.empty_like(src8)
+        api.roundtrip_u8(src8, want8, W, H, lut=JPEG_LUMA)
+        buf8 = src8.clone()
+        api.roundtrip_u8(buf8, buf8, W, H, lut=JPEG_LUMA)
+        assert torch.equal(buf8, want8)
+        b1, b2 = src8.clone(), src8.clone()
+        api.roundtrip_u8_batch([(b1, b1, W, H, JPEG_LUMA), (b2, b2, W, H, JPEG_LUMA)])
+        assert torch.equal(b1, want8) and torch.equal(b2, want8)
+        src16 = synth.plane_i16_torch(W, H, "photo", seed=6, bits=12)
+        for lut in (None, _lut(30)):
+            want16 = torch.empty_like(src16)
+            api.roundtrip_i16(src16, want16, W, H, lut=lut)
+            buf16 = src16.clone()
+            api.roundtrip_i16(buf16, buf16, W, H, lut=lut)
+            assert torch.equal(buf16, want16)
+            c1 = src16.clone()
+            api.i16_batch("roundtrip", [(c1, c1, W, H, lut)])
+            assert torch.equal(c1, want16)
+
+
+@gpu
 def test_u8_batch_empty_lists_and_empty_planes(cuda):
     """nothing to do is not an error: an empty list, planes without blocks between real ones, an empty row range; nothing is written"""
     torch = cuda
