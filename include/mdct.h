@@ -347,7 +347,9 @@ int mdct_comm_world(const mdct_comm *comm);
 /* Row-strip layouts (Q32, BLOCK, int16 / float32 planes): `buf` holds n_rows strips of row_bytes bytes
  * (row_bytes = 8 * pitch in bytes); rank r has filled the strips of mdct_shard_rows(n_rows, world, r).
  * Equal shards: ONE in-place ncclAllGather; ragged: one grouped broadcast per rank.  Asynchronous on
- * `stream` (the stream the kernels ran on: no extra synchronisation needed). */
+ * `stream` (the stream the kernels ran on: no extra synchronisation needed).
+ * (Diagnostics: the environment variable MDCT_FORCE_RAGGED_GATHER=1 selects the grouped-broadcast form for equal shards too -- same
+ * bytes; it lets a one-GPU box drive that form through the real RCCL, tests/test_comm.py.) */
 int mdct_allgather_rows(mdct_comm *comm, void *buf, size_t row_bytes, size_t n_rows, void *stream);
 /* Stereo coefficient-planar output of a sizeX x sizeY call sharded by mdct_shard_rows(sizeY / 16, ...):
  * 64 strided pieces per rank, gathered as 64 collectives inside one RCCL group. */
