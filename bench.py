@@ -478,6 +478,17 @@ def main():
             y1 = [M.prepare_roundtrip_u8(frames8[i][0][0], frames8[i][0][1], yw, yh, lut=synth.JPEG_LUMA) for i in range(NF8)]
             r["y_plane_two_calls_ms"] = round(rate(lambda i: (f8[i % NF8](), i8[i % NF8]()), 6 * yw * yh, n=300, warm=300)["ms"], 4)
             r["y_plane_fused_ms"] = round(rate(lambda i: y1[i % NF8](), 2 * yw * yh, n=300, warm=300)["ms"], 4)
+            # the two halves on the whole frame, one launch each (3 B/px: 8-bit pixels one side, int16 coefficients the other) -- what an encoder
+            # (forward: the coefficients go on to the scan stages) and a decoder (inverse) call; forward then inverse == the fused launch, checked
+            coefs8 = [[torch.empty((h, w), dtype=torch.int16, device="cuda") for (w, h, _, _) in synth.CONFIG3_PLANES] for _ in range(NF8)]
+            back8 = [torch.zeros_like(t[1]) for t in frames8[0]]
+            fwd8 = [M.Batch("fwd_u8_i16", [(t[0], c, t[2], t[3], t[4]) for t, c in zip(frames8[i], coefs8[i])]).prepared() for i in range(NF8)]
+            inv8 = [M.Batch("inv_i16_u8", [((back8[j] if i == 0 else t[1]), c, t[2], t[3], t[4]) for j, (t, c) in enumerate(zip(frames8[i], coefs8[i]))]).prepared() for i in range(NF8)]
+            r["forward_only_batch"] = rate(lambda i: fwd8[i % NF8](), 3 * fpx, n=300, warm=300)
+            r["inverse_only_batch"] = rate(lambda i: inv8[i % NF8](), 3 * fpx, n=300, warm=300)
+            torch.cuda.synchronize()
+            r["forward_then_inverse_equals_fused"] = all(torch.equal(a, b) for a, b in zip(back8, kept8))
+            del coefs8, back8, fwd8, inv8
             # the same kernel on one 8192x8192 8-bit plane (the bench's plane size; 134,217,728 B)
             one8 = [M.prepare_roundtrip_u8(u8s[i].view(H, W), u8d[i].view(H, W), W, H, lut=synth.JPEG_LUMA) for i in range(NSETS)]
             r["plane_8192_ms"] = round(rate(lambda i: one8[i % NSETS](), 2 * W * H, n=300, warm=300)["ms"], 4)
@@ -677,7 +688,7 @@ def main():
 
             ISA_NAME = {"k_q32_avx": "mdct::k_q32_tile(mdct::U8Args)", "k_stereo_sse": "void mdct::k_fwd_quant_u8<1, 1, false, true>(mdct::U8Args)",
                         "k_stereo_scalar": "void mdct::k_fwd_quant_u8<2, 1, false, true>(mdct::U8Args)", "k_encq_sse": "void mdct::k_fwd_quant_u8<1, 3, false, true>(mdct::U8Args)",
-                        "k_encq_scalar": "void mdct::k_fwd_quant_u8<2, 2, false, true>(mdct::U8Args)", "k_u8_batch_420": "void mdct::k_u8_batch<false, false>(mdct::BatchArgs)",
+                        "k_encq_scalar": "void mdct::k_fwd_quant_u8<2, 2, false, true>(mdct::U8Args)", "k_u8_batch_420": "void mdct::k_u8_batch<0, false, false>(mdct::BatchArgs)",
                         "k_i16_batch_420": "void mdct::k_i16_batch<2, 1, false, false>(mdct::BatchArgs)", "k_i16_roundtrip": "void mdct::k_i16_tile<2, false, true, 2>(mdct::I16Args)"}
 
             def u8_block(q, key=None):
@@ -737,7 +748,7 @@ def main():
                 blk["valu"] = valu(ISA_NAME["k_u8_batch_420"], tiles3, c3u["ms"], c3u.get("clock_GHz"), "k_u8_batch_420")
                 blk["parity"] = "unpinned by the reference (it has no inverse); pinned by the CPU checker's composition orc_fwd_u8_i16 -> orc_inv_i16_u8 and equal to the two-call path on the device (tests/test_u8_roundtrip.py)"
                 for k in ("Mpx_s", "launches_per_call", "kernel_argument_form", "kernel_argument_form_equals_device_table_form", "four_frames_per_call_ms_per_frame", "y_plane_two_calls_ms", "y_plane_fused_ms",
-                          "plane_8192_ms", "plane_8192_Mpx_s"):
+                          "plane_8192_ms", "plane_8192_Mpx_s", "forward_only_batch", "inverse_only_batch", "forward_then_inverse_equals_fused"):
                     blk[k] = c3u.get(k)
                 line["roofline_config3_420_u8"] = blk
             c5 = extras.get("config5_f32_fwd", {})

@@ -213,6 +213,23 @@ int mdct_roundtrip_u8_batch(const mdct_plane_u8 *planes, int n_planes, int level
 /* device-resident form: run with mdct_batch_run, free with mdct_batch_destroy (above) */
 int mdct_batch_create_u8(mdct_batch **batch, const mdct_plane_u8 *planes, int n_planes, int level_shift);
 
+/* The two halves of that round trip on plane batches -- what an encoder (pixels -> quantised int16 coefficients) and a decoder
+ * (coefficients -> pixels) run on the planes of a frame in ONE launch: per plane exactly mdct_fwd_u8_i16 / mdct_inv_i16_u8 over the
+ * whole plane (3 bytes per pixel over HBM), on the tile kernel of the round trip.  pitch_px in bytes (no alignment requirement on the
+ * pixel planes), pitch_coef in elements with 16-byte aligned coefficient rows.  Kernel-argument form (no allocation, capture-safe) and
+ * device-resident form (mode = MDCT_MODE_FWD or MDCT_MODE_INV; run with mdct_batch_run) as for the other batches. */
+typedef struct mdct_plane_u8_i16
+{
+  uint8_t *px;                /* 8-bit pixel plane: read by the forward, written by the inverse */
+  int16_t *coef;              /* int16 coefficient plane: written by the forward, read by the inverse */
+  size_t pitch_px, pitch_coef;
+  size_t sizeX, sizeY;
+  const float *lut;           /* HOST pointer to 64 floats (finite, non-zero), or NULL */
+} mdct_plane_u8_i16;
+int mdct_fwd_u8_i16_batch(const mdct_plane_u8_i16 *planes, int n_planes, int level_shift, void *stream);
+int mdct_inv_i16_u8_batch(const mdct_plane_u8_i16 *planes, int n_planes, int level_shift, void *stream);
+int mdct_batch_create_u8_i16(mdct_batch **batch, int mode, const mdct_plane_u8_i16 *planes, int n_planes, int level_shift);
+
 /* ---- the stages either side of the transform (no reference counterpart: its pipeline starts from a
  * ready-made plane, main.cpp:475-493, and ends at the reorder store, simd_dct.cpp:2221-2230) ----------
  * After the quantiser: zig-zag scan (ITU-T T.81 Figure A.6) and run/level pairs (T.81 F.1.2.2) of every

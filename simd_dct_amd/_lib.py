@@ -74,6 +74,9 @@ SIGNATURES = {
     "mdct_batch_run": (c_int, [c_void_p, c_void_p]),
     "mdct_roundtrip_u8": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, f32p, c_int, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mdct_roundtrip_u8_batch": (c_int, [ctypes.POINTER(PlaneU8), c_int, c_int, c_void_p]),
+    "mdct_fwd_u8_i16_batch": (c_int, [ctypes.POINTER(PlaneU8), c_int, c_int, c_void_p]),
+    "mdct_inv_i16_u8_batch": (c_int, [ctypes.POINTER(PlaneU8), c_int, c_int, c_void_p]),
+    "mdct_batch_create_u8_i16": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(PlaneU8), c_int, c_int]),
     "mdct_batch_create_u8": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(PlaneU8), c_int, c_int]),
     "mdct_batch_launches": (c_int, [c_void_p]),
     "mdct_batch_destroy": (c_int, [c_void_p]),

@@ -268,15 +268,28 @@ def roundtrip_u8_batch(planes, level_shift=True, stream=None, check=True):
     return rc
 
 
+def u8_i16_batch(mode, planes, level_shift=True, stream=None, check=True):
+    """mdct_fwd_u8_i16_batch ('fwd') / mdct_inv_i16_u8_batch ('inv'): planes = list of (px uint8, coef int16, sizeX, sizeY, lut-or-None[, pitch_px bytes, pitch_coef elements])"""
+    lib = _lib.load()
+    arr, keep = _plane_array(planes)
+    rc = (lib.mdct_fwd_u8_i16_batch if mode == "fwd" else lib.mdct_inv_i16_u8_batch)(arr, len(planes), int(bool(level_shift)), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
 class Batch:
     """mdct_batch: descriptors and tables uploaded once, every run ONE launch (capture-safe).
-    mode 'roundtrip_u8': 8-bit planes (mdct_batch_create_u8), otherwise int16 planes."""
+    mode 'roundtrip_u8': 8-bit planes (mdct_batch_create_u8); 'fwd_u8_i16' / 'inv_i16_u8': (px, coef, ...) planes (mdct_batch_create_u8_i16);
+    otherwise int16 planes."""
 
     def __init__(self, mode, planes, level_shift=True):
         lib = _lib.load()
         arr, self._keep = _plane_array(planes)
         h = ctypes.c_void_p()
-        if mode == "roundtrip_u8":
+        if mode in ("fwd_u8_i16", "inv_i16_u8"):
+            _check(lib.mdct_batch_create_u8_i16(ctypes.byref(h), MODES["fwd" if mode == "fwd_u8_i16" else "inv"], arr, len(planes), int(bool(level_shift))))
+        elif mode == "roundtrip_u8":
             _check(lib.mdct_batch_create_u8(ctypes.byref(h), arr, len(planes), int(bool(level_shift))))
         else:
             _check(lib.mdct_batch_create(ctypes.byref(h), MODES[mode], arr, len(planes)))
@@ -557,6 +570,12 @@ def prepare_u8_batch(planes, level_shift=True, stream=None):
     """Prepared launch of mdct_roundtrip_u8_batch (planes as for roundtrip_u8_batch)"""
     arr, keep = _plane_array(planes)
     return Prepared(_lib.load().mdct_roundtrip_u8_batch, (arr, ctypes.c_int(len(planes)), ctypes.c_int(int(bool(level_shift))), _stream(stream)), keep)
+
+
+def prepare_u8_i16_batch(mode, planes, level_shift=True, stream=None):
+    lib = _lib.load()
+    arr, keep = _plane_array(planes)
+    return Prepared(lib.mdct_fwd_u8_i16_batch if mode == "fwd" else lib.mdct_inv_i16_u8_batch, (arr, ctypes.c_int(len(planes)), ctypes.c_int(int(bool(level_shift))), _stream(stream)), keep)
 
 
 def prepare_roundtrip_u8(src, dst, sizeX, sizeY, lut=None, level_shift=True, stream=None):

@@ -606,7 +606,19 @@ struct BatchInput
   std::vector<unsigned char> bounded;  // per plane: lut_bounded() (int16 planes) / u8_table_is_tame() (8-bit planes)
 };
 
-constexpr int kModeRoundtripU8 = 3; // internal: the fused 8-bit round trip (k_u8_batch); the public modes are MDCT_MODE_*
+// internal batch modes beside the public MDCT_MODE_*: the 8-bit tile kernel (k_u8_batch) as fused round trip, pixels -> coefficients, coefficients -> pixels
+constexpr int kModeRoundtripU8 = 3, kModeFwdU8 = 4, kModeInvU8 = 5;
+inline bool is_u8_mode(int mode) { return mode >= kModeRoundtripU8 && mode <= kModeInvU8; }
+
+// what the layout code sees of a plane of the mixed (8-bit pixels <-> int16 coefficients) batches
+struct GenPlane
+{
+  const void *from;
+  void *to;
+  size_t pitch_in, pitch_out; // bytes on the pixel side, elements on the coefficient side
+  size_t sizeX, sizeY;
+  const float *lut;
+};
 
 // 8-bit planes: pitches in bytes, no alignment requirement (the reference's loads are unaligned too, simd_dct.cpp:2109)
 int u8_plane_args(const void *from, const void *to, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1)
@@ -640,11 +652,21 @@ bool u8_table_is_tame(const float *lut)
   return ss <= 40000.0 * 40000.0;
 }
 
+// every |entry| >= 1/16 (or no table): |coefficient / lut| <= 16 * 2040 for 8-bit pixels, inside int16 -- the forward 8-bit batch may leave its saturations out
+bool u8_table_is_bounded(const float *lut)
+{
+  for (int i = 0; lut && i < 64; i++)
+    if (!(fabsf(lut[i]) >= 0.0625f))
+      return false;
+  return true;
+}
+
 template <class Plane>
 int batch_input(int mode, const Plane *planes, int n, BatchInput &in)
 {
-  constexpr bool U8 = std::is_same<Plane, mdct_plane_u8>::value;
-  if (U8 ? mode != kModeRoundtripU8 : (mode != mdct::MODE_FWD && mode != mdct::MODE_INV && mode != mdct::MODE_ROUNDTRIP))
+  constexpr bool U8 = std::is_same<Plane, mdct_plane_u8>::value, GEN = std::is_same<Plane, GenPlane>::value;
+  const bool mode_ok = U8 ? mode == kModeRoundtripU8 : (GEN ? (mode == kModeFwdU8 || mode == kModeInvU8) : (mode == mdct::MODE_FWD || mode == mdct::MODE_INV || mode == mdct::MODE_ROUNDTRIP));
+  if (!mode_ok)
     return fail(MDCT_INVALID_PARAMETER, "batch mode %d (MDCT_MODE_FWD / _INV / _ROUNDTRIP)", mode);
   if (n < 0 || (planes == nullptr && n > 0))
     return fail(MDCT_INVALID_PARAMETER, "null plane list");
@@ -657,14 +679,20 @@ int batch_input(int mode, const Plane *planes, int n, BatchInput &in)
   { // validate everything before launching anything
     const Plane &p = planes[i];
     int r;
-    if constexpr (U8)
+    if constexpr (U8 || GEN)
       r = u8_plane_args(p.from, p.to, p.pitch_in, p.pitch_out, p.sizeX, p.sizeY, 0, p.sizeY / 8);
     else
       r = own_plane_args(p.from, p.to, sizeof(int16_t), p.pitch_in, p.pitch_out, p.sizeX, p.sizeY, 0, p.sizeY / 8);
     if (r)
       return r;
+    if constexpr (GEN)
+    { // the coefficient side is read / written as 16-byte rows per lane
+      const bool fwd = mode == kModeFwdU8;
+      if ((((uintptr_t)(fwd ? p.to : p.from)) | ((fwd ? p.pitch_out : p.pitch_in) * sizeof(int16_t))) & 15)
+        return fail(MDCT_INVALID_PARAMETER, "coefficient rows must be 16-byte aligned");
+    }
     in.has_lut[i] = p.lut != nullptr;
-    in.bounded[i] = U8 ? u8_table_is_tame(p.lut) : lut_bounded(p.lut);
+    in.bounded[i] = U8 ? u8_table_is_tame(p.lut) : (GEN ? (mode == kModeFwdU8 && u8_table_is_bounded(p.lut)) : lut_bounded(p.lut));
     if (rt && !p.lut)
       continue; // the fused int16 round trip without a table needs no multipliers at all (1/64 rides in the rounding)
     int id = -1;
@@ -674,7 +702,7 @@ int batch_input(int mode, const Plane *planes, int n, BatchInput &in)
     if (id < 0)
     {
       mdct::OwnTables tb;
-      if ((r = make_own_tables(p.lut, tb, /*pair_order=*/rt || U8)))
+      if ((r = make_own_tables(p.lut, tb, /*pair_order=*/rt || U8 || GEN)))
         return r;
       id = (int)src.size();
       src.push_back(p.lut);
@@ -727,7 +755,7 @@ void u8_px_consts(int level_shift, float (&px)[4])
 
 hipError_t launch_batch(const BatchLaunch &l, int mode, hipStream_t s)
 {
-  return mode == kModeRoundtripU8 ? mdct::launch_u8_batch(l.args, l.total, l.sat, s) : mdct::launch_i16_batch(l.args, l.total, mode, l.lutmode, l.sat, s);
+  return is_u8_mode(mode) ? mdct::launch_u8_batch(l.args, l.total, mode - kModeRoundtripU8, l.sat, s) : mdct::launch_i16_batch(l.args, l.total, mode, l.lutmode, l.sat, s);
 }
 
 // no allocation on the device, no copy: descriptors and tables travel in the kernel arguments, as many planes per launch as fit
@@ -1161,6 +1189,47 @@ int mdct_batch_create(mdct_batch **out, int mode, const mdct_plane_i16 *planes, 
 int mdct_batch_create_u8(mdct_batch **out, const mdct_plane_u8 *planes, int n_planes, int level_shift) { return batch_create(out, kModeRoundtripU8, planes, n_planes, level_shift); }
 
 int mdct_roundtrip_u8_batch(const mdct_plane_u8 *planes, int n_planes, int level_shift, void *stream) { return run_batch(kModeRoundtripU8, planes, n_planes, level_shift, stream); }
+
+} // extern "C"
+
+// pixels <-> coefficients batches: the public struct names the two sides, the layout code wants source and destination
+static int gen_planes(const mdct_plane_u8_i16 *planes, int n, bool fwd, std::vector<GenPlane> &out)
+{
+  if (n < 0 || (planes == nullptr && n > 0))
+    return fail(MDCT_INVALID_PARAMETER, "null plane list");
+  out.resize(n > 0 ? n : 0);
+  for (int i = 0; i < n; i++)
+  {
+    const mdct_plane_u8_i16 &p = planes[i];
+    out[i] = fwd ? GenPlane{p.px, p.coef, p.pitch_px, p.pitch_coef, p.sizeX, p.sizeY, p.lut} : GenPlane{p.coef, p.px, p.pitch_coef, p.pitch_px, p.sizeX, p.sizeY, p.lut};
+  }
+  return MDCT_SUCCESS;
+}
+
+extern "C" {
+
+int mdct_fwd_u8_i16_batch(const mdct_plane_u8_i16 *planes, int n_planes, int level_shift, void *stream)
+{
+  std::vector<GenPlane> g;
+  const int r = gen_planes(planes, n_planes, true, g);
+  return r ? r : run_batch(kModeFwdU8, g.data(), n_planes, level_shift, stream);
+}
+
+int mdct_inv_i16_u8_batch(const mdct_plane_u8_i16 *planes, int n_planes, int level_shift, void *stream)
+{
+  std::vector<GenPlane> g;
+  const int r = gen_planes(planes, n_planes, false, g);
+  return r ? r : run_batch(kModeInvU8, g.data(), n_planes, level_shift, stream);
+}
+
+int mdct_batch_create_u8_i16(mdct_batch **out, int mode, const mdct_plane_u8_i16 *planes, int n_planes, int level_shift)
+{
+  if (mode != MDCT_MODE_FWD && mode != MDCT_MODE_INV)
+    return fail(MDCT_INVALID_PARAMETER, "batch mode %d (MDCT_MODE_FWD: pixels -> coefficients, MDCT_MODE_INV: coefficients -> pixels)", mode);
+  std::vector<GenPlane> g;
+  const int r = gen_planes(planes, n_planes, mode == MDCT_MODE_FWD, g);
+  return r ? r : batch_create(out, mode == MDCT_MODE_FWD ? kModeFwdU8 : kModeInvU8, g.data(), n_planes, level_shift);
+}
 
 // one plane, block rows [by0, by1): the strip as a batch of one (the same kernel, descriptors and table in the arguments)
 int mdct_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)

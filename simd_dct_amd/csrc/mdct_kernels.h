@@ -187,7 +187,8 @@ enum { BATCH_NO_LUT = 0, BATCH_ALL_LUT = 1, BATCH_MIXED = 2 };
 hipError_t launch_i16_batch(const BatchArgs &a, uint32_t total, int mode, int lutmode, bool sat, hipStream_t s);
 // the fused 8-bit round trip on the same descriptors (pointers / pitches in bytes); general: some plane's table needs the saturating
 // quantiser or the clamping output stage (mdct_api.hip: u8_table_is_tame)
-hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, bool general, hipStream_t s);
+// mode: 0 the round trip, 1 pixels -> int16 coefficients, 2 int16 coefficients -> pixels (mdct_kernels.hip: U8_RT / U8_FWD / U8_INV)
+hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, int mode, bool general, hipStream_t s);
 
 hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool safe, hipStream_t s);
 // lut_bounded / luts_bounded: every entry of every table >= 8.01 in magnitude (a quantised coefficient cannot leave int16)

@@ -1704,35 +1704,94 @@ __device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t v)
   asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v));
   return r;
 }
-template <bool SAT, int FIN, bool PRIO>
-__device__ __forceinline__ void u8_roundtrip_rows(const DctConsts &C, const f32x2 shift_magic, const f32x2 lo_hi, const uint8_t *src, uint8_t *dst, size_t pitch_in, size_t pitch_out,
-                                                  uint32_t lane_off, kbytes_t tbp)
+// MODE: the fused round trip (pixels in, pixels out), or one half of it on the same tiles -- U8_FWD pixels -> quantised int16 coefficients
+// (bit for bit k_u8_i16<MODE_FWD>), U8_INV int16 coefficients -> pixels (k_u8_i16<MODE_INV>): what an encoder / a decoder runs on a frame's
+// planes in one launch.  The int16 side is a plane of 16-byte rows per lane (a tile row = 1 KiB), pitch in elements.
+enum { U8_RT = 0, U8_FWD = 1, U8_INV = 2 };
+template <int MODE, bool SAT, int FIN, bool PRIO>
+__device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_magic, const f32x2 lo_hi, const void *src, void *dst, size_t pitch_in, size_t pitch_out, uint32_t lane, kbytes_t tbp)
 {
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
-  uint2 rows[8];
-  load_block_rows_g(src, pitch_in, lane_off, rows);
-  MDCT_PHASE_PRIO(1);
   f32x2 P[4][8];
-#pragma unroll
-  for (int r = 0; r < 8; r++)
+  if constexpr (MODE != U8_INV)
   {
-    const f32x2 a01 = {ubyte_to_float<0>(rows[r].x), ubyte_to_float<1>(rows[r].x)}, a23 = {ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
-    const f32x2 a45 = {ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)}, a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
-    aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
+    uint2 rows[8];
+    load_block_rows_g(static_cast<const uint8_t *>(src), pitch_in, lane * 8, rows);
+    MDCT_PHASE_PRIO(1);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+    {
+      const f32x2 a01 = {ubyte_to_float<0>(rows[r].x), ubyte_to_float<1>(rows[r].x)}, a23 = {ubyte_to_float<2>(rows[r].x), ubyte_to_float<3>(rows[r].x)};
+      const f32x2 a45 = {ubyte_to_float<0>(rows[r].y), ubyte_to_float<1>(rows[r].y)}, a67 = {ubyte_to_float<2>(rows[r].y), ubyte_to_float<3>(rows[r].y)};
+      aan_fwd_h(K, a01, a23, a45, a67, P[0][r], P[1][r], P[2][r], P[3][r]);
+    }
+  }
+  else
+  { // coefficient row v of the block: (c0,c1)(c2,c3)(c4,c5)(c6,c7) in four dwords -> the pairs the column pass works on, (v, A[j]) / (v, B[j])
+    const RowsTiled in{static_cast<const int16_t *>(src), nullptr, pitch_in, 0, lane * 16};
+    uint4 rows[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++)
+      rows[v] = in.ld(v);
+    MDCT_PHASE_PRIO(1);
+#pragma unroll
+    for (int v = 0; v < 8; v++)
+    {
+      const uint4 w = rows[v];
+      P[0][v] = f32x2{(float)(int16_t)(w.x & 0xFFFF), (float)(int16_t)(w.z & 0xFFFF)}; // (c0, c4)
+      P[1][v] = f32x2{(float)(int16_t)(w.y & 0xFFFF), (float)(int16_t)(w.w & 0xFFFF)}; // (c2, c6)
+      P[2][v] = f32x2{(float)(int16_t)(w.z >> 16), (float)(int16_t)(w.y >> 16)};       // (c5, c3)
+      P[3][v] = f32x2{(float)(int16_t)(w.x >> 16), (float)(int16_t)(w.w >> 16)};       // (c1, c7)
+    }
   }
   MDCT_PHASE_PRIO(2);
 #pragma unroll
   for (int j = 0; j < 4; j++)
   {
-    aan_fwd_v(K, P[j]);
-    if (j == 0)
-      P[0][0].x = P[0][0].x - shift_magic.x; // the level shift is exactly "raw DC minus 64 * 128"
     karg_pairs_t tq = (karg_pairs_t)(tbp + offsetof(OwnTables, qf)) + j * 8, td = (karg_pairs_t)(tbp + offsetof(OwnTables, dq)) + j * 8;
-    asm volatile("" : "+s"(tq), "+s"(td)); // two s_load_dwordx16 per j, right where they are used (i16_roundtrip_rows)
-    quant_dequant_pairs<SAT>(K, P[j], tq, td);
-    aan_inv_v(K, P[j]);
+    asm volatile("" : "+s"(tq), "+s"(td)); // the pairs' multipliers by scalar loads, right where they are used (i16_roundtrip_rows)
+    if constexpr (MODE != U8_INV)
+    {
+      aan_fwd_v(K, P[j]);
+      if (j == 0)
+        P[0][0].x = P[0][0].x - shift_magic.x; // the level shift is exactly "raw DC minus 64 * 128"
+    }
+    if constexpr (MODE == U8_RT)
+      quant_dequant_pairs<SAT>(K, P[j], tq, td);
+    else if constexpr (MODE == U8_FWD)
+    { // c = sat_i16(rne(y * qf)): clamp (SAT), then the magic add leaves the int16 in the low half of the word (store_i16x8<0>)
+#pragma unroll
+      for (int v = 0; v < 8; v++)
+      {
+        f32x2 m;
+        MDCT_PKM(m, P[j][v], tq[v], MDCT_K_LH);
+        if constexpr (SAT)
+        {
+          m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
+          m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
+        }
+        MDCT_PKA(P[j][v], m, K.magic, MDCT_K_LL);
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int v = 0; v < 8; v++)
+        MDCT_PKM(P[j][v], P[j][v], td[v], MDCT_K_LH); // z = c * dq
+    }
+    if constexpr (MODE != U8_FWD)
+      aan_inv_v(K, P[j]);
   }
   MDCT_PHASE_PRIO(3);
+  if constexpr (MODE == U8_FWD)
+  {
+    const RowsTiled out{nullptr, static_cast<int16_t *>(dst), 0, pitch_out, lane * 16};
+#pragma unroll
+    for (int v = 0; v < 8; v++)
+      out.st(v, pack_lo16(__float_as_uint(P[0][v].x), __float_as_uint(P[3][v].x)), pack_lo16(__float_as_uint(P[1][v].x), __float_as_uint(P[2][v].y)),
+             pack_lo16(__float_as_uint(P[0][v].y), __float_as_uint(P[2][v].x)), pack_lo16(__float_as_uint(P[1][v].y), __float_as_uint(P[3][v].y)));
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 8; r++)
   {
@@ -1763,7 +1822,7 @@ __device__ __forceinline__ void u8_roundtrip_rows(const DctConsts &C, const f32x
       w1 = pack4_lo8(__float_as_uint(b43.x), __float_as_uint(b25.y), __float_as_uint(b16.y), __float_as_uint(b07.y));
     }
     const u32x2_unaligned_g w = {w0, w1};
-    __builtin_nontemporal_store(w, reinterpret_cast<u32x2_unaligned_g __attribute__((address_space(1))) *>(sgpr_ptr(dst + (size_t)r * pitch_out) + lane_off));
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x2_unaligned_g __attribute__((address_space(1))) *>(sgpr_ptr(static_cast<uint8_t *>(dst) + (size_t)r * pitch_out) + lane * 8));
   }
 }
 
@@ -1776,17 +1835,22 @@ __device__ __forceinline__ void u8_roundtrip_rows(const DctConsts &C, const f32x
 #ifndef MDCT_U8B_PRIO
 #define MDCT_U8B_PRIO true
 #endif
-// GENERAL = false: every plane's table is tame (mdct_api.hip: u8_table_is_tame): no saturations, FIN_SATPK
-template <bool GENERAL, bool SMALL>
+// GENERAL = false: every plane's table is tame (mdct_api.hip: u8_table_is_tame / u8_table_is_bounded): no saturations in the quantiser and,
+// for the round trip, the v_sat_pk_u8_i16 output stage.  U8_INV is always GENERAL: its coefficients are the caller's, not a transform's.
+template <int MODE, bool GENERAL, bool SMALL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT_U8B_WAVES_SMALL : MDCT_U8B_WAVES, SMALL ? MDCT_U8B_WAVES_SMALL : MDCT_U8B_WAVES))) void k_u8_batch(BatchArgs a)
 {
+  static_assert(MODE != U8_INV || GENERAL, "the inverse clamps its output");
   const BatchTile t = batch_tile(blockIdx.x);
   if (t.tile * 64 + threadIdx.x >= t.bpr())
     return;
   const size_t pin = t.pitch_in(), pout = t.pitch_out();
   const f32x2 shift_magic = {a.px[0], a.px[1]}, lo_hi = {a.px[2], a.px[3]};
-  u8_roundtrip_rows<GENERAL, GENERAL ? FIN_CLAMP : FIN_SATPK, MDCT_U8B_PRIO>(a.consts, shift_magic, lo_hi, (const uint8_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.tile * 512,
-                                                                     (uint8_t *)t.to() + (size_t)t.row * 8 * pout + (size_t)t.tile * 512, pin, pout, threadIdx.x * 8, t.tables);
+  // a tile = 64 blocks of one block row: 512 bytes of every pixel row, 512 elements of every coefficient row
+  constexpr size_t in_el = MODE == U8_INV ? 2 : 1, out_el = MODE == U8_FWD ? 2 : 1;
+  const char *src = (const char *)t.from() + ((size_t)t.row * 8 * pin + (size_t)t.tile * 512) * in_el;
+  char *dst = (char *)t.to() + ((size_t)t.row * 8 * pout + (size_t)t.tile * 512) * out_el;
+  u8_rows<MODE, GENERAL, (GENERAL || MODE != U8_RT) ? FIN_CLAMP : FIN_SATPK, MDCT_U8B_PRIO>(a.consts, shift_magic, lo_hi, src, dst, pin, pout, threadIdx.x, t.tables);
 }
 
 // 8-bit pixels <-> int16 coefficients (JPEG-style pair): u8 rows are 8 B per lane (512 B per wave
@@ -2549,24 +2613,29 @@ hipError_t launch_i16_batch(const BatchArgs &a, uint32_t total, int mode, int lu
   return total > 2048 && total <= kTileSmallLaunch ? launch_i16_batch_w<true>(a, total, mode, lutmode, sat, s) : launch_i16_batch_w<false>(a, total, mode, lutmode, sat, s);
 }
 
-hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, bool general, hipStream_t s)
+template <int MODE, bool GENERAL>
+static hipError_t launch_u8_batch_m(const BatchArgs &a, uint32_t total, hipStream_t s)
+{
+  const dim3 g(total), b(64);
+  if (total > 2048 && total <= kTileSmallLaunch)
+    hipLaunchKernelGGL((k_u8_batch<MODE, GENERAL, true>), g, b, 0, s, a);
+  else
+    hipLaunchKernelGGL((k_u8_batch<MODE, GENERAL, false>), g, b, 0, s, a);
+  return hipGetLastError();
+}
+
+// mode: U8_RT / U8_FWD / U8_INV
+hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, int mode, bool general, hipStream_t s)
 {
   if (total == 0)
     return hipSuccess;
-  const dim3 g(total), b(64);
-  const bool small = total > 2048 && total <= kTileSmallLaunch;
-  if (general)
+  switch (mode)
   {
-    if (small)
-      hipLaunchKernelGGL((k_u8_batch<true, true>), g, b, 0, s, a);
-    else
-      hipLaunchKernelGGL((k_u8_batch<true, false>), g, b, 0, s, a);
+  case U8_RT: return general ? launch_u8_batch_m<U8_RT, true>(a, total, s) : launch_u8_batch_m<U8_RT, false>(a, total, s);
+  case U8_FWD: return general ? launch_u8_batch_m<U8_FWD, true>(a, total, s) : launch_u8_batch_m<U8_FWD, false>(a, total, s);
+  case U8_INV: return launch_u8_batch_m<U8_INV, true>(a, total, s);
   }
-  else if (small)
-    hipLaunchKernelGGL((k_u8_batch<false, true>), g, b, 0, s, a);
-  else
-    hipLaunchKernelGGL((k_u8_batch<false, false>), g, b, 0, s, a);
-  return hipGetLastError();
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_clock_probe(unsigned long long *out, unsigned int ticks, unsigned int waves, hipStream_t s)

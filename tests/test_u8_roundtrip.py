@@ -360,3 +360,99 @@ def test_config3_frame_u8_in_one_launch(cuda):
         err = got.astype(np.int32) - src.astype(np.int32)
         # the synthetic "photo" carries +-24 levels of uniform noise (std 14.1) that the Annex-K tables quantise away: the error is that noise
         assert np.sqrt((err ** 2).mean()) < 16.0, i
+
+
+# ----------------------------------------------------------------------------------------------- the two halves on plane batches
+def test_u8_i16_batch_status_codes_without_device():
+    G.build_hip()
+    lib = _lib.load()
+    px = np.zeros(64 * 16, dtype=np.uint8)
+    co = np.zeros(64 * 16 + 8, dtype=np.int16)
+    ok = (px, co, 64, 16, None)
+    for mode in ("fwd", "inv"):
+        assert api.u8_i16_batch(mode, [ok, (px, None, 64, 16, None)], check=False) == 1  # null pointer
+        assert api.u8_i16_batch(mode, [ok, (px, co, 60, 16, None)], check=False) == 2  # not a multiple of 8x8
+        assert api.u8_i16_batch(mode, [ok, (px, co[1:], 64, 8, None)], check=False) == 1 and "16-byte" in api.last_error()  # coefficient rows misaligned
+        assert api.u8_i16_batch(mode, [(px, co, 64, 16, None, 64, 68)], check=False) == 1  # coefficient pitch not a multiple of 8 elements
+    assert lib.mdct_fwd_u8_i16_batch(None, 1, 1, None) == 1
+    h = ctypes.c_void_p()
+    arr, _keep = api._plane_array([ok])
+    assert lib.mdct_batch_create_u8_i16(ctypes.byref(h), 2, arr, 1, 1) == 1 and not h  # MDCT_MODE_ROUNDTRIP is not a mode of this call
+
+
+@gpu
+def test_u8_i16_batches_equal_the_single_plane_calls_and_the_oracle(cuda):
+    """mdct_fwd_u8_i16_batch / mdct_inv_i16_u8_batch: mixed shapes (partial tiles), pitches on both sides, shared / distinct / no / wild tables, both
+    level shifts, both forms (kernel arguments, device table): every plane equals mdct_fwd_u8_i16 / mdct_inv_i16_u8 on the device and the checker;
+    the inverse is fed arbitrary int16 coefficients, extremes included (its output stage clamps)"""
+    import oracle as O
+
+    torch = cuda
+    T = _tables()
+    shapes = [(1920, 32), (8, 8), (72, 24), (520, 16), (512, 8), (200, 40), (3840, 16)]
+    rng = np.random.default_rng(8)
+    for luts, pad, shift in (([None] * 7, 0, True), ([JPEG_LUMA, JPEG_CHROMA, JPEG_CHROMA, None, T["tiny"], _lut(10), T["mixed"]], 16, True), ([T["huge"], JPEG_LUMA, T["ones"], T["sixteenth"], None, T["negative"], T["edge"]], 8, False)):
+        for form in ("args", "device"):
+            px_np = [synth.plane_u8_np(w, h, "photo" if i % 2 else "noise", seed=60 + i) for i, (w, h) in enumerate(shapes)]
+            px = [torch.from_numpy(np.pad(a, ((0, 0), (0, pad)), constant_values=9)).cuda() for a in px_np]
+            coef = [torch.full((h, w + pad), -21846, dtype=torch.int16, device="cuda") for (w, h) in shapes]
+            desc = [(p, c, w, h, l, w + pad, w + pad) for p, c, (w, h), l in zip(px, coef, shapes, luts)]
+            if form == "args":
+                api.u8_i16_batch("fwd", desc, level_shift=shift)
+            else:
+                b = api.Batch("fwd_u8_i16", desc, level_shift=shift)
+                assert b.launches == 1
+                b.run()
+                b.close()
+            torch.cuda.synchronize()
+            for i, ((w, h), l) in enumerate(zip(shapes, luts)):
+                got = coef[i].cpu().numpy()
+                assert np.array_equal(got[:, :w], O.u8_i16("fwd", px_np[i], w, h, lut=l, level_shift=shift)) and (got[:, w:] == -21846).all(), ("fwd", form, i)
+                single = torch.empty((h, w), dtype=torch.int16, device="cuda")
+                api.fwd_u8_i16(torch.from_numpy(px_np[i]).cuda(), single, w, h, lut=l, level_shift=shift)
+                assert torch.equal(single, coef[i][:, :w]), ("fwd vs single", i)
+            # the inverse on arbitrary coefficients
+            co_np = [rng.integers(-32768, 32768, (h, w), dtype=np.int16) if i % 3 == 0 else rng.integers(-600, 600, (h, w), dtype=np.int16) for i, (w, h) in enumerate(shapes)]
+            co = [torch.from_numpy(np.pad(a, ((0, 0), (0, pad)), constant_values=5)).cuda() for a in co_np]
+            out = [torch.full((h, w + pad), CANARY, dtype=torch.uint8, device="cuda") for (w, h) in shapes]
+            idesc = [(o, c, w, h, l, w + pad, w + pad) for o, c, (w, h), l in zip(out, co, shapes, luts)]
+            if form == "args":
+                api.u8_i16_batch("inv", idesc, level_shift=shift)
+            else:
+                b = api.Batch("inv_i16_u8", idesc, level_shift=shift)
+                assert b.launches == 1
+                b.run()
+                b.close()
+            torch.cuda.synchronize()
+            for i, ((w, h), l) in enumerate(zip(shapes, luts)):
+                got = out[i].cpu().numpy()
+                assert np.array_equal(got[:, :w], O.u8_i16("inv", co_np[i], w, h, lut=l, level_shift=shift)) and (got[:, w:] == CANARY).all(), ("inv", form, i)
+                single = torch.empty((h, w), dtype=torch.uint8, device="cuda")
+                api.inv_i16_u8(torch.from_numpy(co_np[i]).cuda(), single, w, h, lut=l, level_shift=shift)
+                assert torch.equal(single, out[i][:, :w]), ("inv vs single", i)
+
+
+@gpu
+def test_config3_frame_forward_then_inverse_batch_equals_the_fused_round_trip(cuda):
+    """the configs[2] frame at full size: one forward launch (pixels -> quantised coefficients of Y, Cb, Cr), one inverse launch, and the
+    fused 8-bit round trip give the same pixels; the coefficients equal the checker's (chroma plane in full)"""
+    import oracle as O
+
+    torch = cuda
+    luts = [JPEG_LUMA, JPEG_CHROMA, JPEG_CHROMA]
+    px = [synth.plane_u8_torch(w, h, "photo", seed=synth.SEED + k) for w, h, k, _ in synth.CONFIG3_PLANES]
+    coef = [torch.empty((h, w), dtype=torch.int16, device="cuda") for w, h, _, _ in synth.CONFIG3_PLANES]
+    back = [torch.full_like(p, CANARY) for p in px]
+    fused = [torch.full_like(p, CANARY) for p in px]
+    dims = [(w, h) for w, h, _, _ in synth.CONFIG3_PLANES]
+    fb = api.Batch("fwd_u8_i16", [(p, c, w, h, l) for p, c, (w, h), l in zip(px, coef, dims, luts)])
+    ib = api.Batch("inv_i16_u8", [(o, c, w, h, l) for o, c, (w, h), l in zip(back, coef, dims, luts)])
+    assert fb.launches == 1 and ib.launches == 1
+    fb.run()
+    ib.run()
+    api.roundtrip_u8_batch([(p, o, w, h, l) for p, o, (w, h), l in zip(px, fused, dims, luts)])
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(back[i], fused[i]), i
+    w, h = dims[1]
+    assert np.array_equal(coef[1].cpu().numpy(), O.u8_i16("fwd", px[1].cpu().numpy(), w, h, lut=JPEG_CHROMA))

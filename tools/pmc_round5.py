@@ -31,7 +31,9 @@ WANT = {
     "k_encq_scalar": ("k_fwd_quant_u8<2, 2, false, true>", None, 2 * W * H),
     "k_f32_tile_fwd": ("k_f32_tile<0>", None, 8 * W * H),
     "k_i16_batch_420": ("k_i16_batch<2, 1, false, false>", None, 4 * FR),
-    "k_u8_batch_420": ("k_u8_batch<false, false>", None, 2 * FR),
+    "k_u8_batch_420": ("k_u8_batch<0, false, false>", None, 2 * FR),
+    "k_u8_batch_420_fwd": ("k_u8_batch<1, false, false>", None, 3 * FR),
+    "k_u8_batch_420_inv": ("k_u8_batch<2, true, false>", None, 3 * FR),
     "k_i16_batch_fwd_256": ("k_i16_batch<0, 1, true, false>", 256 * 4096 * 64, 4 * 256 * 4096 * 4096),
     "k_u8_i16_fwd": ("k_u8_i16<0, true>", None, 3 * W * H),
     "k_u8_i16_inv": ("k_u8_i16<1, true>", None, 3 * W * H),

@@ -12,6 +12,7 @@ by name and grid size.
     q32 stereo_sse stereo_scalar encq_sse encq_scalar   the reference's five behaviours, 8192^2 (k_q32_tile, k_fwd_quant_u8<...>)
     f32                                          configs[4]: k_f32_tile forward
     frame420 frame420_u8                         configs[2]: the 8K 4:2:0 frame as int16 planes (k_i16_batch) / as 8-bit planes (k_u8_batch), one launch
+    frame420_u8_fwd frame420_u8_inv              the two halves of the 8-bit frame: pixels -> int16 coefficients / back, one launch each (k_u8_batch<1|2>)
     batch256                                     configs[3] on one GPU: 256 separately allocated 4096^2 planes, forward, ONE launch (17.2 GB)
     u8_i16_fwd u8_i16_inv                        k_u8_i16
     scan_i16 scan_q32 u8_records split420 huffman px_huffman jpeg_scan   the stages either side (8192^2)"""
@@ -25,7 +26,7 @@ import torch
 import simd_dct_amd as M
 from simd_dct_amd import synth
 
-ALL = ["copy", "roundtrip", "roundtrip_lut", "fwd", "inv", "q32", "stereo_sse", "stereo_scalar", "encq_sse", "encq_scalar", "f32", "frame420", "frame420_u8", "u8_i16_fwd", "u8_i16_inv",
+ALL = ["copy", "roundtrip", "roundtrip_lut", "fwd", "inv", "q32", "stereo_sse", "stereo_scalar", "encq_sse", "encq_scalar", "f32", "frame420", "frame420_u8", "frame420_u8_fwd", "frame420_u8_inv", "u8_i16_fwd", "u8_i16_inv",
        "scan_i16", "scan_q32", "u8_records", "split420", "huffman", "px_huffman", "jpeg_scan", "batch256"]
 which = sys.argv[1] if len(sys.argv) > 1 else "roundtrip"
 names = ALL if which == "all" else which.split(",")
@@ -105,6 +106,22 @@ def run(name):
         o = empty((H, W), torch.float32)
         for i in range(n):
             M.fwd_f32(a, o, W, H)
+    elif name in ("frame420_u8_fwd", "frame420_u8_inv"):
+        drop("i16", "u8")
+        frames = []
+        for f in range(2):
+            pl = []
+            for (w, h, so, tab) in synth.CONFIG3_PLANES:
+                a = up(synth.plane_u8_np(w, h, "photo", seed=synth.SEED + so + 10 * f))
+                pl.append((a, empty((h, w), torch.int16), w, h, K1 if tab == "luma" else K2))
+            frames.append(pl)
+        fb = [M.Batch("fwd_u8_i16", f) for f in frames]
+        for b in fb:
+            b.run()  # (the inverse reads real coefficients)
+        b = fb if name.endswith("fwd") else [M.Batch("inv_i16_u8", [(torch.empty_like(p), c, w, h, l) for (p, c, w, h, l) in f]) for f in frames]
+        for i in range(n):
+            b[i % 2].run()
+        torch.cuda.synchronize()
     elif name in ("frame420", "frame420_u8"):
         drop("i16", "u8")
         u8 = name.endswith("_u8")

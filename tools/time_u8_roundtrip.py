@@ -53,6 +53,12 @@ coefs = [torch.empty((4320, 7680), dtype=torch.int16, device="cuda") for _ in ra
 run("Y alone: mdct_fwd_u8_i16 (the first of the two calls it fuses)", [M.prepare_u8_i16("fwd", f[0][0], coefs[i % 2], 7680, 4320, lut=jl) for i, f in enumerate(frames)], 7680 * 4320, bpp=3)
 run("Y alone: mdct_inv_i16_u8 (the second)", [M.prepare_u8_i16("inv", coefs[i % 2], f[0][1], 7680, 4320, lut=jl) for i, f in enumerate(frames)], 7680 * 4320, bpp=3)
 del coefs
+fc = [[torch.empty((h, w), dtype=torch.int16, device="cuda") for (_, _, w, h, _) in f] for f in frames]
+fwd = [M.Batch("fwd_u8_i16", [(a, c, w, h, l) for (a, b, w, h, l), c in zip(f, cs)]) for f, cs in zip(frames, fc)]
+run("8K 4:2:0 frame u8 -> int16 coefficients, one launch (3 B/px)", [b.prepared() for b in fwd], fpx, bpp=3)
+inv = [M.Batch("inv_i16_u8", [(b, c, w, h, l) for (a, b, w, h, l), c in zip(f, cs)]) for f, cs in zip(frames, fc)]
+run("8K 4:2:0 frame int16 coefficients -> u8, one launch (3 B/px)", [b.prepared() for b in inv], fpx, bpp=3)
+del fc, fwd, inv
 run("8192^2 u8 stream copy of the same bytes", [M.prepare_stream_copy(a, b, 8192 * 8192) for a, b in big], 8192 * 8192)
 lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
 outs = [torch.empty(8192 * 8192, dtype=torch.uint8, device="cuda") for _ in range(2)]
