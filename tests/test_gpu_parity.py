@@ -1010,6 +1010,32 @@ def test_soak_random_differential():
             M.roundtrip_u8_batch(udesc, level_shift=shift)
         for a, o, (uw, uh), l in zip(usrc, u_out, ushapes, utabs):
             assert np.array_equal(o.cpu().numpy(), O.roundtrip_u8(a, uw, uh, lut=l, level_shift=shift)), (it, "u8 batch", uw, uh)
+        # either half of the same batch: pixels -> coefficients, then (on every third case: arbitrary) coefficients -> pixels
+        u_co = [torch.full((uh, uw), -21846, dtype=torch.int16, device="cuda") for (uw, uh) in ushapes]
+        hdesc = [(a, c, uw, uh, l) for a, c, (uw, uh), l in zip(u_in, u_co, ushapes, utabs)]
+        if it % 4 == 2:
+            hb = M.Batch("fwd_u8_i16", hdesc, level_shift=shift)
+            hb.run()
+            hb.close()
+        else:
+            M.u8_i16_batch("fwd", hdesc, level_shift=shift)
+        for a, c, (uw, uh), l in zip(usrc, u_co, ushapes, utabs):
+            assert np.array_equal(c.cpu().numpy(), O.u8_i16("fwd", a, uw, uh, lut=l, level_shift=shift)), (it, "u8 fwd batch", uw, uh)
+        if it % 3 == 1:
+            uco_np = [rng.integers(-32768, 32768, (uh, uw), dtype=np.int16) for (uw, uh) in ushapes]
+            u_co = [dev(a) for a in uco_np]
+        else:
+            uco_np = [c.cpu().numpy() for c in u_co]
+        u_back = [torch.full((uh, uw), 0xA5, dtype=torch.uint8, device="cuda") for (uw, uh) in ushapes]
+        idesc = [(o, c, uw, uh, l) for o, c, (uw, uh), l in zip(u_back, u_co, ushapes, utabs)]
+        if it % 4 == 3:
+            hb = M.Batch("inv_i16_u8", idesc, level_shift=shift)
+            hb.run()
+            hb.close()
+        else:
+            M.u8_i16_batch("inv", idesc, level_shift=shift)
+        for c, o, (uw, uh), l in zip(uco_np, u_back, ushapes, utabs):
+            assert np.array_equal(o.cpu().numpy(), O.u8_i16("inv", c, uw, uh, lut=l, level_shift=shift)), (it, "u8 inv batch", uw, uh)
         f = rng.normal(0, 300, (H2, W2)).astype(np.float32)
         fo = torch.empty((H2, W2), dtype=torch.float32, device="cuda")
         M.fwd_f32(dev(f), fo, W2, H2)

@@ -456,3 +456,69 @@ def test_config3_frame_forward_then_inverse_batch_equals_the_fused_round_trip(cu
         assert torch.equal(back[i], fused[i]), i
     w, h = dims[1]
     assert np.array_equal(coef[1].cpu().numpy(), O.u8_i16("fwd", px[1].cpu().numpy(), w, h, lut=JPEG_CHROMA))
+
+
+@gpu
+def test_u8_i16_batches_empty_many_planes_and_graph_capture(cuda):
+    """the two halves: an empty list and planes without blocks are not errors and write nothing; 70 planes with seven tables (more than the kernel
+    arguments hold: the argument form splits into several launches, the device form stays one); both forms captured into a graph and replayed"""
+    import oracle as O
+
+    torch = cuda
+    assert api.u8_i16_batch("fwd", []) == 0 and api.u8_i16_batch("inv", []) == 0
+    for mode in ("fwd_u8_i16", "inv_i16_u8"):
+        b = api.Batch(mode, [])
+        assert b.launches == 0 and b.run() == 0
+        b.close()
+    px = synth.plane_u8_torch(264, 16, "photo", seed=3)
+    co = torch.full((16, 264), -21846, dtype=torch.int16, device="cuda")
+    none_c = torch.full((8, 8), -21846, dtype=torch.int16, device="cuda")
+    api.u8_i16_batch("fwd", [(px, none_c, 0, 16, None, 264, 8), (px, co, 264, 16, JPEG_LUMA), (px, none_c, 264, 0, None, 264, 264)])
+    torch.cuda.synchronize()
+    assert (none_c == -21846).all() and np.array_equal(co.cpu().numpy(), O.u8_i16("fwd", px.cpu().numpy(), 264, 16, lut=JPEG_LUMA))
+
+    rng = np.random.default_rng(4)
+    shapes = [(8 * int(rng.integers(1, 160)), 8 * int(rng.integers(1, 6))) for _ in range(70)]
+    tabs = [JPEG_LUMA, JPEG_CHROMA, _lut(50), _lut(500), _tables()["ones"], _lut(7), _tables()["tiny"]]
+    luts = [tabs[i % 7] if i % 9 else None for i in range(70)]
+    px_np = [synth.plane_u8_np(w, h, "noise", seed=400 + i) for i, (w, h) in enumerate(shapes)]
+    pxs = [torch.from_numpy(a).cuda() for a in px_np]
+    want_c = [O.u8_i16("fwd", a, w, h, lut=l) for a, (w, h), l in zip(px_np, shapes, luts)]
+    want_p = [O.u8_i16("inv", c, w, h, lut=l) for c, (w, h), l in zip(want_c, shapes, luts)]
+    s = torch.cuda.Stream()
+    for form in ("args", "device", "graph/args", "graph/device"):
+        cos = [torch.full((h, w), -21846, dtype=torch.int16, device="cuda") for (w, h) in shapes]
+        back = [torch.full((h, w), CANARY, dtype=torch.uint8, device="cuda") for (w, h) in shapes]
+        fdesc = [(p, c, w, h, l) for p, c, (w, h), l in zip(pxs, cos, shapes, luts)]
+        idesc = [(o, c, w, h, l) for o, c, (w, h), l in zip(back, cos, shapes, luts)]
+        fb, ib = api.Batch("fwd_u8_i16", fdesc), api.Batch("inv_i16_u8", idesc)
+        assert fb.launches == 1 and ib.launches == 1
+
+        def both(stream=None):
+            if form.endswith("args"):
+                api.u8_i16_batch("fwd", fdesc, stream=stream)
+                api.u8_i16_batch("inv", idesc, stream=stream)
+            else:
+                fb.run(stream=stream)
+                ib.run(stream=stream)
+
+        if form.startswith("graph"):
+            with torch.cuda.stream(s):
+                both(s)  # tables seen once outside the capture
+            s.synchronize()
+            for t in cos:
+                t.fill_(-21846)
+            for t in back:
+                t.fill_(CANARY)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                both(s)
+            g.replay()
+        else:
+            both()
+        torch.cuda.synchronize()
+        for i in range(70):
+            assert np.array_equal(cos[i].cpu().numpy(), want_c[i]), (form, "fwd", i, shapes[i])
+            assert np.array_equal(back[i].cpu().numpy(), want_p[i]), (form, "inv", i, shapes[i])
+        fb.close()
+        ib.close()
