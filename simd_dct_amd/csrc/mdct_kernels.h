@@ -98,15 +98,14 @@ struct I16Args
 };
 
 struct U8I16Args
-{
-  uint8_t *px;    // pixels: input of the forward, output of the inverse
-  int16_t *coef;  // coefficients: output of the forward, input of the inverse
+{ // one plane, 8-bit pixels -> quantised int16 coefficients (k_u8_i16_fwd)
+  const uint8_t *px;
+  int16_t *coef;
   OwnTables tb;
   DctConsts consts;
   size_t pitch_px, pitch_coef; // bytes / elements
   uint32_t bpr, by0, nblocks;
-  float dc_shift;              // forward: 64*128 when level-shifting, else 0
-  float px_lo, px_hi, px_magic; // inverse: clamp bounds and rounding constant (shift folded in)
+  float dc_shift;              // 64*128 when level-shifting, else 0
 };
 
 struct U8RecArgs
@@ -193,7 +192,7 @@ hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, int mode, bool ge
 hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool safe, hipStream_t s);
 // lut_bounded / luts_bounded: every entry of every table >= 8.01 in magnitude (a quantised coefficient cannot leave int16)
 hipError_t launch_i16(const I16Args &a, int mode, bool has_lut, hipStream_t s, bool lut_bounded = false);
-hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s);
+hipError_t launch_u8_i16_fwd(const U8I16Args &a, hipStream_t s);
 hipError_t launch_u8_records(const U8RecArgs &a, bool i16_in, hipStream_t s, bool clamp = true);
 hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, bool clamp, uint32_t n_rows, hipStream_t s);
 hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s);

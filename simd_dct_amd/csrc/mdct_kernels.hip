@@ -1683,10 +1683,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? 4 : 
 // ---------------------------------------------------------------------------------------
 // 8-bit pixels in, 8-bit pixels out: forward -> quantise -> dequantise -> inverse in one pass (BASELINE.json configs[2] as SURVEY.md
 // 8(d) states it: u8 planes, 2 bytes per pixel; the reference's pixel type, simd_dct.cpp:2107-2143, and the half of the codec it
-// does not have).  Bit for bit k_u8_i16<FWD> followed by k_u8_i16<INV>; the int16 coefficients exist only in registers.
+// does not have).  Bit for bit the forward half (k_u8_i16_fwd == k_u8_batch<U8_FWD>) followed by the inverse half (k_u8_batch<U8_INV>); the int16 coefficients exist only in registers.
 //   rows in      8 x 8 B per lane (a tile row = 512 contiguous bytes per wave load), v_cvt_f32_ubyteN
 //   forward      aan_fwd_h per row, aan_fwd_v per column pair -- the packed butterflies of i16_roundtrip_rows; the level shift is
-//                "raw DC - 64 * 128" (k_u8_i16)
+//                "raw DC - 64 * 128" (k_u8_i16_fwd)
 //   quantiser    c = sat_i16(rne(y * qf)), z = c * dq on register pairs; SAT = false (host: every table entry >= 1/16 in
 //                magnitude, so |y / lut| <= 16 * 2040 stays inside int16) leaves the saturations out
 //   inverse      aan_inv_v, aan_inv_h
@@ -1705,7 +1705,7 @@ __device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t v)
   return r;
 }
 // MODE: the fused round trip (pixels in, pixels out), or one half of it on the same tiles -- U8_FWD pixels -> quantised int16 coefficients
-// (bit for bit k_u8_i16<MODE_FWD>), U8_INV int16 coefficients -> pixels (k_u8_i16<MODE_INV>): what an encoder / a decoder runs on a frame's
+// (bit for bit k_u8_i16_fwd), U8_INV int16 coefficients -> pixels: what an encoder / a decoder runs on a frame's
 // planes in one launch.  The int16 side is a plane of 16-byte rows per lane (a tile row = 1 KiB), pitch in elements.
 enum { U8_RT = 0, U8_FWD = 1, U8_INV = 2 };
 template <int MODE, bool SAT, int FIN, bool PRIO>
@@ -1853,16 +1853,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT
   u8_rows<MODE, GENERAL, (GENERAL || MODE != U8_RT) ? FIN_CLAMP : FIN_SATPK, MDCT_U8B_PRIO>(a.consts, shift_magic, lo_hi, src, dst, pin, pout, threadIdx.x, t.tables);
 }
 
-// 8-bit pixels <-> int16 coefficients (JPEG-style pair): u8 rows are 8 B per lane (512 B per wave
-// load/store), int16 rows 16 B per lane.  The level shift costs nothing: on the way in it is
-// exactly "raw DC minus 64*128" (all other AAN outputs are differences of exact integer sums, so
-// the offset cancels bit for bit), on the way out it rides in the rounding constant
-// (1.5*2^23 + 128 is even, so ties round as before and the low byte is rne(x) + 128).
+// 8-bit pixels -> int16 coefficients, one plane (the JPEG-style pair's forward half; the inverse of one plane is a batch of one through
+// k_u8_batch<U8_INV>, mdct_api.hip: mdct_inv_i16_u8): u8 rows are 8 B per lane (512 B per wave load), int16 rows 16 B per lane.  The level
+// shift costs nothing: it is exactly "raw DC minus 64*128" (all other AAN outputs are differences of exact integer sums, so the offset
+// cancels bit for bit).
 #ifndef MDCT_U8I16_WAVES
-#define MDCT_U8I16_WAVES 4 // measured: fwd 34.5 us with 4 (37.8 with 3, 36.4 with 6), inv 34.7
+#define MDCT_U8I16_WAVES 4 // measured: 34.5 us with 4 (37.8 with 3, 36.4 with 6) at 8192^2
 #endif
-template <int MODE, bool HAS_LUT>
-__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_WAVES, MDCT_U8I16_WAVES))) void k_u8_i16(U8I16Args a)
+__global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_WAVES, MDCT_U8I16_WAVES))) void k_u8_i16_fwd(U8I16Args a)
 {
   const uint32_t t = wg_index() * kWG + threadIdx.x;
   if (t >= a.nblocks)
@@ -1872,61 +1870,34 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_
   const size_t by = a.by0 + row;
   const DctConsts &C = a.consts;
   float b[8][8];
-  if constexpr (MODE == MODE_FWD)
+  const uint8_t *src = a.px + by * 8 * a.pitch_px + (size_t)bx * 8;
+  int16_t *dst = a.coef + by * 8 * a.pitch_coef + (size_t)bx * 8;
+  uint2 rows[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+    rows[r] = load8(src + (size_t)r * a.pitch_px);
+#pragma unroll
+  for (int r = 0; r < 8; r++)
   {
-    const uint8_t *src = a.px + by * 8 * a.pitch_px + (size_t)bx * 8;
-    int16_t *dst = a.coef + by * 8 * a.pitch_coef + (size_t)bx * 8;
-    uint2 rows[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-      rows[r] = load8(src + (size_t)r * a.pitch_px);
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-    {
-      b[r][0] = ubyte_to_float<0>(rows[r].x); b[r][1] = ubyte_to_float<1>(rows[r].x);
-      b[r][2] = ubyte_to_float<2>(rows[r].x); b[r][3] = ubyte_to_float<3>(rows[r].x);
-      b[r][4] = ubyte_to_float<0>(rows[r].y); b[r][5] = ubyte_to_float<1>(rows[r].y);
-      b[r][6] = ubyte_to_float<2>(rows[r].y); b[r][7] = ubyte_to_float<3>(rows[r].y);
-    }
-    raw_fwd(C, b);
-    b[0][0] = b[0][0] - a.dc_shift; // 8192 or 0
-#pragma unroll
-    for (int i = 0; i < 64; i++)
-      b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.tb.qf[i];
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-      store_i16x8<0>(C, dst + (size_t)r * a.pitch_coef, b[r]);
+    b[r][0] = ubyte_to_float<0>(rows[r].x); b[r][1] = ubyte_to_float<1>(rows[r].x);
+    b[r][2] = ubyte_to_float<2>(rows[r].x); b[r][3] = ubyte_to_float<3>(rows[r].x);
+    b[r][4] = ubyte_to_float<0>(rows[r].y); b[r][5] = ubyte_to_float<1>(rows[r].y);
+    b[r][6] = ubyte_to_float<2>(rows[r].y); b[r][7] = ubyte_to_float<3>(rows[r].y);
   }
-  else
-  {
-    const int16_t *src = a.coef + by * 8 * a.pitch_coef + (size_t)bx * 8;
-    uint8_t *dst = a.px + by * 8 * a.pitch_px + (size_t)bx * 8;
+  raw_fwd(C, b);
+  b[0][0] = b[0][0] - a.dc_shift; // 8192 or 0
 #pragma unroll
-    for (int r = 0; r < 8; r++)
-      unpack_i16x8(ld_stream16(src + (size_t)r * a.pitch_coef), b[r]);
+  for (int i = 0; i < 64; i++)
+    b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.tb.qf[i];
 #pragma unroll
-    for (int i = 0; i < 64; i++)
-      b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.tb.dq[i];
-    raw_inv(C, b);
-#pragma unroll
-    for (int r = 0; r < 8; r++)
-    {
-      uint32_t t8[8];
-#pragma unroll
-      for (int c = 0; c < 8; c++) // clamp so that rne(x) + shift lands in [0, 255], then the magic add
-        t8[c] = __float_as_uint(__builtin_amdgcn_fmed3f(b[r][c], a.px_lo, a.px_hi) + a.px_magic);
-      typedef unsigned int u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
-      const u32x2_unaligned w = {pack4_lo8(t8[0], t8[1], t8[2], t8[3]), pack4_lo8(t8[4], t8[5], t8[6], t8[7])};
-      __builtin_nontemporal_store(w, reinterpret_cast<u32x2_unaligned *>(dst + (size_t)r * a.pitch_px));
-    }
-  }
-  (void)HAS_LUT;
+  for (int r = 0; r < 8; r++)
+    store_i16x8<0>(C, dst + (size_t)r * a.pitch_coef, b[r]);
 }
 
 // Pixels (or an int16 plane, I16_IN) -> records in one pass (the encoder's front half): the forward
-// transform and quantiser of k_u8_i16<MODE_FWD> (k_i16<MODE_FWD>), then -- instead of storing the int16 plane and reading it back -- the zig-zag scan and
+// transform and quantiser of k_u8_i16_fwd (k_i16<MODE_FWD>), then -- instead of storing the int16 plane and reading it back -- the zig-zag scan and
 // run/level compaction of k_scan (scan_records.h) on the values still in registers.  1 B/px in, 3 B/px out
-// (k_u8_i16 + k_scan move 3 + 5).  Bit for bit the records mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 produce.
+// (k_u8_i16_fwd + k_scan move 3 + 5).  Bit for bit the records mdct_fwd_u8_i16 + mdct_zigzag_rle_i16 produce.
 // One wave per workgroup: every wave works alone on 64 consecutive blocks (lane = block).
 // CLAMP = false (8-bit pixels, every table entry >= 1/16 in magnitude or no table, decided on the host): |coefficient| <= 8 * 255, so the
 // quantised value cannot leave int16 and the 64 saturations per block are left out.
@@ -2650,14 +2621,11 @@ hipError_t launch_park_table(const OwnTables &tb, OwnTables *slot, hipStream_t s
   return hipGetLastError();
 }
 
-hipError_t launch_u8_i16(const U8I16Args &a, int mode, hipStream_t s)
+hipError_t launch_u8_i16_fwd(const U8I16Args &a, hipStream_t s)
 {
   if (a.nblocks == 0)
     return hipSuccess;
-  if (mode == MODE_FWD)
-    hipLaunchKernelGGL((k_u8_i16<MODE_FWD, true>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_u8_i16<MODE_INV, true>), dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
+  hipLaunchKernelGGL(k_u8_i16_fwd, dim3(grid_for(a.nblocks)), dim3(kWG), 0, s, a);
   return hipGetLastError();
 }
 

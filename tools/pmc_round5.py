@@ -33,10 +33,10 @@ WANT = {
     "k_i16_batch_420": ("k_i16_batch<2, 1, false, false>", None, 4 * FR),
     "k_u8_batch_420": ("k_u8_batch<0, false, false>", None, 2 * FR),
     "k_u8_batch_420_fwd": ("k_u8_batch<1, false, false>", None, 3 * FR),
-    "k_u8_batch_420_inv": ("k_u8_batch<2, true, false>", None, 3 * FR),
+    "k_u8_batch_420_inv": ("k_u8_batch<2, true, false>", 12420 * 64, 3 * FR),
     "k_i16_batch_fwd_256": ("k_i16_batch<0, 1, true, false>", 256 * 4096 * 64, 4 * 256 * 4096 * 4096),
-    "k_u8_i16_fwd": ("k_u8_i16<0, true>", None, 3 * W * H),
-    "k_u8_i16_inv": ("k_u8_i16<1, true>", None, 3 * W * H),
+    "k_u8_i16_fwd": ("k_u8_i16_fwd", None, 3 * W * H),
+    "k_u8_i16_inv": ("k_u8_batch<2, true, false>", (W // 8) * (H // 8), 3 * W * H),  # mdct_inv_i16_u8 = a batch of one
     "k_scan_i16_rle": ("k_scan<0, true>", None, 5 * W * H),
     "k_scan_q32_rle": ("k_scan<1, true>", None, 4 * W * H),
     "k_u8_records": ("k_u8_records<false, false>", None, 4 * W * H),

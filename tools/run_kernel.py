@@ -14,7 +14,7 @@ by name and grid size.
     frame420 frame420_u8                         configs[2]: the 8K 4:2:0 frame as int16 planes (k_i16_batch) / as 8-bit planes (k_u8_batch), one launch
     frame420_u8_fwd frame420_u8_inv              the two halves of the 8-bit frame: pixels -> int16 coefficients / back, one launch each (k_u8_batch<1|2>)
     batch256                                     configs[3] on one GPU: 256 separately allocated 4096^2 planes, forward, ONE launch (17.2 GB)
-    u8_i16_fwd u8_i16_inv                        k_u8_i16
+    u8_i16_fwd u8_i16_inv                        one plane: k_u8_i16_fwd / a batch of one through k_u8_batch<U8_INV>
     scan_i16 scan_q32 u8_records split420 huffman px_huffman jpeg_scan   the stages either side (8192^2)"""
 import os
 import sys
