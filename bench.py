@@ -489,6 +489,23 @@ def main():
             torch.cuda.synchronize()
             r["forward_then_inverse_equals_fused"] = all(torch.equal(a, b) for a, b in zip(back8, kept8))
             del coefs8, back8, fwd8, inv8
+            # the same frame as the REFERENCE's product (q32 layout, AVX2-tier bytes: parity pinned by the reference), one launch against the three
+            # calls the reference's caller makes (main.cpp:543); 2 B/px
+            qlut = [(M.QUANTIZE_BASE * np.float32(2000 if tab == "luma" else 1200)).astype(np.float32) for (_, _, _, tab) in synth.CONFIG3_PLANES]
+            qout = [[torch.empty(t[2] * t[3], dtype=torch.uint8, device="cuda") for t in frames8[i]] for i in range(NF8)]
+            q1 = [M.Batch("q32", [(t[0], o, t[2], t[3], l) for t, o, l in zip(frames8[i], qout[i], qlut)]).prepared() for i in range(NF8)]
+            q3 = [[M.prepare_fwd_quant_u8(t[0], o, l, t[2], t[3], 0, t[3] // 8) for t, o, l in zip(frames8[i], qout[i], qlut)] for i in range(NF8)]
+            for c in q3[0]:
+                c()
+            torch.cuda.synchronize()
+            three = [o.clone() for o in qout[0]]
+            for o in qout[0]:
+                o.zero_()
+            r["reference_q32_product_one_launch"] = rate(lambda i: q1[i % NF8](), 2 * fpx, n=300, warm=300)
+            torch.cuda.synchronize()
+            r["reference_q32_product_one_launch"]["equals_three_single_plane_calls"] = all(torch.equal(a, b) for a, b in zip(three, qout[0]))
+            r["reference_q32_product_three_calls_ms"] = round(rate(lambda i: [c() for c in q3[i % NF8]], 2 * fpx, n=300, warm=300)["ms"], 4)
+            del qout, q1, q3, three
             # the same kernel on one 8192x8192 8-bit plane (the bench's plane size; 134,217,728 B)
             one8 = [M.prepare_roundtrip_u8(u8s[i].view(H, W), u8d[i].view(H, W), W, H, lut=synth.JPEG_LUMA) for i in range(NSETS)]
             r["plane_8192_ms"] = round(rate(lambda i: one8[i % NSETS](), 2 * W * H, n=300, warm=300)["ms"], 4)
@@ -748,7 +765,8 @@ def main():
                 blk["valu"] = valu(ISA_NAME["k_u8_batch_420"], tiles3, c3u["ms"], c3u.get("clock_GHz"), "k_u8_batch_420")
                 blk["parity"] = "unpinned by the reference (it has no inverse); pinned by the CPU checker's composition orc_fwd_u8_i16 -> orc_inv_i16_u8 and equal to the two-call path on the device (tests/test_u8_roundtrip.py)"
                 for k in ("Mpx_s", "launches_per_call", "kernel_argument_form", "kernel_argument_form_equals_device_table_form", "four_frames_per_call_ms_per_frame", "y_plane_two_calls_ms", "y_plane_fused_ms",
-                          "plane_8192_ms", "plane_8192_Mpx_s", "forward_only_batch", "inverse_only_batch", "forward_then_inverse_equals_fused"):
+                          "plane_8192_ms", "plane_8192_Mpx_s", "forward_only_batch", "inverse_only_batch", "forward_then_inverse_equals_fused",
+                          "reference_q32_product_one_launch", "reference_q32_product_three_calls_ms"):
                     blk[k] = c3u.get(k)
                 line["roofline_config3_420_u8"] = blk
             c5 = extras.get("config5_f32_fwd", {})

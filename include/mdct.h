@@ -213,6 +213,18 @@ int mdct_roundtrip_u8_batch(const mdct_plane_u8 *planes, int n_planes, int level
 /* device-resident form: run with mdct_batch_run, free with mdct_batch_destroy (above) */
 int mdct_batch_create_u8(mdct_batch **batch, const mdct_plane_u8 *planes, int n_planes, int level_shift);
 
+/* The reference's primary product on a plane list (replaces a caller's loop of simdDCT_EncodeQuantize32ReorderBuffer calls over the planes of
+ * a frame, main.cpp:543 / simd_dct.cpp:113-133): per plane exactly
+ *     mdct_fwd_quant_u8_pitched(from, to, pitch_in, pitch_out, lut, sizeX, sizeY, 0, sizeY / 8, MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX)
+ * -- every block row, the reference's AVX2-tier arithmetic bit for bit (simd_dct.cpp:2064-2262) -- for any number of separately allocated
+ * planes with their own tables in ONE launch.  pitch_in: bytes between pixel rows; pitch_out: bytes between the 8 * sizeX-byte output
+ * strips of consecutive block rows (>= 8 * sizeX, a multiple of 16; 8 * sizeX = the reference's tight layout).  lut is required (HOST
+ * pointer to 64 floats); sizeX % 64 == 0 and sizeY % 8 == 0 as in the reference's dispatcher (:117), else MDCT_NOT_SUPPORTED.  A table
+ * that needs the exact x86 convert emulation (an entry beyond 2^17 in magnitude after scaling, inf, NaN) switches the whole call to it.
+ * Kernel-argument form (no allocation, capture-safe) and device-resident form (run with mdct_batch_run) as for the other batches. */
+int mdct_fwd_quant32_u8_batch(const mdct_plane_u8 *planes, int n_planes, void *stream);
+int mdct_batch_create_q32(mdct_batch **batch, const mdct_plane_u8 *planes, int n_planes);
+
 /* The two halves of that round trip on plane batches -- what an encoder (pixels -> quantised int16 coefficients) and a decoder
  * (coefficients -> pixels) run on the planes of a frame in ONE launch: per plane exactly mdct_fwd_u8_i16 / mdct_inv_i16_u8 over the
  * whole plane (3 bytes per pixel over HBM), on the tile kernel of the round trip.  pitch_px in bytes (no alignment requirement on the

@@ -78,6 +78,8 @@ SIGNATURES = {
     "mdct_inv_i16_u8_batch": (c_int, [ctypes.POINTER(PlaneU8), c_int, c_int, c_void_p]),
     "mdct_batch_create_u8_i16": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(PlaneU8), c_int, c_int]),
     "mdct_batch_create_u8": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(PlaneU8), c_int, c_int]),
+    "mdct_fwd_quant32_u8_batch": (c_int, [ctypes.POINTER(PlaneU8), c_int, c_void_p]),
+    "mdct_batch_create_q32": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(PlaneU8), c_int]),
     "mdct_batch_launches": (c_int, [c_void_p]),
     "mdct_batch_destroy": (c_int, [c_void_p]),
     "mdct_zigzag_rle_i16": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -268,6 +268,26 @@ def roundtrip_u8_batch(planes, level_shift=True, stream=None, check=True):
     return rc
 
 
+def _q32_planes(planes):
+    """(src, dst, sizeX, sizeY, lut[, pitch_in, strip pitch]): the output strip pitch defaults to the reference's tight 8 * sizeX"""
+    return [(p[0], p[1], p[2], p[3], p[4], p[5] if len(p) > 5 else None, p[6] if len(p) > 6 and p[6] is not None else 8 * p[2]) for p in planes]
+
+
+def fwd_quant32_u8_batch(planes, stream=None, check=True):
+    """mdct_fwd_quant32_u8_batch: the reference's q32 product (every block row) of a list of 8-bit planes, one launch;
+    planes = list of (src uint8, dst uint8, sizeX, sizeY, lut[, pitch_in bytes, output strip pitch bytes])"""
+    arr, keep = _plane_array(_q32_planes(planes))
+    rc = _lib.load().mdct_fwd_quant32_u8_batch(arr, len(planes), _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
+def prepare_fwd_quant32_u8_batch(planes, stream=None):
+    arr, keep = _plane_array(_q32_planes(planes))
+    return Prepared(_lib.load().mdct_fwd_quant32_u8_batch, (arr, ctypes.c_int(len(planes)), _stream(stream)), keep)
+
+
 def u8_i16_batch(mode, planes, level_shift=True, stream=None, check=True):
     """mdct_fwd_u8_i16_batch ('fwd') / mdct_inv_i16_u8_batch ('inv'): planes = list of (px uint8, coef int16, sizeX, sizeY, lut-or-None[, pitch_px bytes, pitch_coef elements])"""
     lib = _lib.load()
@@ -281,13 +301,16 @@ def u8_i16_batch(mode, planes, level_shift=True, stream=None, check=True):
 class Batch:
     """mdct_batch: descriptors and tables uploaded once, every run ONE launch (capture-safe).
     mode 'roundtrip_u8': 8-bit planes (mdct_batch_create_u8); 'fwd_u8_i16' / 'inv_i16_u8': (px, coef, ...) planes (mdct_batch_create_u8_i16);
+    'q32': 8-bit planes -> the reference's q32 product (mdct_batch_create_q32; pitch_out = output strip pitch, default 8 * sizeX);
     otherwise int16 planes."""
 
     def __init__(self, mode, planes, level_shift=True):
         lib = _lib.load()
-        arr, self._keep = _plane_array(planes)
+        arr, self._keep = _plane_array(_q32_planes(planes) if mode == "q32" else planes)
         h = ctypes.c_void_p()
-        if mode in ("fwd_u8_i16", "inv_i16_u8"):
+        if mode == "q32":
+            _check(lib.mdct_batch_create_q32(ctypes.byref(h), arr, len(planes)))
+        elif mode in ("fwd_u8_i16", "inv_i16_u8"):
             _check(lib.mdct_batch_create_u8_i16(ctypes.byref(h), MODES["fwd" if mode == "fwd_u8_i16" else "inv"], arr, len(planes), int(bool(level_shift))))
         elif mode == "roundtrip_u8":
             _check(lib.mdct_batch_create_u8(ctypes.byref(h), arr, len(planes), int(bool(level_shift))))

@@ -120,6 +120,32 @@ bool table_needs_safe(const float *q)
   return false;
 }
 
+// the reference tiers' constants as the packed-fp32 kernels take them (mdct_kernels.hip: PkConsts)
+static mdct::PkConstsArg pk_consts(bool q32, bool scalar)
+{
+  const mdct::DctConsts c;
+  // scalar tiers (mdct_kernels.hip: encode_block_pk): nm.y = the bias 127/255 of :245 / :362, bias = (255, 0.5 - 2^-25)
+  return mdct::PkConstsArg{{c.a, c.f}, {c.c, c.d}, {c.b, c.e}, {c.n, scalar ? 127.0f / 255.0f : (q32 ? c.magic23 + 128.0f : c.magic23)},
+                           {c.d, c.a}, {c.f, c.d}, {c.f, c.c}, {c.c, c.a},
+                           {scalar ? 255.0f : 1.f / (float)0xFF, scalar ? nextafterf(0.5f, 0.0f) : 127.0f},
+                           {1.f / 255.f, (float)(1.0 / 255.0 - (double)(1.f / 255.f))}}; // (c, c2): 0x3b808081, 0xaf7efeff
+}
+
+// the q32 product's multipliers 255 / (lut * 0.95) (simd_dct.cpp:2239) in the packed kernels' pair order: (v * 4 + j) * 2 + {0, 1} = coefficient
+// (v, kPairA[j]) / (v, kPairB[j]); the fast quantiser works on -v (complement trick), the safe one on v
+static void q32_pair_table(const float *lut, bool negate, float (&out)[64])
+{
+  static const int pa[4] = {0, 2, 1, 5}, pb[4] = {4, 6, 3, 7}; // == mdct::kPairA / kPairB
+  constexpr float vr = .95f;
+  for (int m = 0; m < 8; m++)
+    for (int j = 0; j < 4; j++)
+    {
+      const float qa = 255.0f / (lut[m * 8 + pa[j]] * vr), qb = 255.0f / (lut[m * 8 + pb[j]] * vr);
+      out[(m * 4 + j) * 2] = negate ? -qa : qa;
+      out[(m * 4 + j) * 2 + 1] = negate ? -qb : qb;
+    }
+}
+
 int own_plane_args(const void *from, const void *to, size_t esz, size_t pitch_in, size_t pitch_out, size_t sizeX, size_t sizeY, size_t by0, size_t by1)
 {
   if (from == nullptr || to == nullptr)
@@ -613,6 +639,7 @@ struct BatchInput
 // internal batch modes beside the public MDCT_MODE_*: the 8-bit tile kernel (k_u8_batch) as fused round trip, pixels -> coefficients, coefficients -> pixels
 constexpr int kModeRoundtripU8 = 3, kModeFwdU8 = 4, kModeInvU8 = 5;
 inline bool is_u8_mode(int mode) { return mode >= kModeRoundtripU8 && mode <= kModeInvU8; }
+constexpr int kModeQ32 = 6; // 8-bit planes -> the reference's q32 product (k_q32_batch)
 
 // what the layout code sees of a plane of the mixed (8-bit pixels <-> int16 coefficients) batches
 struct GenPlane
@@ -669,16 +696,31 @@ template <class Plane>
 int batch_input(int mode, const Plane *planes, int n, BatchInput &in)
 {
   constexpr bool U8 = std::is_same<Plane, mdct_plane_u8>::value, GEN = std::is_same<Plane, GenPlane>::value;
-  const bool mode_ok = U8 ? mode == kModeRoundtripU8 : (GEN ? (mode == kModeFwdU8 || mode == kModeInvU8) : (mode == mdct::MODE_FWD || mode == mdct::MODE_INV || mode == mdct::MODE_ROUNDTRIP));
+  const bool mode_ok = U8 ? (mode == kModeRoundtripU8 || mode == kModeQ32) : (GEN ? (mode == kModeFwdU8 || mode == kModeInvU8) : (mode == mdct::MODE_FWD || mode == mdct::MODE_INV || mode == mdct::MODE_ROUNDTRIP));
   if (!mode_ok)
     return fail(MDCT_INVALID_PARAMETER, "batch mode %d (MDCT_MODE_FWD / _INV / _ROUNDTRIP)", mode);
   if (n < 0 || (planes == nullptr && n > 0))
     return fail(MDCT_INVALID_PARAMETER, "null plane list");
-  const bool rt = mode == mdct::MODE_ROUNDTRIP;
+  const bool rt = mode == mdct::MODE_ROUNDTRIP, q32 = mode == kModeQ32;
   in.table_id.assign(n, -1);
   in.has_lut.assign(n, 0);
   in.bounded.assign(n, 0);
   std::vector<const float *> src; // what each distinct table was made from (nullptr = no quantisation)
+  bool q32_safe = false;          // q32: one form of the quantiser (and of its tables) for the whole call
+  if constexpr (U8)
+    for (int i = 0; q32 && i < n; i++)
+    { // argument checks in the order of the reference's dispatcher: null -> 1, shape -> 2 (simd_dct.cpp:117-118); the table is null-checked too
+      const Plane &p = planes[i];
+      if (p.from == nullptr || p.to == nullptr || p.lut == nullptr)
+        return fail(MDCT_INVALID_PARAMETER, "null pointer (plane %d)", i);
+      if (p.sizeX % 64 != 0 || p.sizeY % 8 != 0)
+        return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu: width must be a multiple of 64 and height of 8 for the q32 layout", p.sizeX, p.sizeY);
+      if (p.pitch_out < 8 * p.sizeX || p.pitch_out % 16 != 0)
+        return fail(MDCT_INVALID_PARAMETER, "output strip pitch %zu must be >= 8*sizeX = %zu and a multiple of 16", p.pitch_out, 8 * p.sizeX);
+      float q[64];
+      q32_pair_table(p.lut, false, q);
+      q32_safe = q32_safe || table_needs_safe(q);
+    }
   for (int i = 0; i < n; i++)
   { // validate everything before launching anything
     const Plane &p = planes[i];
@@ -696,7 +738,7 @@ int batch_input(int mode, const Plane *planes, int n, BatchInput &in)
         return fail(MDCT_INVALID_PARAMETER, "coefficient rows must be 16-byte aligned");
     }
     in.has_lut[i] = p.lut != nullptr;
-    in.bounded[i] = U8 ? u8_table_is_tame(p.lut) : (GEN ? (mode == kModeFwdU8 && u8_table_is_bounded(p.lut)) : lut_bounded(p.lut));
+    in.bounded[i] = q32 ? !q32_safe : (U8 ? u8_table_is_tame(p.lut) : (GEN ? (mode == kModeFwdU8 && u8_table_is_bounded(p.lut)) : lut_bounded(p.lut)));
     if (rt && !p.lut)
       continue; // the fused int16 round trip without a table needs no multipliers at all (1/64 rides in the rounding)
     int id = -1;
@@ -706,7 +748,12 @@ int batch_input(int mode, const Plane *planes, int n, BatchInput &in)
     if (id < 0)
     {
       mdct::OwnTables tb;
-      if ((r = make_own_tables(p.lut, tb, /*pair_order=*/rt || U8 || GEN)))
+      if (q32)
+      {
+        memset(&tb, 0, sizeof(tb));
+        q32_pair_table(p.lut, !q32_safe, tb.qf);
+      }
+      else if ((r = make_own_tables(p.lut, tb, /*pair_order=*/rt || U8 || GEN)))
         return r;
       id = (int)src.size();
       src.push_back(p.lut);
@@ -731,6 +778,7 @@ void batch_header(const mdct::BatchLayout &lay, const BatchInput &in, BatchLaunc
   mdct::BatchArgs &a = l.args;
   a.consts = mdct::DctConsts();
   memset(a.px, 0, sizeof(a.px));
+  a.pk = pk_consts(/*q32=*/true, /*scalar=*/false);
   memset(&a.head, 0, sizeof(a.head));
   a.head.n = (uint32_t)lay.descs.size();
   a.head.uniform = lay.uniform;
@@ -759,6 +807,8 @@ void u8_px_consts(int level_shift, float (&px)[4])
 
 hipError_t launch_batch(const BatchLaunch &l, int mode, hipStream_t s)
 {
+  if (mode == kModeQ32)
+    return mdct::launch_q32_batch(l.args, l.total, l.sat, s);
   return is_u8_mode(mode) ? mdct::launch_u8_batch(l.args, l.total, mode - kModeRoundtripU8, l.sat, s) : mdct::launch_i16_batch(l.args, l.total, mode, l.lutmode, l.sat, s);
 }
 
@@ -894,13 +944,7 @@ static int fwd_quant_u8(const uint8_t *from, uint8_t *to, size_t pitch_in, size_
     const bool negate = q32 && !safe; // the q32 fast quantiser works on -v (complement trick)
     for (int i = 0; i < 64; i++)
       a.qt.q[i] = negate ? -t[i] : t[i];
-    const mdct::DctConsts &c = a.consts;
-    const bool scalar = profile == MDCT_PROFILE_REF_SCALAR;
-    // scalar tiers (mdct_kernels.hip: encode_block_pk): nm.y = the bias 127/255 of :245 / :362, bias = (255, 0.5 - 2^-25)
-    a.pk = mdct::PkConstsArg{{c.a, c.f}, {c.c, c.d}, {c.b, c.e}, {c.n, scalar ? 127.0f / 255.0f : (q32 ? c.magic23 + 128.0f : c.magic23)},
-                             {c.d, c.a}, {c.f, c.d}, {c.f, c.c}, {c.c, c.a},
-                             {scalar ? 255.0f : 1.f / (float)0xFF, scalar ? nextafterf(0.5f, 0.0f) : 127.0f},
-                             {1.f / 255.f, (float)(1.0 / 255.0 - (double)(1.f / 255.f))}}; // (c, c2): 0x3b808081, 0xaf7efeff
+    a.pk = pk_consts(q32, profile == MDCT_PROFILE_REF_SCALAR);
   }
   a.pitch = pitch_in;
   a.sizeX = sizeX;
@@ -1199,6 +1243,11 @@ int mdct_batch_create(mdct_batch **out, int mode, const mdct_plane_i16 *planes, 
 int mdct_batch_create_u8(mdct_batch **out, const mdct_plane_u8 *planes, int n_planes, int level_shift) { return batch_create(out, kModeRoundtripU8, planes, n_planes, level_shift); }
 
 int mdct_roundtrip_u8_batch(const mdct_plane_u8 *planes, int n_planes, int level_shift, void *stream) { return run_batch(kModeRoundtripU8, planes, n_planes, level_shift, stream); }
+
+// the reference's primary product (q32 layout, AVX2-tier arithmetic: mdct_fwd_quant_u8 with MDCT_LAYOUT_Q32 / MDCT_PROFILE_REF_AVX over every
+// block row) on a plane list, one launch; pitch_out = bytes between the block rows' 8 * sizeX-byte output strips
+int mdct_fwd_quant32_u8_batch(const mdct_plane_u8 *planes, int n_planes, void *stream) { return run_batch(kModeQ32, planes, n_planes, 0, stream); }
+int mdct_batch_create_q32(mdct_batch **out, const mdct_plane_u8 *planes, int n_planes) { return batch_create(out, kModeQ32, planes, n_planes, 0); }
 
 } // extern "C"
 

@@ -176,6 +176,7 @@ struct BatchArgs
   const OwnTables *tables; // device memory, or nullptr: embedded (blob)
   DctConsts consts;
   alignas(8) float px[4];  // k_u8_batch only: (64 * shift, 1.5 * 2^23 + shift, -shift, 255 - shift), shift = 128 with the level shift, else 0
+  PkConstsArg pk;          // k_q32_batch only: the reference's AVX2-tier constants as register pairs (U8Args::pk)
   alignas(64) unsigned char blob[kBatchBlob]; // [tables][descriptors]
 };
 static_assert(offsetof(BatchArgs, descs) == 64 && offsetof(BatchArgs, tables) == 72, "the batch kernels read head + pointers as 20 consecutive dwords");
@@ -188,6 +189,8 @@ hipError_t launch_i16_batch(const BatchArgs &a, uint32_t total, int mode, int lu
 // quantiser or the clamping output stage (mdct_api.hip: u8_table_is_tame)
 // mode: 0 the round trip, 1 pixels -> int16 coefficients, 2 int16 coefficients -> pixels (mdct_kernels.hip: U8_RT / U8_FWD / U8_INV)
 hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, int mode, bool general, hipStream_t s);
+// the reference's q32 product on the same descriptors (pitch_out = bytes between the block rows' output strips); safe: some table needs the exact convert emulation
+hipError_t launch_q32_batch(const BatchArgs &a, uint32_t total, bool safe, hipStream_t s);
 
 hipError_t launch_fwd_quant_u8(const U8Args &a, int layout, int profile, bool safe, hipStream_t s);
 // lut_bounded / luts_bounded: every entry of every table >= 8.01 in magnitude (a quantised coefficient cannot leave int16)

@@ -415,8 +415,9 @@ struct NoHook
 };
 // after_rows: called between the row pass and the column pass, when the 16 registers of `rows` are dead (a caller that works on
 // several tiles issues the next tile's loads there)
-template <bool SAFE, bool PRIO = false, class AfterRows = NoHook>
-__device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uint2 (&rows)[8], const QuantTable &qt, uint32_t (&out)[64], AfterRows after_rows = AfterRows())
+// qp[v * 4 + j]: the multiplier pair, from the kernel arguments (QuantTable) or through a wave-uniform pointer (plane batches)
+template <bool SAFE, bool PRIO = false, class AfterRows = NoHook, class Pairs>
+__device__ __forceinline__ void encode_block_avx_pk_t(const PkConsts &K, const uint2 (&rows)[8], const Pairs qp_of, uint32_t (&out)[64], AfterRows after_rows = AfterRows())
 {
   MDCT_PHASE_PRIO(1);
   f32x2 col[4][8]; // col[j][r] = (B[r][kPairA[j]], B[r][kPairB[j]]) after the row pass
@@ -438,7 +439,7 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
 #pragma unroll
     for (int v = 0; v < 8; v++)
     {
-      const f32x2 qp = reinterpret_cast<const f32x2 *>(qt.q)[v * 4 + j];
+      const f32x2 qp = qp_of[v * 4 + j];
       f32x2 m;
       m = col[j][v] * qp;
       if constexpr (SAFE)
@@ -457,6 +458,12 @@ __device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uin
       }
     }
   }
+}
+
+template <bool SAFE, bool PRIO = false, class AfterRows = NoHook>
+__device__ __forceinline__ void encode_block_avx_pk(const PkConsts &K, const uint2 (&rows)[8], const QuantTable &qt, uint32_t (&out)[64], AfterRows after_rows = AfterRows())
+{
+  encode_block_avx_pk_t<SAFE, PRIO, AfterRows>(K, rows, reinterpret_cast<const f32x2 *>(qt.q), out, after_rows);
 }
 
 #ifndef MDCT_BLOCK_STAGE
@@ -1853,6 +1860,48 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT
   u8_rows<MODE, GENERAL, (GENERAL || MODE != U8_RT) ? FIN_CLAMP : FIN_SATPK, MDCT_U8B_PRIO>(a.consts, shift_magic, lo_hi, src, dst, pin, pout, threadIdx.x, t.tables);
 }
 
+// The reference's primary product (B1, simd_dct.cpp:2064-2262: k_q32_tile above) on a plane batch: any list of separately allocated 8-bit planes,
+// each with its own table and its own output buffer, in ONE launch -- a frame's Y, Cb and Cr where the reference's caller makes three calls
+// (main.cpp:543).  One wave = one 64-block tile of one block row of one plane (batch_tile); sizeX % 64 == 0 (the reference's own condition,
+// :117), so a partial last tile (3840-wide planes: 7.5 tiles per row) is a whole number of 8-block groups: its idle lanes redo the last block
+// and their bytes are never read back.  Block row r of a plane lands at r * pitch_out (8 * sizeX when tight), group g of the row at + 512 g
+// (:2227-2230).  Tables: OwnTables::qf holds the 64 multipliers 255 / (lut * 0.95) in pair order, negated for the fast quantiser.
+template <bool SAFE>
+__global__ __launch_bounds__(64, SAFE ? 1 : MDCT_Q32_MINW) void k_q32_batch(BatchArgs a)
+{
+  __shared__ __attribute__((aligned(16))) uint8_t wl[64 * kQ32RowStride];
+  const BatchTile t = batch_tile(blockIdx.x);
+  const uint32_t lane = threadIdx.x;
+  const uint32_t nb = min(64u, t.bpr() - t.tile * 64); // blocks of this tile, a multiple of 8
+  const size_t pin = t.pitch_in(), pout = t.pitch_out();
+  uint32_t q[64];
+  {
+    uint2 rows[8];
+    load_block_rows_g((const uint8_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.tile * 512, pin, min(lane, nb - 1) * 8, rows);
+    encode_block_avx_pk_t<SAFE>(reinterpret_cast<const PkConsts &>(a.pk), rows, (karg_pairs_t)t.tables, q);
+  }
+#pragma unroll
+  for (int c = 0; c < 64; c++)
+    wl[c * kQ32RowStride + lane] = (uint8_t)q[c];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // the tile's (up to) 4 KiB of output: store k, lane l -> coefficients c2 = 2 (l & 31), c2 + 1 of group 2k + (l >> 5) at group * 512 + c2 * 8
+  const gptr_t outw = sgpr_ptr((uint8_t *)t.to() + (size_t)t.row * pout + (size_t)t.tile * 4096);
+  const uint32_t rd = (lane & 31) * (2 * kQ32RowStride) + (lane >> 5) * 8;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if ((2 * k + (lane >> 5)) * 8 < nb)
+    {
+      const uint2 lo = *reinterpret_cast<const uint2 *>(wl + rd + k * 16);
+      const uint2 hi = *reinterpret_cast<const uint2 *>(wl + rd + k * 16 + kQ32RowStride);
+      u32x4_g v = {lo.x, lo.y, hi.x, hi.y};
+      if constexpr (!SAFE)
+        v = ~v; // the fast quantiser staged complemented bytes (encode_block_avx_pk)
+      store16_g(outw + k * 1024 + lane * 16, v);
+    }
+}
+
 // 8-bit pixels -> int16 coefficients, one plane (the JPEG-style pair's forward half; the inverse of one plane is a batch of one through
 // k_u8_batch<U8_INV>, mdct_api.hip: mdct_inv_i16_u8): u8 rows are 8 B per lane (512 B per wave load), int16 rows 16 B per lane.  The level
 // shift costs nothing: it is exactly "raw DC minus 64*128" (all other AAN outputs are differences of exact integer sums, so the offset
@@ -2592,6 +2641,17 @@ static hipError_t launch_u8_batch_m(const BatchArgs &a, uint32_t total, hipStrea
     hipLaunchKernelGGL((k_u8_batch<MODE, GENERAL, true>), g, b, 0, s, a);
   else
     hipLaunchKernelGGL((k_u8_batch<MODE, GENERAL, false>), g, b, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_q32_batch(const BatchArgs &a, uint32_t total, bool safe, hipStream_t s)
+{
+  if (total == 0)
+    return hipSuccess;
+  if (safe)
+    hipLaunchKernelGGL(k_q32_batch<true>, dim3(total), dim3(64), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_q32_batch<false>, dim3(total), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 

@@ -1036,6 +1036,26 @@ def test_soak_random_differential():
             M.u8_i16_batch("inv", idesc, level_shift=shift)
         for c, o, (uw, uh), l in zip(uco_np, u_back, ushapes, utabs):
             assert np.array_equal(o.cpu().numpy(), O.u8_i16("inv", c, uw, uh, lut=l, level_shift=shift)), (it, "u8 inv batch", uw, uh)
+        # the reference's q32 product on a plane list (widths % 64): ordinary tables, sometimes one that needs the exact-convert build
+        nq = int(rng.integers(1, 6))
+        qshapes = [(int(rng.integers(1, 14)) * 64, int(rng.integers(1, 6)) * 8) for _ in range(nq)]
+        qtabs = [lut_x(float(rng.choice([8, 100, 2000, 5e4]))) * rng.uniform(0.5, 2, 64).astype(np.float32) for _ in range(nq)]
+        if it % 7 == 0:
+            qtabs[0] = np.full(64, float(rng.choice([1e-4, 3e-6])), dtype=np.float32)
+        qsrc = [rng.integers(0, 256, (qh, qw), dtype=np.uint8) for (qw, qh) in qshapes]
+        qpad = [int(rng.integers(0, 3)) * 16 for _ in range(nq)]
+        q_in = [dev(a) for a in qsrc]
+        q_out = [torch.full((qh // 8, 8 * qw + pd), 0xA5, dtype=torch.uint8, device="cuda") for (qw, qh), pd in zip(qshapes, qpad)]
+        qdesc = [(a, o, qw, qh, l, qw, 8 * qw + pd) for a, o, (qw, qh), l, pd in zip(q_in, q_out, qshapes, qtabs, qpad)]
+        if it % 4 == 0:
+            qb = M.Batch("q32", qdesc)
+            qb.run()
+            qb.close()
+        else:
+            M.fwd_quant32_u8_batch(qdesc)
+        for a, o, (qw, qh), l in zip(qsrc, q_out, qshapes, qtabs):
+            g = o.cpu().numpy()
+            assert np.array_equal(g[:, : 8 * qw].reshape(-1), O.q32_native(a, l, qw, qh, 0, qh // 8)[1]) and (g[:, 8 * qw:] == 0xA5).all(), (it, "q32 batch", qw, qh)
         f = rng.normal(0, 300, (H2, W2)).astype(np.float32)
         fo = torch.empty((H2, W2), dtype=torch.float32, device="cuda")
         M.fwd_f32(dev(f), fo, W2, H2)

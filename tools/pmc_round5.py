@@ -32,6 +32,7 @@ WANT = {
     "k_f32_tile_fwd": ("k_f32_tile<0>", None, 8 * W * H),
     "k_i16_batch_420": ("k_i16_batch<2, 1, false, false>", None, 4 * FR),
     "k_u8_batch_420": ("k_u8_batch<0, false, false>", None, 2 * FR),
+    "k_q32_batch_420": ("k_q32_batch<false>", None, 2 * FR),
     "k_u8_batch_420_fwd": ("k_u8_batch<1, false, false>", None, 3 * FR),
     "k_u8_batch_420_inv": ("k_u8_batch<2, true, false>", 12420 * 64, 3 * FR),
     "k_i16_batch_fwd_256": ("k_i16_batch<0, 1, true, false>", 256 * 4096 * 64, 4 * 256 * 4096 * 4096),

@@ -13,6 +13,7 @@ by name and grid size.
     f32                                          configs[4]: k_f32_tile forward
     frame420 frame420_u8                         configs[2]: the 8K 4:2:0 frame as int16 planes (k_i16_batch) / as 8-bit planes (k_u8_batch), one launch
     frame420_u8_fwd frame420_u8_inv              the two halves of the 8-bit frame: pixels -> int16 coefficients / back, one launch each (k_u8_batch<1|2>)
+    frame420_q32                                 the same frame as the reference's q32 product, one launch (k_q32_batch)
     batch256                                     configs[3] on one GPU: 256 separately allocated 4096^2 planes, forward, ONE launch (17.2 GB)
     u8_i16_fwd u8_i16_inv                        one plane: k_u8_i16_fwd / a batch of one through k_u8_batch<U8_INV>
     scan_i16 scan_q32 u8_records split420 huffman px_huffman jpeg_scan   the stages either side (8192^2)"""
@@ -26,7 +27,7 @@ import torch
 import simd_dct_amd as M
 from simd_dct_amd import synth
 
-ALL = ["copy", "roundtrip", "roundtrip_lut", "fwd", "inv", "q32", "stereo_sse", "stereo_scalar", "encq_sse", "encq_scalar", "f32", "frame420", "frame420_u8", "frame420_u8_fwd", "frame420_u8_inv", "u8_i16_fwd", "u8_i16_inv",
+ALL = ["copy", "roundtrip", "roundtrip_lut", "fwd", "inv", "q32", "stereo_sse", "stereo_scalar", "encq_sse", "encq_scalar", "f32", "frame420", "frame420_u8", "frame420_u8_fwd", "frame420_u8_inv", "frame420_q32", "u8_i16_fwd", "u8_i16_inv",
        "scan_i16", "scan_q32", "u8_records", "split420", "huffman", "px_huffman", "jpeg_scan", "batch256"]
 which = sys.argv[1] if len(sys.argv) > 1 else "roundtrip"
 names = ALL if which == "all" else which.split(",")
@@ -106,6 +107,19 @@ def run(name):
         o = empty((H, W), torch.float32)
         for i in range(n):
             M.fwd_f32(a, o, W, H)
+    elif name == "frame420_q32":
+        drop("i16", "u8")
+        frames = []
+        for f in range(2):
+            pl = []
+            for (w, h, so, tab) in synth.CONFIG3_PLANES:
+                a = up(synth.plane_u8_np(w, h, "photo", seed=synth.SEED + so + 10 * f))
+                pl.append((a, empty((w * h,), torch.uint8), w, h, lut2000 if tab == "luma" else (M.QUANTIZE_BASE * np.float32(1200)).astype(np.float32)))
+            frames.append(pl)
+        b = [M.Batch("q32", f) for f in frames]
+        for i in range(n):
+            b[i % 2].run()
+        torch.cuda.synchronize()
     elif name in ("frame420_u8_fwd", "frame420_u8_inv"):
         drop("i16", "u8")
         frames = []

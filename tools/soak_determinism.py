@@ -83,7 +83,10 @@ for (W, H) in ((8192, 8192), (4104, 2056 - 2056 % 16), (2048, 7680)):
         soak("8-bit 4:2:0 frame -> int16 coefficients, one launch", uc, lambda: M.u8_i16_batch("fwd", hdesc))
         idesc = [(b, c, w, h, l) for b, c, (w, h), l in zip(uo, uc, shapes8, (K1, synth.JPEG_CHROMA, synth.JPEG_CHROMA))]
         soak("int16 coefficients -> 8-bit 4:2:0 frame, one launch", uo, lambda: M.u8_i16_batch("inv", idesc))
-        del ui, uo, udesc, ub, uc, hdesc, idesc
+        qo = [torch.empty(w * h, dtype=torch.uint8, device="cuda") for (w, h) in shapes8]
+        qdesc = [(a, o, w, h, lut2000) for a, o, (w, h) in zip(ui, qo, shapes8)]
+        soak("8-bit 4:2:0 frame -> q32 product, one launch", qo, lambda: M.fwd_quant32_u8_batch(qdesc))
+        del ui, uo, udesc, ub, uc, hdesc, idesc, qo, qdesc
     soak("i16 coef -> u8 px", [p8], lambda: M.inv_i16_u8(i16, p8, W, H, lut=K1))
     f32 = i16.float()
     of = torch.empty_like(f32)

@@ -59,6 +59,14 @@ run("8K 4:2:0 frame u8 -> int16 coefficients, one launch (3 B/px)", [b.prepared(
 inv = [M.Batch("inv_i16_u8", [(b, c, w, h, l) for (a, b, w, h, l), c in zip(f, cs)]) for f, cs in zip(frames, fc)]
 run("8K 4:2:0 frame int16 coefficients -> u8, one launch (3 B/px)", [b.prepared() for b in inv], fpx, bpp=3)
 del fc, fwd, inv
+ql = [(M.QUANTIZE_BASE * np.float32(s)).astype(np.float32) for s in (2000, 1200, 1200)]
+qo = [[torch.empty(w * h, dtype=torch.uint8, device="cuda") for (_, _, w, h, _) in f] for f in frames]
+qb = [M.Batch("q32", [(a, o, w, h, l) for (a, b, w, h, _), o, l in zip(f, os_, ql)]) for f, os_ in zip(frames, qo)]
+run("8K 4:2:0 frame -> the reference's q32 product, one launch (2 B/px)", [b.prepared() for b in qb], fpx)
+run("   ... kernel-argument form", [M.prepare_fwd_quant32_u8_batch([(a, o, w, h, l) for (a, b, w, h, _), o, l in zip(f, os_, ql)]) for f, os_ in zip(frames, qo)], fpx)
+q3 = [[M.prepare_fwd_quant_u8(a, o, l, w, h, 0, h // 8) for (a, b, w, h, _), o, l in zip(f, os_, ql)] for f, os_ in zip(frames, qo)]
+run("   ... as the three single-plane calls of the reference's caller", [(lambda cs: (lambda: [c() for c in cs]))(cs) for cs in q3], fpx)
+del qo, qb, q3
 run("8192^2 u8 stream copy of the same bytes", [M.prepare_stream_copy(a, b, 8192 * 8192) for a, b in big], 8192 * 8192)
 lut = (M.QUANTIZE_BASE * np.float32(2000)).astype(np.float32)
 outs = [torch.empty(8192 * 8192, dtype=torch.uint8, device="cuda") for _ in range(2)]
