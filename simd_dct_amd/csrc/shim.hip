@@ -71,6 +71,15 @@ struct HipDev
   bool event_wait(hipEvent_t &e) { return hipEventSynchronize(e) == hipSuccess; }
   bool h2d_async(uint8_t *dev, const uint8_t *host, size_t n, hipStream_t s) { return hipMemcpyAsync(dev, host, n, hipMemcpyHostToDevice, s) == hipSuccess; }
   bool d2h_async(uint8_t *host, const uint8_t *dev, size_t n, hipStream_t s) { return hipMemcpyAsync(host, dev, n, hipMemcpyDeviceToHost, s) == hipSuccess; }
+  // `height` pieces of `width` bytes, `dpitch` / `spitch` apart: one DMA submission for the stereo layout's 2 input and 64 output pieces
+  bool h2d_2d_async(uint8_t *dev, size_t dpitch, const uint8_t *host, size_t spitch, size_t width, size_t height, hipStream_t s)
+  {
+    return hipMemcpy2DAsync(dev, dpitch, host, spitch, width, height, hipMemcpyHostToDevice, s) == hipSuccess;
+  }
+  bool d2h_2d_async(uint8_t *host, size_t dpitch, const uint8_t *dev, size_t spitch, size_t width, size_t height, hipStream_t s)
+  {
+    return hipMemcpy2DAsync(host, dpitch, dev, spitch, width, height, hipMemcpyDeviceToHost, s) == hipSuccess;
+  }
   int launch(size_t r0, size_t r1, hipStream_t s) { return mdct_fwd_quant_u8(d_in, d_out, sizeX, lut, sizeX, sizeY, r0, r1, layout, profile, s); }
 };
 
@@ -247,24 +256,34 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
   const size_t total = sizeX * sizeY;
   const size_t strip = 8 * sizeX; // bytes per block row, input and output alike
 
-  // Both pointers on the host and a strip layout: chunked pipeline (shim_host.h: StripPipeline).  Block-row strips of up to 4 MiB
-  // travel through three internal streams -- copies in, kernels, copies out -- four chunks in flight, so that both directions of
-  // the link stay busy at once (PCIe is full duplex); the caller's pageable memory is touched only by plain memcpy to/from pinned
-  // bounce buffers.  A host-pointer call is synchronous by nature (the output must be in host memory on return) and its operands
-  // are not produced by any stream, so it does not involve the thread's configured stream.
-  if (!dev_in && !dev_out && (layout == MDCT_LAYOUT_Q32 || layout == MDCT_LAYOUT_BLOCK))
+  // Both pointers on the host: chunked pipeline (shim_host.h: StripPipeline).  Block rows in chunks of up to 4 MiB travel through three
+  // internal streams -- copies in, kernels, copies out -- four chunks in flight, so that both directions of the link stay busy at once
+  // (PCIe is full duplex); the caller's pageable memory is touched only by plain memcpy to/from pinned bounce buffers.  A host-pointer
+  // call is synchronous by nature (the output must be in host memory on return) and its operands are not produced by any stream, so it
+  // does not involve the thread's configured stream.  What a chunk of block rows [r0, r1) is made of:
+  //   Q32 / BLOCK   one strip of 8 * sizeX bytes per row, in and out
+  //   BLOCK_SSE     the same strips; of every 128 output bytes (a block pair) the tier writes the first 64 (simd_dct.cpp:1662-1676): only
+  //                 those go from the bounce buffer to the caller, the rest stays the caller's; the last pair's surviving spill (:1676) --
+  //                 64 bytes behind the last row -- follows the last chunk
+  //   STEREO        a row covers 8 pixel rows of BOTH stacked images (2 pieces, half a plane apart) and 2 * bpr bytes of each of the 64
+  //                 coefficient planes (64 pieces, sizeX * sizeY / 64 apart): one 2-D copy each way per chunk
+  if (!dev_in && !dev_out)
   {
-    const bool pinned_in = classify(pFrom) == PTR_PINNED, pinned_out = classify(pTo) == PTR_PINNED;
+    const bool half_pairs = layout == MDCT_LAYOUT_BLOCK_SSE, stereo = layout == MDCT_LAYOUT_STEREO;
+    const bool pinned_in = classify(pFrom) == PTR_PINNED, pinned_out = !half_pairs && classify(pTo) == PTR_PINNED;
+    const mdct_host::Pieces pin{stereo ? (size_t)2 : (size_t)1, sizeX * sizeY / 2, strip}, pout{stereo ? (size_t)64 : (size_t)1, sizeX * sizeY / 64, stereo ? sizeX / 4 : strip};
+    const size_t row_bytes = pin.count * pin.row; // == pout.count * pout.row: a block row moves as many bytes out as in
     // chunks of at most 4 MiB, and at least eight of them when the call is large enough (fill and drain cost one chunk per stage)
-    const size_t bytes = (b1 - b0) * strip;
+    const size_t bytes = (b1 - b0) * row_bytes;
     size_t chunk = bytes / 8;
     chunk = chunk > ((size_t)4 << 20) ? ((size_t)4 << 20) : (chunk < ((size_t)1 << 20) ? ((size_t)1 << 20) : chunk);
-    size_t rows_per_chunk = chunk / strip;
+    size_t rows_per_chunk = chunk / row_bytes;
     rows_per_chunk = rows_per_chunk < 1 ? 1 : rows_per_chunk;
+    const size_t tail = half_pairs && b1 > b0 && b1 * strip + 64 <= total ? 64 : 0;
     // (the mirrors need to reach the last processed row only: the reference's top-half loop, and the sizeY = 2H call form that turns
-    // it into a whole-plane call, touch half of the sizeX * sizeY bytes their shape describes)
-    const size_t reach = b1 * strip;
-    if (reserve(st.in, st.in_cap, reach) && reserve(st.out, st.out_cap, reach) && reserve_pipeline(st, rows_per_chunk * strip > ((size_t)4 << 20) ? rows_per_chunk * strip : ((size_t)4 << 20)))
+    // it into a whole-plane call, touch half of the sizeX * sizeY bytes their shape describes; the stereo layout's pieces span the planes)
+    const size_t reach = stereo ? total : b1 * strip + tail;
+    if (reserve(st.in, st.in_cap, reach) && reserve(st.out, st.out_cap, reach) && reserve_pipeline(st, rows_per_chunk * row_bytes > ((size_t)4 << 20) ? rows_per_chunk * row_bytes : ((size_t)4 << 20)))
     {
       st.hip.device = dev;
       st.hip.d_in = st.in;
@@ -275,7 +294,13 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
       st.hip.layout = layout;
       st.hip.profile = profile;
       mdct_host::StripPipeline<HipDev> pl{&st.hip, &st.pool_in, &st.pool_out, pFrom, pTo, st.in, st.out, st.pin_in, st.pin_out, st.stream[0], st.stream[1], st.stream[2],
-                                          st.e_in, st.e_k, st.e_out, st.in_latch, st.out_latch, strip, rows_per_chunk, pinned_in, pinned_out, true};
+                                          st.e_in, st.e_k, st.e_out, st.in_latch, st.out_latch, pin, pout, rows_per_chunk, pinned_in, pinned_out, true};
+      if (half_pairs)
+      {
+        pl.out_keep = 64;
+        pl.out_period = 128;
+        pl.out_tail = tail;
+      }
       const int r = pl.run(b0, b1); // shim_host.h
       if (r == mdct_host::PIPELINE_FAILED)
         return pipeline_failed(st);

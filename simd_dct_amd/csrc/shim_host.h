@@ -69,6 +69,43 @@ inline int level_from_flags(int set_level, const bool *sse2, const bool *ssse3, 
   return LEVEL_AVX2;
 }
 
+// `count` pieces of `len` bytes, `dpitch` / `spitch` apart; period != 0: of every `period` bytes of a piece only the first `keep` are copied
+// (the SSE encq tier writes the first 64 bytes of every 128-byte block pair, simd_dct.cpp:1662-1676: the rest stays the caller's)
+inline void copy_pieces(uint8_t *dst, size_t dpitch, const uint8_t *src, size_t spitch, size_t len, size_t count, size_t keep, size_t period)
+{
+  for (size_t p = 0; p < count; p++)
+  {
+    uint8_t *d = dst + p * dpitch;
+    const uint8_t *s = src + p * spitch;
+    if (period == 0)
+      memcpy(d, s, len);
+    else
+      for (size_t o = 0; o < len; o += period)
+        memcpy(d + o, s + o, len - o < keep ? len - o : keep);
+  }
+}
+
+// One direction's view of the planes: `count` pieces per block row range, piece p of block rows [r0, r1) at base + p * stride + r0 * row,
+// (r1 - r0) * row bytes -- host plane and device mirror alike.  Strip layouts (Q32, BLOCK, BLOCK_SSE): one piece, row = 8 * sizeX.  The
+// stereo layout reads 2 pieces (the stacked images, simd_dct.cpp:1089-1099) and writes 64 (the coefficient planes, :1061).
+struct Pieces
+{
+  size_t count, stride, row;
+};
+
+// worker k of n takes this part of a chunk's pieces: whole pieces when there are enough of them, else a byte range of every piece
+struct Share
+{
+  size_t p0, p1, o0, o1;
+};
+inline Share share_of(size_t count, size_t len, size_t k, size_t n, size_t align)
+{
+  if (count >= 2 * n)
+    return {count * k / n, count * (k + 1) / n, 0, len};
+  const size_t a = (len * k / n) / align * align, b = k + 1 == n ? len : (len * (k + 1) / n) / align * align;
+  return {0, count, a, b};
+}
+
 // The host pipeline's extra hands.  Copying between the caller's pageable memory and the pinned bounce buffers must keep up with
 // a link that moves ~48 GB/s each way at once (tools/pcie_bench, profiles/r05_pcie_bench.log) while one core sustains ~27-30 GB/s of
 // memcpy: helper threads per calling thread (started on first use, joined when the thread's staging is released) take shares of
@@ -89,6 +126,9 @@ struct CopyPool
     const uint8_t *src;
     size_t len;        // 0: nothing to copy (the data was DMA'd straight into pinned caller memory)
     std::atomic<int> *latch;
+    // several pieces of `len` bytes, `dst_pitch` / `src_pitch` apart (count <= 1: one piece), and of every `period` bytes only the first
+    // `keep` (period 0: all of them) -- copy_pieces below
+    size_t count = 1, dst_pitch = 0, src_pitch = 0, keep = 0, period = 0;
   };
   enum { kThreads = 3 };
   std::thread th[kThreads];
@@ -116,7 +156,7 @@ struct CopyPool
       }
       const bool ok = (!j.has_stream || dev->stream_wait(j.stream)) && (!j.event || dev->event_wait(*j.event));
       if (ok && j.len)
-        memcpy(j.dst, j.src, j.len);
+        copy_pieces(j.dst, j.dst_pitch, j.src, j.src_pitch, j.len, j.count < 1 ? 1 : j.count, j.keep, j.period);
       if (!ok)
         failed = true;
       {
@@ -197,6 +237,7 @@ struct StripPipeline
 {
   typedef typename Dev::stream_t stream_t;
   typedef typename Dev::event_t event_t;
+  typedef typename CopyPool<Dev>::Job Job;
   Dev *dev;
   CopyPool<Dev> *pool_in, *pool_out;
   const uint8_t *from; // caller's input plane (host)
@@ -206,14 +247,19 @@ struct StripPipeline
   stream_t s_in, s_k, s_out;
   event_t *e_in, *e_k, *e_out;             // [kPipeSlots] each
   std::atomic<int> *in_latch, *out_latch;  // [kPipeSlots] each
-  size_t strip;          // bytes per block row, input and output alike
+  Pieces in, out;        // where the block rows of either plane lie
   size_t rows_per_chunk;
   bool pinned_in, pinned_out; // caller memory is DMA-able in place: no bounce buffer, no memcpy
   bool use_helpers;
+  // of every out_period bytes of the output strips only the first out_keep are the call's, the rest stays the caller's (0: all); the caller
+  // passes pinned_out = false with it.  out_tail: bytes right behind the last processed row that the call writes too (the SSE encq tier's
+  // surviving spill, simd_dct.cpp:1676), handed over after the last chunk.  Single-piece layouts only.
+  size_t out_keep = 0, out_period = 0, out_tail = 0;
 
-  // Block rows [b0, b1) in chunks of rows_per_chunk rows; chunk c uses slot c % kPipeSlots of either direction:
+  // Block rows [b0, b1) in chunks of rows_per_chunk rows; chunk c uses slot c % kPipeSlots of either direction, its pieces packed back
+  // to back in the slot's bounce buffer:
   //   caller -> pin_in[slot]         the calling thread and two helpers, a third each (after the slot's previous DMA in has left it)
-  //   pin_in[slot] -> device         s_in;  e_in[slot] behind it
+  //   pin_in[slot] -> device         s_in (one 2-D copy when there are several pieces);  e_in[slot] behind it
   //   kernel                         s_k, after e_in[slot];  e_k[slot] behind it
   //   device -> pin_out[slot]        s_out, after e_k[slot] and after the helpers have emptied the slot;  e_out[slot] behind it
   //   pin_out[slot] -> caller        two helpers, half each, after e_out[slot]
@@ -240,30 +286,46 @@ struct StripPipeline
       (void)dev->stream_wait(s_out);
       return (int)PIPELINE_FAILED;
     };
+    // one worker's share of a chunk between the caller's plane (pieces `pc.stride` apart) and a bounce buffer (pieces packed, `len` apart)
+    auto job = [](const Share &sh, uint8_t *dst, size_t dpitch, const uint8_t *src, size_t spitch, event_t *ev, std::atomic<int> *latch, size_t keep, size_t period) {
+      Job j{false, stream_t(), ev, dst + sh.p0 * dpitch + sh.o0, src + sh.p0 * spitch + sh.o0, sh.o1 - sh.o0, latch};
+      j.count = sh.p1 - sh.p0;
+      j.dst_pitch = dpitch;
+      j.src_pitch = spitch;
+      j.keep = keep;
+      j.period = period;
+      return j;
+    };
+    auto run_job = [](const Job &j) {
+      if (j.len)
+        copy_pieces(j.dst, j.dst_pitch, j.src, j.src_pitch, j.len, j.count, j.keep, j.period);
+    };
     int r = 0;
     for (size_t c = 0; c < nchunks && r == 0; c++)
     {
       const int sl = (int)(c % kPipeSlots);
       const size_t r0 = b0 + c * rows_per_chunk, r1 = r0 + rows_per_chunk < b1 ? r0 + rows_per_chunk : b1;
-      const size_t off = r0 * strip, len = (r1 - r0) * strip;
-      const uint8_t *h_in = from + off; // pinned caller memory is DMA'd in place
+      const size_t ioff = r0 * in.row, ilen = (r1 - r0) * in.row; // per piece
+      const size_t ooff = r0 * out.row, olen = (r1 - r0) * out.row;
+      bool in_place = pinned_in; // pinned caller memory is DMA'd in place
       if (!pinned_in)
       {
         if (c >= (size_t)kPipeSlots && !dev->event_wait(e_in[sl])) // chunk c - kPipeSlots has left the bounce buffer
           return abandon();
-        const size_t third = helpers ? (len / 3) & ~(size_t)63 : 0, mine = len - 2 * third;
+        const size_t workers = helpers ? 3 : 1;
         if (helpers)
         {
           in_latch[sl] = 2;
-          pool_in->push({false, stream_t(), nullptr, pin_in[sl] + mine, from + off + mine, third, &in_latch[sl]});
-          pool_in->push({false, stream_t(), nullptr, pin_in[sl] + mine + third, from + off + mine + third, third, &in_latch[sl]});
+          for (size_t k = 1; k < 3; k++)
+            pool_in->push(job(share_of(in.count, ilen, k, 3, 64), pin_in[sl], ilen, from + ioff, in.stride, nullptr, &in_latch[sl], 0, 0));
         }
-        memcpy(pin_in[sl], from + off, mine);
+        run_job(job(share_of(in.count, ilen, 0, workers, 64), pin_in[sl], ilen, from + ioff, in.stride, nullptr, nullptr, 0, 0));
         if (helpers)
           pool_in->wait(in_latch[sl]);
-        h_in = pin_in[sl];
       }
-      if (!dev->h2d_async(d_in + off, h_in, len, s_in) || !dev->event_record(e_in[sl], s_in) || !dev->stream_wait_event(s_k, e_in[sl]))
+      const bool copied_in = in.count == 1 ? dev->h2d_async(d_in + ioff, in_place ? from + ioff : pin_in[sl], ilen, s_in)
+                                           : dev->h2d_2d_async(d_in + ioff, in.stride, in_place ? from + ioff : pin_in[sl], in_place ? in.stride : ilen, ilen, in.count, s_in);
+      if (!copied_in || !dev->event_record(e_in[sl], s_in) || !dev->stream_wait_event(s_k, e_in[sl]))
         return abandon();
       r = dev->launch(r0, r1, s_k);
       if (r != 0)
@@ -276,24 +338,28 @@ struct StripPipeline
         if (pool_out->failed.load())
           return abandon();
       }
-      if (!dev->stream_wait_event(s_out, e_k[sl]) || !dev->d2h_async(pinned_out ? to + off : pin_out[sl], d_out + off, len, s_out))
+      if (!dev->stream_wait_event(s_out, e_k[sl]))
+        return abandon();
+      const bool copied_out = out.count == 1 ? dev->d2h_async(pinned_out ? to + ooff : pin_out[sl], d_out + ooff, olen, s_out)
+                                             : dev->d2h_2d_async(pinned_out ? to + ooff : pin_out[sl], pinned_out ? out.stride : olen, d_out + ooff, out.stride, olen, out.count, s_out);
+      if (!copied_out)
         return abandon();
       if (!pinned_out)
       {
         if (!dev->event_record(e_out[sl], s_out))
           return abandon();
+        const size_t align = out_period ? out_period : 64;
         if (helpers)
         {
-          const size_t half = (len / 2) & ~(size_t)63;
           out_latch[sl] = 2;
-          pool_out->push({false, stream_t(), &e_out[sl], to + off, pin_out[sl], half, &out_latch[sl]});
-          pool_out->push({false, stream_t(), &e_out[sl], to + off + half, pin_out[sl] + half, len - half, &out_latch[sl]});
+          for (size_t k = 0; k < 2; k++)
+            pool_out->push(job(share_of(out.count, olen, k, 2, align), to + ooff, out.stride, pin_out[sl], olen, &e_out[sl], &out_latch[sl], out_keep, out_period));
         }
         else
         { // without helpers: one chunk at a time on the way out
           if (!dev->event_wait(e_out[sl]))
             return abandon();
-          memcpy(to + off, pin_out[sl], len);
+          run_job(job(share_of(out.count, olen, 0, 1, align), to + ooff, out.stride, pin_out[sl], olen, nullptr, nullptr, out_keep, out_period));
         }
       }
     }
@@ -308,6 +374,14 @@ struct StripPipeline
         pool_out->wait(out_latch[sl]);
       if (pool_out->failed.load() || pool_in->failed.load())
         return abandon();
+    }
+    if (out_tail && nchunks > 0)
+    { // behind the last kernel on s_out's own order (every slot is free again: through slot 0's bounce buffer)
+      const size_t toff = b1 * out.row;
+      if (!dev->stream_wait(s_k) || !dev->d2h_async(pinned_out ? to + toff : pin_out[0], d_out + toff, out_tail, s_out) || !dev->stream_wait(s_out))
+        return abandon();
+      if (!pinned_out)
+        memcpy(to + toff, pin_out[0], out_tail);
     }
     // s_out's last copy is behind every kernel, which is behind every copy in: when s_out is idle, so is the pipeline
     if (!dev->stream_wait(s_out) || !dev->stream_wait(s_k) || !dev->stream_wait(s_in))

@@ -107,12 +107,44 @@ struct FakeEvent
 
 static uint8_t kernel_byte(uint8_t in, size_t i) { return (uint8_t)(in * 31u + (uint8_t)(i * 7u) + (uint8_t)(i >> 11)); }
 
+// The planes of a call as the pipeline sees them (shim_host.h: Pieces), and the stand-in kernel: block row r gathers its in.count pieces of
+// in.row bytes, maps every byte with its position, and scatters the result over its out.count pieces of out.row bytes.  keep / period:
+// of every `period` output bytes the kernel writes the first `keep` and rubbish into the rest of the DEVICE plane (the SSE encq tier
+// writes half of every block pair, simd_dct.cpp:1662-1676); tail: it also writes `tail` bytes behind its last row (the spill, :1676).
+struct Geometry
+{
+  Pieces in, out;
+  size_t rows;               // block rows of the planes
+  size_t keep = 0, period = 0, tail = 0;
+  size_t row_bytes() const { return in.count * in.row; }
+  size_t in_bytes() const { return (in.count - 1) * in.stride + rows * in.row; }
+  size_t out_bytes() const { return (out.count - 1) * out.stride + rows * out.row + tail; }
+};
+static Geometry strips(size_t strip, size_t rows) { return {{1, 0, strip}, {1, 0, strip}, rows}; }
+static Geometry half_pairs(size_t strip, size_t rows) { return {{1, 0, strip}, {1, 0, strip}, rows, 64, 128, 64}; }
+// 2 stacked input images, 16 output planes (the stereo layout has 64; the pipeline only sees "several")
+static Geometry stereo_like(size_t strip, size_t rows) { return {{2, rows * strip + 192, strip}, {16, rows * strip / 8 + 64, strip / 8}, rows}; }
+
+static uint8_t spill_byte(size_t r1, size_t k) { return (uint8_t)(0x40 + r1 * 3 + k); }
+static void kernel_rows(const Geometry &g, const uint8_t *in, uint8_t *out, size_t r0, size_t r1)
+{
+  for (size_t r = r0; r < r1; r++)
+    for (size_t k = 0; k < g.row_bytes(); k++)
+    {
+      const uint8_t v = kernel_byte(in[(k / g.in.row) * g.in.stride + r * g.in.row + k % g.in.row], r * g.row_bytes() + k);
+      const size_t o = k % g.out.row;
+      out[(k / g.out.row) * g.out.stride + r * g.out.row + o] = (g.period && o % g.period >= g.keep) ? (uint8_t)0xEE : v;
+    }
+  for (size_t k = 0; k < g.tail && r1 > r0; k++)
+    out[r1 * g.out.row + k] = spill_byte(r1, k); // (overwritten by the next chunk's kernel, except behind the call's last row)
+}
+
 struct FakeDev
 {
   typedef FakeStream *stream_t;
   const uint8_t *d_in = nullptr;
   uint8_t *d_out = nullptr;
-  size_t strip = 0;
+  Geometry geo;
   // failure injection: the n-th call of each kind fails (counted from 0; -1 = never)
   std::atomic<int> h2d_calls{0}, d2h_calls{0}, launch_calls{0}, wait_calls{0};
   int fail_h2d = -1, fail_d2h = -1, fail_launch = -1, fail_wait = -1;
@@ -148,18 +180,20 @@ struct FakeDev
     e.wait_for(e.target());
     return wait_calls++ != fail_wait;
   }
-  bool h2d_async(uint8_t *dev, const uint8_t *host, size_t n, stream_t s)
+  bool h2d_async(uint8_t *dev, const uint8_t *host, size_t n, stream_t s) { return h2d_2d_async(dev, n, host, n, n, 1, s); }
+  bool d2h_async(uint8_t *host, const uint8_t *dev, size_t n, stream_t s) { return d2h_2d_async(host, n, dev, n, n, 1, s); }
+  bool h2d_2d_async(uint8_t *dev, size_t dpitch, const uint8_t *host, size_t spitch, size_t width, size_t height, stream_t s)
   {
     if (h2d_calls++ == fail_h2d)
       return false;
-    s->push([=] { memcpy(dev, host, n); });
+    s->push([=] { copy_pieces(dev, dpitch, host, spitch, width, height, 0, 0); });
     return true;
   }
-  bool d2h_async(uint8_t *host, const uint8_t *dev, size_t n, stream_t s)
+  bool d2h_2d_async(uint8_t *host, size_t dpitch, const uint8_t *dev, size_t spitch, size_t width, size_t height, stream_t s)
   {
     if (d2h_calls++ == fail_d2h)
       return false;
-    s->push([=] { memcpy(host, dev, n); });
+    s->push([=] { copy_pieces(host, dpitch, dev, spitch, width, height, 0, 0); });
     return true;
   }
   int launch(size_t r0, size_t r1, stream_t s)
@@ -168,11 +202,8 @@ struct FakeDev
       return 2; // "not supported", like a failed kernel launch
     const uint8_t *in = d_in;
     uint8_t *out = d_out;
-    const size_t st = strip;
-    s->push([=] {
-      for (size_t i = r0 * st; i < r1 * st; i++)
-        out[i] = kernel_byte(in[i], i);
-    });
+    const Geometry g = geo;
+    s->push([=] { kernel_rows(g, in, out, r0, r1); });
     return 0;
   }
 };
@@ -180,7 +211,8 @@ struct FakeDev
 // one calling thread's staging, as thread_local Staging of shim.hip: everything exact-size on the heap
 struct Rig
 {
-  size_t strip, rows, rpc;
+  Geometry geo;
+  size_t rpc;
   std::unique_ptr<uint8_t[]> d_in, d_out, pin_in[kPipeSlots], pin_out[kPipeSlots];
   uint8_t *pin_in_p[kPipeSlots], *pin_out_p[kPipeSlots];
   FakeStream streams[3];
@@ -188,25 +220,29 @@ struct Rig
   FakeDev dev;
   CopyPool<FakeDev> pool_in, pool_out;
   std::atomic<int> in_latch[kPipeSlots] = {}, out_latch[kPipeSlots] = {};
-  Rig(size_t strip_, size_t rows_, size_t rpc_) : strip(strip_), rows(rows_), rpc(rpc_)
+  Rig(const Geometry &g, size_t rpc_) : geo(g), rpc(rpc_)
   {
-    d_in.reset(new uint8_t[strip * rows]);
-    d_out.reset(new uint8_t[strip * rows]);
+    d_in.reset(new uint8_t[g.in_bytes()]);
+    d_out.reset(new uint8_t[g.out_bytes()]);
     for (int i = 0; i < kPipeSlots; i++)
     {
-      pin_in[i].reset(new uint8_t[strip * rpc]);
-      pin_out[i].reset(new uint8_t[strip * rpc]);
+      pin_in[i].reset(new uint8_t[g.row_bytes() * rpc]);
+      pin_out[i].reset(new uint8_t[g.row_bytes() * rpc]);
       pin_in_p[i] = pin_in[i].get();
       pin_out_p[i] = pin_out[i].get();
     }
     dev.d_in = d_in.get();
     dev.d_out = d_out.get();
-    dev.strip = strip;
+    dev.geo = g;
   }
+  Rig(size_t strip, size_t rows, size_t rpc_) : Rig(strips(strip, rows), rpc_) {}
   int run(const uint8_t *from, uint8_t *to, size_t b0, size_t b1, bool helpers, bool pinned_in, bool pinned_out)
   {
     StripPipeline<FakeDev> pl{&dev, &pool_in, &pool_out, from, to, d_in.get(), d_out.get(), pin_in_p, pin_out_p, &streams[0], &streams[1], &streams[2],
-                              e_in, e_k, e_out, in_latch, out_latch, strip, rpc, pinned_in, pinned_out, helpers};
+                              e_in, e_k, e_out, in_latch, out_latch, geo.in, geo.out, rpc, pinned_in, pinned_out, helpers};
+    pl.out_keep = geo.keep;
+    pl.out_period = geo.period;
+    pl.out_tail = b1 > b0 && b1 < geo.rows + (geo.tail ? 1 : 0) ? geo.tail : 0; // (the planes of these tests hold the last row's spill too)
     return pl.run(b0, b1);
   }
   bool quiescent()
@@ -231,18 +267,28 @@ static std::vector<uint8_t> make_plane(size_t n, unsigned seed)
   return v;
 }
 
-static void check_rows(const std::vector<uint8_t> &in, const uint8_t *out, size_t strip, size_t rows, size_t b0, size_t b1, uint8_t canary)
+// what a call on block rows [b0, b1) must leave in the caller's output plane, byte for byte: the kernel's bytes where it writes, the
+// caller's canary everywhere else (other rows, the gaps between pieces, the unwritten half of every pair)
+static void check_geo(const Geometry &g, const std::vector<uint8_t> &in, const uint8_t *out, size_t b0, size_t b1, uint8_t canary)
 {
-  for (size_t i = 0; i < strip * rows; i++)
-  {
-    const size_t r = i / strip;
-    const uint8_t want = (r >= b0 && r < b1) ? kernel_byte(in[i], i) : canary;
-    if (out[i] != want)
+  std::vector<uint8_t> dev_out(g.out_bytes(), 0), want(g.out_bytes(), canary);
+  kernel_rows(g, in.data(), dev_out.data(), b0, b1);
+  for (size_t p = 0; p < g.out.count; p++)
+    for (size_t o = b0 * g.out.row; o < b1 * g.out.row; o++)
+      if (!g.period || (o % g.out.row) % g.period < g.keep)
+        want[p * g.out.stride + o] = dev_out[p * g.out.stride + o];
+  for (size_t k = 0; k < g.tail && b1 > b0; k++)
+    want[b1 * g.out.row + k] = spill_byte(b1, k);
+  for (size_t i = 0; i < g.out_bytes(); i++)
+    if (out[i] != want[i])
     {
-      fprintf(stderr, "byte %zu (row %zu): got %u want %u\n", i, r, out[i], want);
+      fprintf(stderr, "byte %zu: got %u want %u (rows [%zu, %zu))\n", i, out[i], want[i], b0, b1);
       exit(1);
     }
-  }
+}
+static void check_rows(const std::vector<uint8_t> &in, const uint8_t *out, size_t strip, size_t rows, size_t b0, size_t b1, uint8_t canary)
+{
+  check_geo(strips(strip, rows), in, out, b0, b1, canary);
 }
 
 static void test_single_caller()
@@ -265,6 +311,34 @@ static void test_single_caller()
           }
         }
   puts("single caller: ok");
+}
+
+// the layouts whose chunks are not one strip: several pieces per direction (stereo: 2-D copies, helpers sharing by piece or by byte range),
+// and the half-written pairs with their trailing spill (only the kernel's bytes reach the caller, never the rubbish between them)
+static void test_pieces_and_half_pairs()
+{
+  for (int kind = 0; kind < 2; kind++)
+    for (size_t rows : {1, 2, 5, 13, 22})
+      for (size_t rpc : {1, 2, 3})
+        for (int helpers = 0; helpers < 2; helpers++)
+          for (int pins = 0; pins < (kind == 0 ? 4 : 2); pins++) // (half pairs: the output always goes through the bounce buffers)
+          {
+            const Geometry g = kind == 0 ? stereo_like(1024, rows) : half_pairs(1024, rows);
+            const std::vector<uint8_t> in = make_plane(g.in_bytes(), (unsigned)(rows * 8 + rpc + kind));
+            std::unique_ptr<uint8_t[]> out(new uint8_t[g.out_bytes()]);
+            for (size_t b0 = 0; b0 < rows; b0 += (rows > 4 ? 4 : 1))
+              for (size_t b1 : {rows, (b0 + rows + 1) / 2})
+              {
+                if (b1 <= b0)
+                  continue;
+                memset(out.get(), 0x7E, g.out_bytes());
+                Rig rig(g, rpc);
+                CHECK(rig.run(in.data(), out.get(), b0, b1, helpers, pins & 1, pins & 2) == PIPELINE_OK);
+                CHECK(rig.quiescent());
+                check_geo(g, in, out.get(), b0, b1, 0x7E);
+              }
+          }
+  puts("several pieces per chunk, half-written pairs with their spill: ok");
 }
 
 // the reference's intended multi-core use: concurrent calls on disjoint row ranges of the SAME planes
@@ -297,16 +371,18 @@ static void test_four_callers()
 static void test_failures()
 {
   const size_t strip = 2048, rows = 13, rpc = 2; // 7 chunks: the slots are reused
-  const std::vector<uint8_t> in = make_plane(strip * rows, 5);
+  for (int geo = 0; geo < 3; geo++)
   for (int helpers = 0; helpers < 2; helpers++)
     for (int kind = 0; kind < 4; kind++)
-      for (int at = 0; at < 7; at++)
+      for (int at = 0; at < 8; at++)
       {
-        std::unique_ptr<uint8_t[]> out(new uint8_t[strip * rows]);
-        memset(out.get(), 0x11, strip * rows);
+        const Geometry g = geo == 0 ? strips(strip, rows) : (geo == 1 ? stereo_like(strip, rows) : half_pairs(strip, rows));
+        const std::vector<uint8_t> in = make_plane(g.in_bytes(), 5);
+        std::unique_ptr<uint8_t[]> out(new uint8_t[g.out_bytes()]);
+        memset(out.get(), 0x11, g.out_bytes());
         int r;
         {
-          Rig rig(strip, rows, rpc);
+          Rig rig(g, rpc);
           if (kind == 0) rig.dev.fail_h2d = at;
           if (kind == 1) rig.dev.fail_d2h = at;
           if (kind == 2) rig.dev.fail_launch = at;
@@ -319,7 +395,7 @@ static void test_failures()
             CHECK(st.q.empty() && !st.busy);
           }
           if (kind == 2)
-            CHECK(r == 2);
+            CHECK(r == (at < 7 ? 2 : PIPELINE_OK)); // 7 chunks = 7 launches; (at == 7 is there for the half pairs' eighth copy out: the spill)
           else
             CHECK(r == PIPELINE_FAILED || r == PIPELINE_OK); // a failing wait during abandon()'s own drain does not change a success
         } // rig and its buffers are gone
@@ -407,6 +483,7 @@ int main()
   test_ref_range();
   test_levels();
   test_single_caller();
+  test_pieces_and_half_pairs();
   test_four_callers();
   test_failures();
   test_exit_with_jobs_queued();

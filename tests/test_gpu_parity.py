@@ -661,6 +661,59 @@ def test_host_pointer_pipeline_multi_chunk():
         M.set_max_simd(M.SIMD_AVX2)
 
 
+@pytest.mark.parametrize("beh", ["stereo_sse", "encq_sse", "stereo_scalar"])
+def test_host_pointer_pipeline_multi_chunk_scattered_layouts(beh):
+    """the chunked pipeline on the layouts whose chunks are not one strip -- stereo: 2 input pieces (the stacked images) and 64 output pieces
+    (the coefficient planes) per chunk, one 2-D copy each way; SSE encq: of every 128 output bytes only the tier's 64 go from the bounce
+    buffer to the caller, the last pair's surviving spill (simd_dct.cpp:1676) follows the last chunk -- on a plane of many chunks: the full
+    range, partial ranges, two host threads on disjoint ranges, pageable and pinned caller memory; everything the tier does not write keeps
+    the caller's canary"""
+    import threading
+    from simd_dct_amd import _lib
+
+    lib = _lib.load()
+    fn, level, _, _ = BEHAVIOURS[beh]
+    W, H = 4096, 4096
+    img = np.ascontiguousarray(synth.plane_u8_np(W, H, "photo").reshape(-1))
+    lut = lut_x(8)
+    M.set_max_simd(level)
+    try:
+        for pinned in (False, True):
+            for (y0, y1) in ((0, H), (496, 2000), (1024, 1039)):
+                out = np.full(W * H, CANARY, dtype=np.uint8)
+                if pinned:
+                    assert lib.mdct_shim_pin(img.ctypes.data, img.nbytes) == 0 and lib.mdct_shim_pin(out.ctypes.data, out.nbytes) == 0
+                try:
+                    assert fn(img, out, lut, W, H, y0, y1) == 0
+                finally:
+                    if pinned:
+                        assert lib.mdct_shim_unpin(img.ctypes.data) == 0 and lib.mdct_shim_unpin(out.ctypes.data) == 0
+                want = np.full(W * H, CANARY, dtype=np.uint8)
+                O.run_behaviour(beh, img, lut, W, H, y0, y1, out=want)
+                assert np.array_equal(out, want), (beh, pinned, y0, y1, int((out != want).sum()))
+        # two threads, disjoint ranges of the same planes, an unprocessed block row between them (it receives the SSE encq tier's spill)
+        out = np.full(W * H, CANARY, dtype=np.uint8)
+        errs = []
+
+        def work(y0, y1):
+            for _ in range(2):
+                if fn(img, out, lut, W, H, y0, y1) != 0:
+                    errs.append((y0, y1))
+
+        ts = [threading.Thread(target=work, args=(0, 1903)), threading.Thread(target=work, args=(1920, H))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs
+        want = np.full(W * H, CANARY, dtype=np.uint8)
+        O.run_behaviour(beh, img, lut, W, H, 0, 1903, out=want)
+        O.run_behaviour(beh, img, lut, W, H, 1920, H, out=want)
+        assert np.array_equal(out, want), int((out != want).sum())
+    finally:
+        M.set_max_simd(M.SIMD_AVX2)
+
+
 def test_host_pipeline_helpers_under_four_concurrent_callers():
     """four host threads, each on its own quarter of a 8192 x 8192 plane through the reference API with pageable memory:
     every call runs the multi-chunk pipeline with its own three copy helpers (CopyPool, csrc/shim.hip); repeated, then a
