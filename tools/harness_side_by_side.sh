@@ -14,6 +14,6 @@ synth.plane_u8_np(8192, 8192, "photo").tofile(sys.argv[1])
 PY
 for bin in simd_dct_original simd_dct_relinked simd_dct_relinked_warm; do
   echo "== $bin"
-  ./oracle/_ref/$bin "$RAW" 8192 8192 --quality 2000 --runs 16 --mode enc-quant32 --mode enc-quant-stereo --mode enc-quant 2>&1 | grep -v "^Features\|^$" | tail -8
+  ./oracle/_ref/$bin "$RAW" 8192 8192 --quality 2000 --runs 16 --mode enc-quant32 --mode enc-quant-stereo --mode enc-quant 2>&1 | tr "\r" "\n" | grep -v "^Features\|^$"
 done
 rm -f "$RAW"
