@@ -349,6 +349,11 @@ void mdct_zigzag_table(uint8_t *zz64);
  * sizeX, sizeY multiples of 16; pitches of the int16 planes in elements. */
 int mdct_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr,
                      size_t pitch_y, size_t pitch_c, void *stream);
+/* The same split into 8-BIT planes, not level-shifted (feeds the 8-bit plane batches -- mdct_roundtrip_u8_batch, mdct_fwd_u8_i16_batch,
+ * mdct_fwd_quant32_u8_batch: BASELINE.json configs[2] as SURVEY.md 8(d) states it -- which shift by themselves): y = Y, cb / cr =
+ * (a+b+c+d+2) >> 2; pitches in bytes, no alignment requirement.  3 bytes in + 1.5 bytes out per pixel. */
+int mdct_split420_u8_planes(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, uint8_t *y, uint8_t *cb, uint8_t *cr,
+                            size_t pitch_y, size_t pitch_c, void *stream);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------------
  * The reference has no communication; its only parallelism hook is the caller-side row range

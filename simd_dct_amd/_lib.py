@@ -96,6 +96,7 @@ SIGNATURES = {
     "mdct_huffman_spec": (c_int, [c_int, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "mdct_zigzag_table": (None, [c_void_p]),
     "mdct_split420_u8": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "mdct_split420_u8_planes": (c_int, [c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mdct_shard_rows": (None, [c_size_t, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "mdct_stereo_shard_piece": (c_int, [c_size_t, c_size_t, c_int, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "mdct_comm_get_unique_id": (c_int, [c_void_p]),

@@ -471,6 +471,15 @@ def split420_u8(ycc, sizeX, sizeY, y, cb, cr, pitch=None, pitch_y=None, pitch_c=
     return rc
 
 
+def split420_u8_planes(ycc, sizeX, sizeY, y, cb, cr, pitch=None, pitch_y=None, pitch_c=None, stream=None, check=True):
+    """interleaved 8-bit Y Cb Cr -> 8-bit Y (full) and Cb / Cr (2x2 box average) planes, not level-shifted: the input of the 8-bit plane batches"""
+    rc = _lib.load().mdct_split420_u8_planes(_ptr(ycc), 3 * sizeX if pitch is None else pitch, sizeX, sizeY, _ptr(y), _ptr(cb), _ptr(cr),
+                                             sizeX if pitch_y is None else pitch_y, sizeX // 2 if pitch_c is None else pitch_c, _stream(stream))
+    if check:
+        _check(rc)
+    return rc
+
+
 # ------------------------------------------------------------------------- multi-GPU (RCCL via the C-ABI)
 UNIQUE_ID_BYTES = 128
 

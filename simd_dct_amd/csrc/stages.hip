@@ -132,7 +132,7 @@ __global__ __launch_bounds__(scan_wg(SRC)) void k_scan(ScanArgs a)
 struct SplitArgs
 {
   const uint8_t *ycc;
-  int16_t *y, *cb, *cr;
+  void *y, *cb, *cr;              // int16 planes (level-shifted) or 8-bit planes (k_split420<true>)
   size_t pitch, pitch_y, pitch_c; // bytes / elements / elements
   uint32_t strips, nthreads;      // 8-pixel strips per row pair, threads in the launch
 };
@@ -146,7 +146,10 @@ __device__ __forceinline__ int byte_of(const uint32_t (&w)[6])
   return (int)((w[N / 4] >> (8 * (N % 4))) & 0xFF);
 }
 
-// one thread: 8 pixels x 2 rows (48 bytes in; 2 x 16 B of Y, 8 B of Cb, 8 B of Cr out)
+// one thread: 8 pixels x 2 rows (48 bytes in; 2 x 16 B of Y, 8 B of Cb, 8 B of Cr out).  U8_OUT: the planes stay 8-bit and unshifted
+// (2 x 8 B of Y, 4 B of Cb, 4 B of Cr) -- what the 8-bit plane batches take (mdct_roundtrip_u8_batch, mdct_fwd_u8_i16_batch,
+// mdct_fwd_quant32_u8_batch), which do the level shift themselves.
+template <bool U8_OUT>
 __global__ __launch_bounds__(kWG) void k_split420(SplitArgs a)
 {
   const uint32_t t = blockIdx.x * kWG + threadIdx.x;
@@ -163,22 +166,38 @@ __global__ __launch_bounds__(kWG) void k_split420(SplitArgs a)
     w0[2 * i] = v0.x; w0[2 * i + 1] = v0.y;
     w1[2 * i] = v1.x; w1[2 * i + 1] = v1.y;
   }
-  auto pack = [](int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); };
-#define Y0(i) (byte_of<3 * (i)>(w0) - 128)
-#define Y1(i) (byte_of<3 * (i)>(w1) - 128)
-#define C4(k, i) (((byte_of<3 * (2 * (i)) + (k)>(w0) + byte_of<3 * (2 * (i) + 1) + (k)>(w0) + byte_of<3 * (2 * (i)) + (k)>(w1) + byte_of<3 * (2 * (i) + 1) + (k)>(w1) + 2) >> 2) - 128)
-  const u32x4 y0 = {pack(Y0(0), Y0(1)), pack(Y0(2), Y0(3)), pack(Y0(4), Y0(5)), pack(Y0(6), Y0(7))};
-  const u32x4 y1 = {pack(Y1(0), Y1(1)), pack(Y1(2), Y1(3)), pack(Y1(4), Y1(5)), pack(Y1(6), Y1(7))};
-  const u32x2 cb = {pack(C4(1, 0), C4(1, 1)), pack(C4(1, 2), C4(1, 3))};
-  const u32x2 cr = {pack(C4(2, 0), C4(2, 1)), pack(C4(2, 2), C4(2, 3))};
+  constexpr int kShift = U8_OUT ? 0 : 128;
+#define Y0(i) (byte_of<3 * (i)>(w0) - kShift)
+#define Y1(i) (byte_of<3 * (i)>(w1) - kShift)
+#define C4(k, i) (((byte_of<3 * (2 * (i)) + (k)>(w0) + byte_of<3 * (2 * (i) + 1) + (k)>(w0) + byte_of<3 * (2 * (i)) + (k)>(w1) + byte_of<3 * (2 * (i) + 1) + (k)>(w1) + 2) >> 2) - kShift)
+  if constexpr (U8_OUT)
+  {
+    auto pack4 = [](int b0, int b1, int b2, int b3) { return (uint32_t)b0 | ((uint32_t)b1 << 8) | ((uint32_t)b2 << 16) | ((uint32_t)b3 << 24); };
+    const u32x2_unaligned y0 = {pack4(Y0(0), Y0(1), Y0(2), Y0(3)), pack4(Y0(4), Y0(5), Y0(6), Y0(7))};
+    const u32x2_unaligned y1 = {pack4(Y1(0), Y1(1), Y1(2), Y1(3)), pack4(Y1(4), Y1(5), Y1(6), Y1(7))};
+    typedef unsigned int u32_unaligned __attribute__((aligned(1)));
+    uint8_t *py = static_cast<uint8_t *>(a.y) + (size_t)(2 * rp) * a.pitch_y + (size_t)s * 8;
+    __builtin_nontemporal_store(y0, reinterpret_cast<u32x2_unaligned *>(py));
+    __builtin_nontemporal_store(y1, reinterpret_cast<u32x2_unaligned *>(py + a.pitch_y));
+    __builtin_nontemporal_store(pack4(C4(1, 0), C4(1, 1), C4(1, 2), C4(1, 3)), reinterpret_cast<u32_unaligned *>(static_cast<uint8_t *>(a.cb) + (size_t)rp * a.pitch_c + (size_t)s * 4));
+    __builtin_nontemporal_store(pack4(C4(2, 0), C4(2, 1), C4(2, 2), C4(2, 3)), reinterpret_cast<u32_unaligned *>(static_cast<uint8_t *>(a.cr) + (size_t)rp * a.pitch_c + (size_t)s * 4));
+  }
+  else
+  {
+    auto pack = [](int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); };
+    const u32x4 y0 = {pack(Y0(0), Y0(1)), pack(Y0(2), Y0(3)), pack(Y0(4), Y0(5)), pack(Y0(6), Y0(7))};
+    const u32x4 y1 = {pack(Y1(0), Y1(1)), pack(Y1(2), Y1(3)), pack(Y1(4), Y1(5)), pack(Y1(6), Y1(7))};
+    const u32x2 cb = {pack(C4(1, 0), C4(1, 1)), pack(C4(1, 2), C4(1, 3))};
+    const u32x2 cr = {pack(C4(2, 0), C4(2, 1)), pack(C4(2, 2), C4(2, 3))};
+    int16_t *py = static_cast<int16_t *>(a.y) + (size_t)(2 * rp) * a.pitch_y + (size_t)s * 8;
+    __builtin_nontemporal_store(y0, reinterpret_cast<u32x4 *>(py));
+    __builtin_nontemporal_store(y1, reinterpret_cast<u32x4 *>(py + a.pitch_y));
+    __builtin_nontemporal_store(cb, reinterpret_cast<u32x2 *>(static_cast<int16_t *>(a.cb) + (size_t)rp * a.pitch_c + (size_t)s * 4));
+    __builtin_nontemporal_store(cr, reinterpret_cast<u32x2 *>(static_cast<int16_t *>(a.cr) + (size_t)rp * a.pitch_c + (size_t)s * 4));
+  }
 #undef Y0
 #undef Y1
 #undef C4
-  int16_t *py = a.y + (size_t)(2 * rp) * a.pitch_y + (size_t)s * 8;
-  __builtin_nontemporal_store(y0, reinterpret_cast<u32x4 *>(py));
-  __builtin_nontemporal_store(y1, reinterpret_cast<u32x4 *>(py + a.pitch_y));
-  __builtin_nontemporal_store(cb, reinterpret_cast<u32x2 *>(a.cb + (size_t)rp * a.pitch_c + (size_t)s * 4));
-  __builtin_nontemporal_store(cr, reinterpret_cast<u32x2 *>(a.cr + (size_t)rp * a.pitch_c + (size_t)s * 4));
 }
 
 
@@ -652,7 +671,7 @@ static int pack_rows(const uint8_t *segments, const uint32_t *seg_bytes, const u
   return e == hipSuccess ? MDCT_SUCCESS : mdct_set_error(MDCT_NOT_SUPPORTED, "pack kernel launch: %s", hipGetErrorString(e));
 }
 
-int mdct_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr, size_t pitch_y, size_t pitch_c, void *stream)
+static int run_split420(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, void *y, void *cb, void *cr, size_t pitch_y, size_t pitch_c, bool u8_out, void *stream)
 {
   if (ycc == nullptr || y == nullptr || cb == nullptr || cr == nullptr)
     return mdct_set_error(MDCT_INVALID_PARAMETER, "null pointer");
@@ -660,7 +679,7 @@ int mdct_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t size
     return mdct_set_error(MDCT_NOT_SUPPORTED, "image %zux%zu is not a multiple of 16x16", sizeX, sizeY);
   if (pitch < 3 * sizeX || pitch_y < sizeX || pitch_c < sizeX / 2)
     return mdct_set_error(MDCT_INVALID_PARAMETER, "pitch smaller than a row");
-  if (((uintptr_t)y | (pitch_y * 2)) & 15 || ((uintptr_t)cb | (uintptr_t)cr | (pitch_c * 2)) & 7)
+  if (!u8_out && ((((uintptr_t)y | (pitch_y * 2)) & 15) || (((uintptr_t)cb | (uintptr_t)cr | (pitch_c * 2)) & 7)))
     return mdct_set_error(MDCT_INVALID_PARAMETER, "Y rows must be 16-byte and chroma rows 8-byte aligned");
   const size_t strips = sizeX / 8, n = strips * (sizeY / 2);
   if (n > 0x7FFFFFFFull)
@@ -677,9 +696,23 @@ int mdct_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t size
   a.pitch_c = pitch_c;
   a.strips = (uint32_t)strips;
   a.nthreads = (uint32_t)n;
-  hipLaunchKernelGGL(mdct::k_split420, dim3((uint32_t)((n + mdct::kWG - 1) / mdct::kWG)), dim3(mdct::kWG), 0, (hipStream_t)stream, a);
+  const dim3 grid((uint32_t)((n + mdct::kWG - 1) / mdct::kWG));
+  if (u8_out)
+    hipLaunchKernelGGL(mdct::k_split420<true>, grid, dim3(mdct::kWG), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(mdct::k_split420<false>, grid, dim3(mdct::kWG), 0, (hipStream_t)stream, a);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? MDCT_SUCCESS : mdct_set_error(MDCT_NOT_SUPPORTED, "split kernel launch: %s", hipGetErrorString(e));
+}
+
+int mdct_split420_u8(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, int16_t *y, int16_t *cb, int16_t *cr, size_t pitch_y, size_t pitch_c, void *stream)
+{
+  return run_split420(ycc, pitch, sizeX, sizeY, y, cb, cr, pitch_y, pitch_c, false, stream);
+}
+
+int mdct_split420_u8_planes(const uint8_t *ycc, size_t pitch, size_t sizeX, size_t sizeY, uint8_t *y, uint8_t *cb, uint8_t *cr, size_t pitch_y, size_t pitch_c, void *stream)
+{
+  return run_split420(ycc, pitch, sizeX, sizeY, y, cb, cr, pitch_y, pitch_c, true, stream);
 }
 
 } // extern "C"

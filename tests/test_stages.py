@@ -125,6 +125,10 @@ def test_stage_argument_checks_without_device():
     c = np.zeros((8, 8), dtype=np.int16)
     assert api.split420_u8(ycc, 24, 16, y, c, c, check=False) == 2
     assert api.split420_u8(ycc, 16, 16, y, c, c, pitch=40, check=False) == 1
+    y8, c8 = np.zeros((16, 16), dtype=np.uint8), np.zeros((8, 8), dtype=np.uint8)
+    assert api.split420_u8_planes(ycc, 24, 16, y8, c8, c8, check=False) == 2
+    assert api.split420_u8_planes(ycc, 16, 16, y8, c8, c8, pitch_c=4, check=False) == 1
+    assert api.split420_u8_planes(ycc, 16, 16, y8, None, c8, check=False) == 1
 
 
 # ------------------------------------------------------------------------------------------ GPU
@@ -353,3 +357,38 @@ def test_split420_matches_the_checker_and_feeds_config3():
     single = torch.empty_like(y)
     api.roundtrip_i16(y, single, W, H, lut=lut)
     assert torch.equal(single, outs[0])
+
+
+@pytest.mark.gpu
+def test_split420_into_8bit_planes_feeds_the_8bit_config3_path():
+    """mdct_split420_u8_planes: the 4:2:0 split into unshifted 8-bit planes == the checker's int16 split + 128, any pitches / alignment with
+    canaries; BASELINE.json configs[2] as SURVEY.md 8(d) states it end to end: interleaved 7680x4320 frame -> split -> the three 8-bit planes
+    through mdct_roundtrip_u8_batch in one launch == the int16 route's reconstruction (split420_u8 -> roundtrip_i16_planes) + 128, clamped"""
+    api.init(0)
+    for (W, H, py, pc) in ((16, 16, 16, 8), (64, 32, 67, 35), (1008, 48, 1011, 505), (1920, 1088, 1920, 960)):
+        ycc = _ycc(W, H, seed=W + 1)
+        y = torch.full((H, py), 77, dtype=torch.uint8, device="cuda")
+        cb = torch.full((H // 2, pc), 77, dtype=torch.uint8, device="cuda")
+        cr = torch.full((H // 2, pc), 77, dtype=torch.uint8, device="cuda")
+        api.split420_u8_planes(_dev(ycc), W, H, y, cb, cr, pitch_y=py, pitch_c=pc)
+        wy, wcb, wcr = O.split420(ycc, W, H)
+        for got, want, w in ((y, wy, W), (cb, wcb, W // 2), (cr, wcr, W // 2)):
+            g = got.cpu().numpy()
+            assert np.array_equal(g[:, :w].astype(np.int16) - 128, want) and (g[:, w:] == 77).all(), (W, H)
+    W, H = 7680, 4320
+    ycc = torch.stack([synth.plane_u8_torch(W, H, "photo", seed=s) for s in (1, 2, 3)], dim=-1).contiguous()
+    p8 = [torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H // 2, W // 2), dtype=torch.uint8, device="cuda"), torch.empty((H // 2, W // 2), dtype=torch.uint8, device="cuda")]
+    api.split420_u8_planes(ycc, W, H, *p8)
+    assert torch.equal(p8[0], ycc[:, :, 0])
+    p16 = [torch.empty(t.shape, dtype=torch.int16, device="cuda") for t in p8]
+    api.split420_u8(ycc, W, H, *p16)
+    for a, b in zip(p8, p16):
+        assert torch.equal(a.to(torch.int16) - 128, b)
+    luts = [synth.JPEG_LUMA, synth.JPEG_CHROMA, synth.JPEG_CHROMA]
+    dims = [(W, H), (W // 2, H // 2), (W // 2, H // 2)]
+    o8 = [torch.empty_like(t) for t in p8]
+    o16 = [torch.empty_like(t) for t in p16]
+    api.roundtrip_u8_batch([(a, o, w, h, l) for a, o, (w, h), l in zip(p8, o8, dims, luts)])
+    api.roundtrip_i16_planes([(a, o, w, h, l) for a, o, (w, h), l in zip(p16, o16, dims, luts)])
+    for a, b in zip(o8, o16):  # the same transform, quantiser and inverse on the same (shifted) samples: only the output clamp differs
+        assert torch.equal(a.to(torch.int16), (b + 128).clamp(0, 255))

@@ -41,7 +41,8 @@ WANT = {
     "k_scan_i16_rle": ("k_scan<0, true>", None, 5 * W * H),
     "k_scan_q32_rle": ("k_scan<1, true>", None, 4 * W * H),
     "k_u8_records": ("k_u8_records<false, false>", None, 4 * W * H),
-    "k_split420": ("k_split420", None, 6 * W * H),
+    "k_split420": ("k_split420<false>", None, 6 * W * H),
+    "k_split420_u8_planes": ("k_split420<true>", None, 9 * W * H // 2),
     "k_huffman_rows_q60": ("k_huffman_rows", None, 3 * W * H),
     "k_px_huffman_rows_q60": ("k_px_huffman_rows<false, 4, false, false>", None, W * H),
     "k_px_jpeg_scan_k1": ("k_px_huffman_rows<false, 4, true, false>", None, W * H),

@@ -16,7 +16,7 @@ by name and grid size.
     frame420_q32                                 the same frame as the reference's q32 product, one launch (k_q32_batch)
     batch256                                     configs[3] on one GPU: 256 separately allocated 4096^2 planes, forward, ONE launch (17.2 GB)
     u8_i16_fwd u8_i16_inv                        one plane: k_u8_i16_fwd / a batch of one through k_u8_batch<U8_INV>
-    scan_i16 scan_q32 u8_records split420 huffman px_huffman jpeg_scan   the stages either side (8192^2)"""
+    scan_i16 scan_q32 u8_records split420 split420_u8_planes huffman px_huffman jpeg_scan   the stages either side (8192^2)"""
 import os
 import sys
 
@@ -28,7 +28,7 @@ import simd_dct_amd as M
 from simd_dct_amd import synth
 
 ALL = ["copy", "roundtrip", "roundtrip_lut", "fwd", "inv", "q32", "stereo_sse", "stereo_scalar", "encq_sse", "encq_scalar", "f32", "frame420", "frame420_u8", "frame420_u8_fwd", "frame420_u8_inv", "frame420_q32", "u8_i16_fwd", "u8_i16_inv",
-       "scan_i16", "scan_q32", "u8_records", "split420", "huffman", "px_huffman", "jpeg_scan", "batch256"]
+       "scan_i16", "scan_q32", "u8_records", "split420", "split420_u8_planes", "huffman", "px_huffman", "jpeg_scan", "batch256"]
 which = sys.argv[1] if len(sys.argv) > 1 else "roundtrip"
 names = ALL if which == "all" else which.split(",")
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 6
@@ -207,13 +207,14 @@ def run(name):
                 scan, off = empty((W * H // 2,), torch.uint8), empty((H // 8 + 1,), torch.int64)
                 for i in range(n):
                     M.fwd_u8_jpeg_scan(s[i % 2].view(H, W), W, H, hseg, work, scan, off, lut=K1)
-    elif name == "split420":
+    elif name in ("split420", "split420_u8_planes"):
         drop("i16", "u8")
         rng = np.random.default_rng(1)
         ycc = up(rng.integers(0, 256, size=(H, W * 3), dtype=np.uint8))
-        y, cb, cr = empty((H, W), torch.int16), empty((H // 2, W // 2), torch.int16), empty((H // 2, W // 2), torch.int16)
+        dt = torch.int16 if name == "split420" else torch.uint8
+        y, cb, cr = empty((H, W), dt), empty((H // 2, W // 2), dt), empty((H // 2, W // 2), dt)
         for i in range(n):
-            M.split420_u8(ycc, W, H, y, cb, cr)
+            (M.split420_u8 if name == "split420" else M.split420_u8_planes)(ycc, W, H, y, cb, cr)
     else:
         raise SystemExit(f"unknown kernel name {name!r}; one of {ALL}")
     torch.cuda.synchronize()

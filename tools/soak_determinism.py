@@ -139,6 +139,9 @@ for (W, H) in ((8192, 8192), (4104, 2056 - 2056 % 16), (2048, 7680)):
         cb = torch.empty((H // 2, W // 2), dtype=torch.int16, device="cuda")
         cr = torch.empty_like(cb)
         soak("4:2:0 split", [y, cb, cr], lambda: M.split420_u8(ycc, W, H, y, cb, cr))
+        y8, cb8, cr8 = torch.empty((H, W), dtype=torch.uint8, device="cuda"), torch.empty((H // 2, W // 2), dtype=torch.uint8, device="cuda"), torch.empty((H // 2, W // 2), dtype=torch.uint8, device="cuda")
+        soak("4:2:0 split into 8-bit planes", [y8, cb8, cr8], lambda: M.split420_u8_planes(ycc, W, H, y8, cb8, cr8))
+        del y8, cb8, cr8
         del ycc, y, cb, cr
     torch.cuda.empty_cache()
 print("soak ok" if not failed else f"!! {failed} kernels were not deterministic")

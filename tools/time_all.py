@@ -106,6 +106,7 @@ cases += [
     ("u8 px -> finished JPEG scan, ONE launch, Annex K.1 table", 1.15, W * H, [lambda i=i: M.fwd_u8_jpeg_scan(u8[i], W, H, hseg[i % 2], pwork, pscan, poff, lut=K1) for i in range(NS)]),
     ("  the same as two launches: fused kernel + counted pack", 1.15, W * H, [lambda i=i: (M.fwd_u8_huffman_rows(u8[i], W, H, hseg[i % 2], hnb[i % 2], lut=K1, ff_counts=pff), M.jpeg_pack_rows(hseg[i % 2], hnb[i % 2], hstride, H // 8, pscan, poff, ff_counts=pff)) for i in range(NS)]),
     ("4:2:0 split (3+3 B/px)", 6, W * H, [lambda i=i: M.split420_u8(ycc[i], W, H, sy[i], scb[i], scr[i]) for i in range(2)]),
+    ("4:2:0 split into 8-bit planes (3+1.5 B/px)", 4.5, W * H, [lambda i=i: M.split420_u8_planes(ycc[i], W, H, sy[i].view(torch.uint8), scb[i].view(torch.uint8), scr[i].view(torch.uint8)) for i in range(2)]),
 ]
 # config 4 on one GPU: 256 independent 4096x4096 int16 planes, forward only.  Blocks are
 # independent, so a batch stacked in memory IS one tall plane: one launch, no per-plane drain.
