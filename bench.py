@@ -502,6 +502,7 @@ def main():
             for o in qout[0]:
                 o.zero_()
             r["reference_q32_product_one_launch"] = rate(lambda i: q1[i % NF8](), 2 * fpx, n=300, warm=300)
+            r["reference_q32_product_one_launch"]["clock_GHz"] = clock_under(lambda i: q1[i % NF8](), r["reference_q32_product_one_launch"]["ms"])
             torch.cuda.synchronize()
             r["reference_q32_product_one_launch"]["equals_three_single_plane_calls"] = all(torch.equal(a, b) for a, b in zip(three, qout[0]))
             r["reference_q32_product_three_calls_ms"] = round(rate(lambda i: [c() for c in q3[i % NF8]], 2 * fpx, n=300, warm=300)["ms"], 4)
@@ -706,7 +707,7 @@ def main():
             ISA_NAME = {"k_q32_avx": "mdct::k_q32_tile(mdct::U8Args)", "k_stereo_sse": "void mdct::k_fwd_quant_u8<1, 1, false, true>(mdct::U8Args)",
                         "k_stereo_scalar": "void mdct::k_fwd_quant_u8<2, 1, false, true>(mdct::U8Args)", "k_encq_sse": "void mdct::k_fwd_quant_u8<1, 3, false, true>(mdct::U8Args)",
                         "k_encq_scalar": "void mdct::k_fwd_quant_u8<2, 2, false, true>(mdct::U8Args)", "k_u8_batch_420": "void mdct::k_u8_batch<0, false, false>(mdct::BatchArgs)",
-                        "k_i16_batch_420": "void mdct::k_i16_batch<2, 1, false, false>(mdct::BatchArgs)", "k_i16_roundtrip": "void mdct::k_i16_tile<2, false, true, 2>(mdct::I16Args)"}
+                        "k_i16_batch_420": "void mdct::k_i16_batch<2, 1, false, false>(mdct::BatchArgs)", "k_q32_batch_420": "void mdct::k_q32_batch<false>(mdct::BatchArgs)", "k_i16_roundtrip": "void mdct::k_i16_tile<2, false, true, 2>(mdct::I16Args)"}
 
             def u8_block(q, key=None):
                 # the reference's own products on the same plane size: 2 algorithmic bytes per pixel
@@ -769,6 +770,20 @@ def main():
                           "reference_q32_product_one_launch", "reference_q32_product_three_calls_ms"):
                     blk[k] = c3u.get(k)
                 line["roofline_config3_420_u8"] = blk
+                q1f = c3u.get("reference_q32_product_one_launch") or {}
+                if "GBps" in q1f:  # the same frame as the REFERENCE's product: its own block, parity pinned by the reference
+                    line["roofline_q32_frame_420"] = {
+                        "bound": "vector issue at the clock the chip holds under this kernel (valu.frac_of_valu_floor), like roofline_u8",
+                        "kernel": "mdct::k_q32_batch<fast quantiser>", "what": "Y 7680x4320 + Cb/Cr 3840x2160 8-bit planes -> the reference's q32 product of each (own table, own output buffer), "
+                        "ONE launch (mdct_batch_run of mdct_batch_create_q32) where the reference's caller makes three calls (main.cpp:543)",
+                        "reference": "simdDCT_EncodeQuantize32ReorderBuffer_AVX2_Float per plane, simd_dct.cpp:2064-2262",
+                        "parity": "pinned by the reference: every plane equals the single-plane call on the device in this run (equals_three_single_plane_calls), whose 8192^2 output "
+                                  "hashes to the real reference's (roofline_u8); against the checker: tests/test_q32_batch.py",
+                        "achieved": q1f["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(q1f["GBps"] / HBM_PEAK_GBPS, 4),
+                        "algorithmic_bytes_per_launch": 2 * fpx3, "avg_launch_ms": q1f["ms"], "Mpx_s": round(fpx3 / (q1f["ms"] * 1e-3) / 1e6, 0),
+                        "three_single_plane_calls_ms": c3u.get("reference_q32_product_three_calls_ms"), "equals_three_single_plane_calls": q1f.get("equals_three_single_plane_calls"),
+                        "traffic": traffic.get("k_q32_batch_420_bytes_per_launch"), "traffic_round": traffic.get("traffic_round"),
+                        "valu": valu(ISA_NAME["k_q32_batch_420"], tiles3, q1f["ms"], q1f.get("clock_GHz"), "k_q32_batch_420")}
             c5 = extras.get("config5_f32_fwd", {})
             if "GBps" in c5:
                 line["roofline_f32"] = own_block(c5, "mdct::k_f32_tile<MODE_FWD>", 8 * W * H, "BASELINE.json configs[4]: float32 DCT-II, 8192x8192 plane (mdct_fwd_f32)", "k_f32_tile_fwd_bytes_per_launch")

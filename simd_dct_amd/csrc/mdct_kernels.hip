@@ -1866,8 +1866,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT
 // :117), so a partial last tile (3840-wide planes: 7.5 tiles per row) is a whole number of 8-block groups: its idle lanes redo the last block
 // and their bytes are never read back.  Block row r of a plane lands at r * pitch_out (8 * sizeX when tight), group g of the row at + 512 g
 // (:2227-2230).  Tables: OwnTables::qf holds the 64 multipliers 255 / (lut * 0.95) in pair order, negated for the fast quantiser.
+// (steered to exactly 3 / 4 / 5 waves per SIMD the frame takes 26.8-27.3 / 25.5-26.0 / 26.7-27.3 us against 24.5-24.8 as below: profiles/r05_exp_q32_batch_waves.log)
+#ifdef MDCT_Q32B_WAVES
+#define MDCT_Q32B_ATTR __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MDCT_Q32B_WAVES, MDCT_Q32B_WAVES)))
+#else
+#define MDCT_Q32B_ATTR __launch_bounds__(64, SAFE ? 1 : MDCT_Q32_MINW)
+#endif
 template <bool SAFE>
-__global__ __launch_bounds__(64, SAFE ? 1 : MDCT_Q32_MINW) void k_q32_batch(BatchArgs a)
+__global__ MDCT_Q32B_ATTR void k_q32_batch(BatchArgs a)
 {
   __shared__ __attribute__((aligned(16))) uint8_t wl[64 * kQ32RowStride];
   const BatchTile t = batch_tile(blockIdx.x);
