@@ -841,6 +841,8 @@ __global__ MDCT_U8_ATTR void k_fwd_quant_u8(U8Args a)
     // (Two barrier-free forms were measured and lost: a wave-private reorder with 64-byte pieces, 37 vs 32 us,
     // profiles/r03_exp_stereo_wave_private_reorder.log; one wave walking four tiles so that it owns the 256-byte pieces itself,
     // 17 KiB of LDS per wave = 9 waves per CU, 49.3 vs 32.0 us (SSE) and 37.7 vs 34.0 (scalar), profiles/r04_exp_stereo_wave4.log.
+    // Workgroups of 128 blocks -- a barrier between two waves instead of four, 128-byte pieces per plane: 32.1-32.6 vs 31.4-31.6 us (SSE),
+    // 32.6-33.2 vs 31.8-32.3 (scalar), profiles/r05_exp_stereo_wg128.log.
     // The tier runs 739 vector instructions per wave against q32's 663 -- the reference's x(1/255) and +127.0f are operations of
     // their own -- and 30.3 us against 27.3: it sits at the same vector-issue bound as q32, the barrier is not what it waits for.)
     __shared__ __attribute__((aligned(16))) uint8_t slds[64 * kStereoRowStride];
