@@ -27,7 +27,7 @@ def build_oracle():
 def oracle():
     global _orc
     if _orc is None:
-        src_m = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("dct_oracle.c", "dct_oracle.h"))
+        src_m = max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("dct_oracle.c", "dct_oracle.h", "time_mt.c"))
         if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < src_m:
             build_oracle()
         lib = ctypes.CDLL(ORACLE_SO)
@@ -49,6 +49,7 @@ def oracle():
         lib.orc_jpeg_pack_rows.argtypes = [vp, vp, sz, sz, ctypes.c_int, vp, sz, vp]
         lib.orc_huffman_spec.argtypes = [ctypes.c_int, vp, vp, vp]
         lib.orc_split420_u8.argtypes = [vp, sz, sz, sz, vp, vp, vp, sz, sz]
+        lib.orc_time_q32_mt.argtypes = [vp, ctypes.c_int, vp, vp, f32p, sz, sz, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
         lib.orc_dct8.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_int]
         lib.orc_idct8_own.argtypes = [vp, ctypes.c_ssize_t]
         _orc = lib
