@@ -26,9 +26,14 @@ enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2, K_OWN = 3 };
 
 /* ------------------------------------------------------------------------------------------
  * Engine-own 1-D kernels [unpinned]: the Arai-Agui-Nakajima scaled DCT (5 multiplies and 29
- * additions per 8 points, as popularised by the IJG float DCT), chosen because VALU issue
- * -- not HBM -- bounds these kernels on gfx950 and neither FMA nor packed fp32 ops are
- * cheaper there than separate mul/add.  Every operation is individually rounded.
+ * additions per 8 points, as popularised by the IJG float DCT).  VALU issue -- not HBM -- bounds
+ * the 8-bit kernels that use it on gfx950 and a packed fused multiply-add issues in the time of a
+ * packed multiply, so from round 6 on every multiply whose product feeds one or two additions is
+ * FUSED with them: 4 of the 5 multiplies per pass ride an fma (30 instead of 34 operations; the
+ * fifth, z5, feeds two fmas as the addend).  Every written operation -- add, sub, mul, fma -- is
+ * rounded once; fma(a, b, c) is the IEEE fusedMultiplyAdd (C99 fmaf), fma(-a, b, c) negates exactly.
+ * The engine's kernels (csrc/mdct_kernels.hip: aan_fwd8 / aan_inv8 and their packed forms) perform
+ * the same operations on the same operands.
  *   forward:  y_k = sqrt(8) * a_k * X_k      (X = orthonormal DCT-II, a_0 = 1, a_k = sqrt2*cos(k*pi/16))
  *   inverse:  takes z_k = a_k * X_k / sqrt(8) ... per dimension; the 2-D tables below carry
  *             the factors so that forward-table * inverse-table == 1/64 exactly.
@@ -45,48 +50,54 @@ static const float A_1847 = 1.847759065022573512f; /* 2*cos(pi/8)          */
 static const float A_1082 = 1.082392200292393968f; /* 2*(cos(pi/8)-cos(3pi/8)) */
 static const float A_2613 = 2.613125929752753056f; /* 2*(cos(pi/8)+cos(3pi/8)) */
 
-void orc_aan_fwd8(float *p, ptrdiff_t s)
+/* The functions that reach the butterflies are compiled twice (GCC function multi-versioning): for hosts with FMA3, where
+ * fmaf is one instruction, and for any x86-64, where it is libm's exactly rounded software fmaf.  Same bits either way. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__) && !defined(ORC_NO_CLONES)
+#define ORC_FMA_CLONES __attribute__((target_clones("fma", "default")))
+#else
+#define ORC_FMA_CLONES
+#endif
+
+static inline __attribute__((always_inline)) void aan_fwd8(float *p, ptrdiff_t s)
 {
   const float d0 = p[0], d1 = p[s], d2 = p[2 * s], d3 = p[3 * s], d4 = p[4 * s], d5 = p[5 * s], d6 = p[6 * s], d7 = p[7 * s];
   const float t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6;
   const float t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
   /* even part */
   const float e10 = t0 + t3, e13 = t0 - t3, e11 = t1 + t2, e12 = t1 - t2;
-  const float z1 = (e12 + e13) * A_707;
+  const float s1 = e12 + e13;
   /* odd part */
   const float o10 = t4 + t5, o11 = t5 + t6, o12 = t6 + t7;
   const float z5 = (o10 - o12) * A_382;
-  const float z2 = (A_541 * o10) + z5;
-  const float z4 = (A_1306 * o12) + z5;
-  const float z3 = o11 * A_707;
-  const float z11 = t7 + z3, z13 = t7 - z3;
+  const float z2 = fmaf(A_541, o10, z5);
+  const float z4 = fmaf(A_1306, o12, z5);
+  const float z11 = fmaf(o11, A_707, t7), z13 = fmaf(-o11, A_707, t7);
   p[0] = e10 + e11;
   p[4 * s] = e10 - e11;
-  p[2 * s] = e13 + z1;
-  p[6 * s] = e13 - z1;
+  p[2 * s] = fmaf(s1, A_707, e13);
+  p[6 * s] = fmaf(-s1, A_707, e13);
   p[5 * s] = z13 + z2;
   p[3 * s] = z13 - z2;
   p[s] = z11 + z4;
   p[7 * s] = z11 - z4;
 }
 
-void orc_aan_inv8(float *p, ptrdiff_t s)
+static inline __attribute__((always_inline)) void aan_inv8(float *p, ptrdiff_t s)
 {
   const float i0 = p[0], i1 = p[s], i2 = p[2 * s], i3 = p[3 * s], i4 = p[4 * s], i5 = p[5 * s], i6 = p[6 * s], i7 = p[7 * s];
   /* even part */
   const float e10 = i0 + i4, e11 = i0 - i4;
   const float e13 = i2 + i6;
-  const float e12 = ((i2 - i6) * A_1414) - e13;
+  const float e12 = fmaf(i2 - i6, A_1414, -e13);
   const float t0 = e10 + e13, t3 = e10 - e13, t1 = e11 + e12, t2 = e11 - e12;
   /* odd part */
   const float z13 = i5 + i3, z10 = i5 - i3, z11 = i1 + i7, z12 = i1 - i7;
   const float t7 = z11 + z13;
-  const float o11 = (z11 - z13) * A_1414;
   const float z5 = (z10 + z12) * A_1847;
-  const float o10 = (A_1082 * z12) - z5;
-  const float o12 = z5 - (A_2613 * z10);
+  const float o10 = fmaf(A_1082, z12, -z5);
+  const float o12 = fmaf(-A_2613, z10, z5);
   const float t6 = o12 - t7;
-  const float t5 = o11 - t6;
+  const float t5 = fmaf(z11 - z13, A_1414, -t6);
   const float t4 = o10 + t5;
   p[0] = t0 + t7;
   p[7 * s] = t0 - t7;
@@ -97,6 +108,9 @@ void orc_aan_inv8(float *p, ptrdiff_t s)
   p[4 * s] = t3 + t4;
   p[3 * s] = t3 - t4;
 }
+
+ORC_FMA_CLONES void orc_aan_fwd8(float *p, ptrdiff_t s) { aan_fwd8(p, s); }
+ORC_FMA_CLONES void orc_aan_inv8(float *p, ptrdiff_t s) { aan_inv8(p, s); }
 
 /* 2-D tables, index v*8+u.  fwd: raw AAN output -> orthonormal coefficient; inv: orthonormal
  * coefficient -> AAN inverse input (includes the 1/8 of the two inverse passes).  Products of
@@ -504,27 +518,27 @@ static void own_tables(const float *lut, float *qf, float *dq)
   }
 }
 
-static void raw_fwd(float *blk)
+static inline __attribute__((always_inline)) void raw_fwd(float *blk)
 {
   for (int r = 0; r < 8; r++)
-    orc_aan_fwd8(blk + r * 8, 1);
+    aan_fwd8(blk + r * 8, 1);
   for (int c = 0; c < 8; c++)
-    orc_aan_fwd8(blk + c, 8);
+    aan_fwd8(blk + c, 8);
 }
 
-static void raw_inv(float *blk)
+static inline __attribute__((always_inline)) void raw_inv(float *blk)
 {
   for (int c = 0; c < 8; c++)
-    orc_aan_inv8(blk + c, 8);
+    aan_inv8(blk + c, 8);
   for (int r = 0; r < 8; r++)
-    orc_aan_inv8(blk + r * 8, 1);
+    aan_inv8(blk + r * 8, 1);
 }
 
 #define FOR_BLOCKS for (size_t by = by0; by < by1; by++) for (size_t bx = 0; bx < W / 8; bx++)
 #define LOAD_I16(blk) for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c]
 #define AT(r, c) to[(by * 8 + (r)) * po + bx * 8 + (c)]
 
-int orc_fwd_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
+ORC_FMA_CLONES int orc_fwd_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
@@ -542,7 +556,7 @@ int orc_fwd_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const fl
   return 0;
 }
 
-int orc_inv_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
+ORC_FMA_CLONES int orc_inv_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
@@ -562,7 +576,7 @@ int orc_inv_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const fl
   return 0;
 }
 
-int orc_roundtrip_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
+ORC_FMA_CLONES int orc_roundtrip_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, const float *lut, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
@@ -587,7 +601,7 @@ int orc_roundtrip_i16(const int16_t *from, int16_t *to, size_t pi, size_t po, co
 /* 8-bit pixels <-> int16 coefficients (the JPEG-style pair).  level_shift != 0 centres the
  * pixels on zero (x - 128) on the way in and adds 128 back on the way out; pixels saturate to
  * [0, 255].  Same AAN arithmetic and tables as the int16 entry points. */
-int orc_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pi, size_t po, const float *lut, int level_shift, size_t W, size_t H, size_t by0, size_t by1)
+ORC_FMA_CLONES int orc_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pi, size_t po, const float *lut, int level_shift, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
@@ -607,7 +621,7 @@ int orc_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pi, size_t po, const
   return 0;
 }
 
-int orc_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pi, size_t po, const float *lut, int level_shift, size_t W, size_t H, size_t by0, size_t by1)
+ORC_FMA_CLONES int orc_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pi, size_t po, const float *lut, int level_shift, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
@@ -634,7 +648,7 @@ int orc_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pi, size_t po, const
 /* Fused 8-bit round trip (BASELINE.json configs[2] as SURVEY.md 8(d) states it: u8 planes in, u8 planes out): per block exactly
  * orc_fwd_u8_i16 followed by orc_inv_i16_u8 with the same table and level shift -- the int16 coefficients exist only in between
  * (tests/test_oracle.py checks this function against that composition).  pitches in bytes. */
-int orc_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pi, size_t po, const float *lut, int level_shift, size_t W, size_t H, size_t by0, size_t by1)
+ORC_FMA_CLONES int orc_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pi, size_t po, const float *lut, int level_shift, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
@@ -661,7 +675,7 @@ int orc_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pi, size_t po, con
   return 0;
 }
 
-int orc_fwd_f32(const float *from, float *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
+ORC_FMA_CLONES int orc_fwd_f32(const float *from, float *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)
@@ -680,7 +694,7 @@ int orc_fwd_f32(const float *from, float *to, size_t pi, size_t po, size_t W, si
   return 0;
 }
 
-int orc_inv_f32(const float *from, float *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
+ORC_FMA_CLONES int orc_inv_f32(const float *from, float *to, size_t pi, size_t po, size_t W, size_t H, size_t by0, size_t by1)
 {
   const int e = own_args(from, to, pi, po, W, H, by0, by1);
   if (e)

@@ -41,31 +41,33 @@ namespace mdct
 enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2 }; // the reference's three 1-D kernels (the engine-own one is aan_fwd8 below)
 
 // ---------------------------------------------------------------------------------------
-// Engine-own 1-D kernels (int16 / float32 paths; no reference counterpart): the scaled
-// Arai-Agui-Nakajima butterfly, 5 mul + 29 add per 8 points instead of 28 + 28.  Measured
-// on MI355X (tools/valubench, tools/experiments/exp_roundtrip): these kernels are bound by VALU ISSUE,
-// v_add/v_mul_f32 issue at ~2-3 cycles per wave64, v_fma_f32 and v_pk_*_f32 at ~4-5, so
-// neither fusing nor packing buys anything -- only fewer operations do.  The scale factors
-// live in 64-entry tables applied where a multiply exists anyway (quantise / dequantise),
+// Engine-own 1-D kernels (int16 / float32 / 8-bit round-trip paths; no reference counterpart, so the
+// reference tiers' no-FMA rule does not bind them): the scaled Arai-Agui-Nakajima butterfly, 5 mul + 29 add
+// per 8 points instead of 28 + 28, with 4 of the 5 multiplies FUSED into the additions they feed (round 6):
+// 30 operations per pass.  On MI355X a v_pk_fma_f32 issues in the time of a v_pk_mul_f32 (~4.2 cycles per
+// wave64, profiles/valu_issue_costs.json), so every fused pair saves a packed issue slot in the packed forms
+// below (the VALU-issue-bound k_u8_batch); a scalar v_fma_f32 costs about a v_mul + v_add, so the scalar forms
+// here gain nothing and lose nothing -- they follow because all forms must produce the same bits.
+// Explicit __builtin_fmaf only: contraction stays off, the compiler fuses nothing on its own.
+// The scale factors live in 64-entry tables applied where a multiply exists anyway (quantise / dequantise),
 // and for the fused round trip they cancel to exactly 1/64, which the final rounding step
-// absorbs (see store_i16x8).  Same operation order as the CPU checker (orc_aan_*).
+// absorbs (see store_i16x8).  Same operations on the same operands as the CPU checker (orc_aan_*).
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void aan_fwd8(const DctConsts &C, float &p0, float &p1, float &p2, float &p3, float &p4, float &p5, float &p6, float &p7)
 {
   const float t0 = p0 + p7, t7 = p0 - p7, t1 = p1 + p6, t6 = p1 - p6;
   const float t2 = p2 + p5, t5 = p2 - p5, t3 = p3 + p4, t4 = p3 - p4;
   const float e10 = t0 + t3, e13 = t0 - t3, e11 = t1 + t2, e12 = t1 - t2;
-  const float z1 = (e12 + e13) * C.c707;
+  const float s1 = e12 + e13;
   const float o10 = t4 + t5, o11 = t5 + t6, o12 = t6 + t7;
   const float z5 = (o10 - o12) * C.c382;
-  const float z2 = (C.c541 * o10) + z5;
-  const float z4 = (C.c1306 * o12) + z5;
-  const float z3 = o11 * C.c707;
-  const float z11 = t7 + z3, z13 = t7 - z3;
+  const float z2 = __builtin_fmaf(C.c541, o10, z5);
+  const float z4 = __builtin_fmaf(C.c1306, o12, z5);
+  const float z11 = __builtin_fmaf(o11, C.c707, t7), z13 = __builtin_fmaf(-o11, C.c707, t7);
   p0 = e10 + e11;
   p4 = e10 - e11;
-  p2 = e13 + z1;
-  p6 = e13 - z1;
+  p2 = __builtin_fmaf(s1, C.c707, e13);
+  p6 = __builtin_fmaf(-s1, C.c707, e13);
   p5 = z13 + z2;
   p3 = z13 - z2;
   p1 = z11 + z4;
@@ -76,16 +78,15 @@ __device__ __forceinline__ void aan_inv8(const DctConsts &C, float &p0, float &p
 {
   const float e10 = p0 + p4, e11 = p0 - p4;
   const float e13 = p2 + p6;
-  const float e12 = ((p2 - p6) * C.c1414) - e13;
+  const float e12 = __builtin_fmaf(p2 - p6, C.c1414, -e13);
   const float t0 = e10 + e13, t3 = e10 - e13, t1 = e11 + e12, t2 = e11 - e12;
   const float z13 = p5 + p3, z10 = p5 - p3, z11 = p1 + p7, z12 = p1 - p7;
   const float t7 = z11 + z13;
-  const float o11 = (z11 - z13) * C.c1414;
   const float z5 = (z10 + z12) * C.c1847;
-  const float o10 = (C.c1082 * z12) - z5;
-  const float o12 = z5 - (C.c2613 * z10);
+  const float o10 = __builtin_fmaf(C.c1082, z12, -z5);
+  const float o12 = __builtin_fmaf(-C.c2613, z10, z5);
   const float t6 = o12 - t7;
-  const float t5 = o11 - t6;
+  const float t5 = __builtin_fmaf(z11 - z13, C.c1414, -t6);
   const float t4 = o10 + t5;
   p0 = t0 + t7;
   p7 = t0 - t7;
@@ -138,6 +139,7 @@ __device__ __forceinline__ void raw_inv(const DctConsts &C, float (&b)[8][8])
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define MDCT_PKA(d, a, b, mods) asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "v"(b))
 #define MDCT_PKM(d, a, k, mods) asm("v_pk_mul_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "s"(k))
+#define MDCT_PKF(d, a, k, c, mods) asm("v_pk_fma_f32 %0, %1, %2, %3 " mods : "=v"(d) : "v"(a), "s"(k), "v"(c)) // d = a * k + c, one rounding
 // halves of the constant operand (src1) used for (lo, hi) of the result
 #define MDCT_K_LL "op_sel:[0,0] op_sel_hi:[1,0]"
 #define MDCT_K_HH "op_sel:[0,1] op_sel_hi:[1,1]"
@@ -1127,7 +1129,7 @@ static_assert(offsetof(DctConsts, c707) == 0 && offsetof(DctConsts, c382) == 4 &
 // forward, one line in natural pairs (p0,p1)(p2,p3)(p4,p5)(p6,p7) -> (y0,y4) (y2,y6) (y5,y3) (y1,y7)
 __device__ __forceinline__ void aan_fwd_h_stmt(const AanPk &K, f32x2 a01, f32x2 a23, f32x2 a45, f32x2 a67, f32x2 &o04, f32x2 &o26, f32x2 &o53, f32x2 &o17)
 {
-  f32x2 t01, t23, t76, t54, e01, e32, w, o, z13, z24, z1113;
+  f32x2 t01, t23, t76, t54, e01, e32, w, o, z24, z1113;
   MDCT_PKA(t01, a01, a67, MDCT_X);                   // (t0, t1) = (p0+p7, p1+p6)
   MDCT_PKA(t23, a23, a45, MDCT_X);                   // (t2, t3) = (p2+p5, p3+p4)
   MDCT_PKA(t76, a01, a67, MDCT_X " " MDCT_NEG_B);    // (t7, t6) = (p0-p7, p1-p6)
@@ -1135,17 +1137,16 @@ __device__ __forceinline__ void aan_fwd_h_stmt(const AanPk &K, f32x2 a01, f32x2 
   MDCT_PKA(e01, t01, t23, MDCT_X);                   // (e10, e11) = (t0+t3, t1+t2)
   MDCT_PKA(e32, t01, t23, MDCT_X " " MDCT_NEG_B);    // (e13, e12) = (t0-t3, t1-t2)
   MDCT_PKA(o04, e01, e01, MDCT_SUMDIFF);                  // (e10+e11, e10-e11)
-  w.x = e32.y + e32.x;                               // e12 + e13
+  w.x = e32.y + e32.x;                               // s1 = e12 + e13
   w.y = t54.x + t76.y;                               // o11 = t5 + t6
   o.x = t54.y + t54.x;                               // o10 = t4 + t5
   o.y = t76.y + t76.x;                               // o12 = t6 + t7
   f32x2 z5;
   z5.x = (o.x - o.y) * K.c707_382.y;                 // z5 = (o10 - o12) * c382
-  MDCT_PKM(z13, w, K.c707_382, MDCT_K_LL);           // (z1, z3) = (e12+e13, o11) * c707
-  MDCT_PKM(z24, o, K.c541_1306, MDCT_K_LH);          // (c541 o10, c1306 o12)
-  MDCT_PKA(z24, z24, z5, "op_sel:[0,0] op_sel_hi:[1,0]"); // (z2, z4) = (.. + z5, .. + z5)
-  MDCT_PKA(z1113, t76, z13, MDCT_LOHI " neg_hi:[0,1]"); // (z11, z13) = (t7+z3, t7-z3)
-  MDCT_PKA(o26, e32, z13, MDCT_LOLO " neg_hi:[0,1]");   // (e13+z1, e13-z1)
+  z5.y = z5.x;
+  MDCT_PKF(z24, o, K.c541_1306, z5, "op_sel:[0,0,0] op_sel_hi:[1,1,0]");                   // (z2, z4) = (c541 o10 + z5, c1306 o12 + z5)
+  MDCT_PKF(z1113, w, K.c707_382, t76, "op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[1,0,0]");  // (z11, z13) = (o11 c707 + t7, -o11 c707 + t7)
+  MDCT_PKF(o26, w, K.c707_382, e32, "op_sel:[0,0,0] op_sel_hi:[0,0,0] neg_hi:[1,0,0]");    // (s1 c707 + e13, -s1 c707 + e13)
   MDCT_PKA(o53, z1113, z24, MDCT_HILO " neg_hi:[0,1]"); // (z13+z2, z13-z2)
   MDCT_PKA(o17, z1113, z24, MDCT_LOHI " neg_hi:[0,1]"); // (z11+z4, z11-z4)
 }
@@ -1153,19 +1154,20 @@ __device__ __forceinline__ void aan_fwd_h_stmt(const AanPk &K, f32x2 a01, f32x2 
 // forward down a pair of columns, in place (direct image of aan_fwd8)
 __device__ __forceinline__ void aan_fwd_v_stmt(const AanPk &K, f32x2 (&p)[8])
 {
-  f32x2 t0, t7, t1, t6, t2, t5, t3, t4, e10, e13, e11, e12, z1, o10, o11, o12, z5, z2, z4, z3, z11, z13;
+  f32x2 t0, t7, t1, t6, t2, t5, t3, t4, e10, e13, e11, e12, s1, o10, o11, o12, z5, z2, z4, z11, z13;
   MDCT_PKA(t0, p[0], p[7], ""); MDCT_PKA(t7, p[0], p[7], MDCT_NEG_B); MDCT_PKA(t1, p[1], p[6], ""); MDCT_PKA(t6, p[1], p[6], MDCT_NEG_B);
   MDCT_PKA(t2, p[2], p[5], ""); MDCT_PKA(t5, p[2], p[5], MDCT_NEG_B); MDCT_PKA(t3, p[3], p[4], ""); MDCT_PKA(t4, p[3], p[4], MDCT_NEG_B);
   MDCT_PKA(e10, t0, t3, ""); MDCT_PKA(e13, t0, t3, MDCT_NEG_B); MDCT_PKA(e11, t1, t2, ""); MDCT_PKA(e12, t1, t2, MDCT_NEG_B);
-  MDCT_PKA(z1, e12, e13, ""); MDCT_PKM(z1, z1, K.c707_382, MDCT_K_LL);
+  MDCT_PKA(s1, e12, e13, "");
   MDCT_PKA(o10, t4, t5, ""); MDCT_PKA(o11, t5, t6, ""); MDCT_PKA(o12, t6, t7, "");
   MDCT_PKA(z5, o10, o12, MDCT_NEG_B); MDCT_PKM(z5, z5, K.c707_382, MDCT_K_HH);
-  MDCT_PKM(z2, o10, K.c541_1306, MDCT_K_LL); MDCT_PKA(z2, z2, z5, "");
-  MDCT_PKM(z4, o12, K.c541_1306, MDCT_K_HH); MDCT_PKA(z4, z4, z5, "");
-  MDCT_PKM(z3, o11, K.c707_382, MDCT_K_LL);
-  MDCT_PKA(z11, t7, z3, ""); MDCT_PKA(z13, t7, z3, MDCT_NEG_B);
+  MDCT_PKF(z2, o10, K.c541_1306, z5, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+  MDCT_PKF(z4, o12, K.c541_1306, z5, "op_sel:[0,1,0] op_sel_hi:[1,1,1]");
+  MDCT_PKF(z11, o11, K.c707_382, t7, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+  MDCT_PKF(z13, o11, K.c707_382, t7, "op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]");
   MDCT_PKA(p[0], e10, e11, ""); MDCT_PKA(p[4], e10, e11, MDCT_NEG_B);
-  MDCT_PKA(p[2], e13, z1, ""); MDCT_PKA(p[6], e13, z1, MDCT_NEG_B);
+  MDCT_PKF(p[2], s1, K.c707_382, e13, "op_sel:[0,0,0] op_sel_hi:[1,0,1]");
+  MDCT_PKF(p[6], s1, K.c707_382, e13, "op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]");
   MDCT_PKA(p[5], z13, z2, ""); MDCT_PKA(p[3], z13, z2, MDCT_NEG_B);
   MDCT_PKA(p[1], z11, z4, ""); MDCT_PKA(p[7], z11, z4, MDCT_NEG_B);
 }
@@ -1173,18 +1175,20 @@ __device__ __forceinline__ void aan_fwd_v_stmt(const AanPk &K, f32x2 (&p)[8])
 // inverse down a pair of columns, in place (direct image of aan_inv8)
 __device__ __forceinline__ void aan_inv_v_stmt(const AanPk &K, f32x2 (&p)[8])
 {
-  f32x2 e10, e11, e13, e12, t0, t3, t1, t2, z13, z10, z11, z12, t7, o11, z5, o10, o12, t6, t5, t4, m;
+  f32x2 e10, e11, e13, e12, t0, t3, t1, t2, z13, z10, z11, z12, t7, d, z5, o10, o12, t6, t5, t4;
   MDCT_PKA(e10, p[0], p[4], ""); MDCT_PKA(e11, p[0], p[4], MDCT_NEG_B);
   MDCT_PKA(e13, p[2], p[6], "");
-  MDCT_PKA(e12, p[2], p[6], MDCT_NEG_B); MDCT_PKM(e12, e12, K.c1414_1847, MDCT_K_LL); MDCT_PKA(e12, e12, e13, MDCT_NEG_B);
+  MDCT_PKA(d, p[2], p[6], MDCT_NEG_B); MDCT_PKF(e12, d, K.c1414_1847, e13, "op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]");
   MDCT_PKA(t0, e10, e13, ""); MDCT_PKA(t3, e10, e13, MDCT_NEG_B); MDCT_PKA(t1, e11, e12, ""); MDCT_PKA(t2, e11, e12, MDCT_NEG_B);
   MDCT_PKA(z13, p[5], p[3], ""); MDCT_PKA(z10, p[5], p[3], MDCT_NEG_B); MDCT_PKA(z11, p[1], p[7], ""); MDCT_PKA(z12, p[1], p[7], MDCT_NEG_B);
   MDCT_PKA(t7, z11, z13, "");
-  MDCT_PKA(o11, z11, z13, MDCT_NEG_B); MDCT_PKM(o11, o11, K.c1414_1847, MDCT_K_LL);
+  MDCT_PKA(d, z11, z13, MDCT_NEG_B);
   MDCT_PKA(z5, z10, z12, ""); MDCT_PKM(z5, z5, K.c1414_1847, MDCT_K_HH);
-  MDCT_PKM(m, z12, K.c1082_2613, MDCT_K_LL); MDCT_PKA(o10, m, z5, MDCT_NEG_B);
-  MDCT_PKM(m, z10, K.c1082_2613, MDCT_K_HH); MDCT_PKA(o12, z5, m, MDCT_NEG_B);
-  MDCT_PKA(t6, o12, t7, MDCT_NEG_B); MDCT_PKA(t5, o11, t6, MDCT_NEG_B); MDCT_PKA(t4, o10, t5, "");
+  MDCT_PKF(o10, z12, K.c1082_2613, z5, "op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]");
+  MDCT_PKF(o12, z10, K.c1082_2613, z5, "op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]");
+  MDCT_PKA(t6, o12, t7, MDCT_NEG_B);
+  MDCT_PKF(t5, d, K.c1414_1847, t6, "op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]");
+  MDCT_PKA(t4, o10, t5, "");
   MDCT_PKA(p[0], t0, t7, ""); MDCT_PKA(p[7], t0, t7, MDCT_NEG_B);
   MDCT_PKA(p[1], t1, t6, ""); MDCT_PKA(p[6], t1, t6, MDCT_NEG_B);
   MDCT_PKA(p[2], t2, t5, ""); MDCT_PKA(p[5], t2, t5, MDCT_NEG_B);
@@ -1197,18 +1201,17 @@ __device__ __forceinline__ void aan_inv_h_stmt(const AanPk &K, f32x2 i04, f32x2 
   f32x2 e, f, t03, t12, z3, z1, td, u, v;
   MDCT_PKA(e, i04, i04, MDCT_SUMDIFF);                    // (e10, e11) = (c0+c4, c0-c4)
   MDCT_PKA(f, i26, i26, MDCT_SUMDIFF);                    // (e13, c2-c6)
-  f.y = (f.y * K.c1414_1847.x) - f.x;                // e12 = (c2-c6)*sqrt2 - e13
+  f.y = __builtin_fmaf(f.y, K.c1414_1847.x, -f.x);   // e12 = (c2-c6)*sqrt2 - e13, fused
   MDCT_PKA(t03, e, f, MDCT_LOLO " neg_hi:[0,1]");       // (t0, t3) = (e10+e13, e10-e13)
   MDCT_PKA(t12, e, f, MDCT_HIHI " neg_hi:[0,1]");       // (t1, t2) = (e11+e12, e11-e12)
   MDCT_PKA(z3, i53, i53, MDCT_SUMDIFF);                   // (z13, z10) = (c5+c3, c5-c3)
   MDCT_PKA(z1, i17, i17, MDCT_SUMDIFF);                   // (z11, z12) = (c1+c7, c1-c7)
   MDCT_PKA(td, z1, z3, MDCT_LOLO " neg_hi:[0,1]");      // (t7, z11-z13)
-  td.y = td.y * K.c1414_1847.x;                      // o11
   const float z5 = (z3.y + z1.y) * K.c1414_1847.y;   // (z10 + z12) * c1847
-  const float o10 = (K.c1082_2613.x * z1.y) - z5;
-  const float o12 = z5 - (K.c1082_2613.y * z3.y);
+  const float o10 = __builtin_fmaf(K.c1082_2613.x, z1.y, -z5);
+  const float o12 = __builtin_fmaf(-K.c1082_2613.y, z3.y, z5);
   u.x = o12 - td.x;                                  // t6
-  u.y = td.y - u.x;                                  // t5
+  u.y = __builtin_fmaf(td.y, K.c1414_1847.x, -u.x);  // t5 = (z11-z13)*sqrt2 - t6, fused
   v.x = o10 + u.y;                                   // t4
   MDCT_PKA(o07, t03, td, MDCT_LOLO " neg_hi:[0,1]");    // (t0+t7, t0-t7)
   MDCT_PKA(o16, t12, u, MDCT_LOLO " neg_hi:[0,1]");     // (t1+t6, t1-t6)
@@ -1232,6 +1235,12 @@ __device__ __forceinline__ void aan_inv_h_stmt(const AanPk &K, f32x2 i04, f32x2 
 #define MDCT_SUB " neg_lo:[0,1] neg_hi:[0,1]\n\t"
 #define MDCT_KLO " op_sel:[0,0] op_sel_hi:[1,0]\n\t" // times the constant pair's low half, both halves
 #define MDCT_KHI " op_sel:[0,1] op_sel_hi:[1,1]\n\t" // times its high half
+// v_pk_fma_f32 d, a, k, c: a * (the constant pair's low / high half, both halves) + c; _NA negates a (-a k + c), _NC negates c (a k - c)
+#define MDCT_FKLO " op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+#define MDCT_FKHI " op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+#define MDCT_FKLO_NA " op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+#define MDCT_FKHI_NA " op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+#define MDCT_FKLO_NC " op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
 
 __device__ __forceinline__ void aan_fwd_v(const AanPk &K, f32x2 (&p)[8])
 {
@@ -1253,22 +1262,18 @@ __device__ __forceinline__ void aan_fwd_v(const AanPk &K, f32x2 (&p)[8])
       "v_pk_add_f32 %1, %0, %1" MDCT_SUB       /* r1 = e12 = t1 - t2 */
       "v_pk_add_f32 %0, %3, %8\n\t"            /* r0 = out0 = e10 + e11 */
       "v_pk_add_f32 %8, %3, %8" MDCT_SUB       /* T  = out4 = e10 - e11 */
-      "v_pk_add_f32 %3, %1, %2\n\t"            /* r3 = e12 + e13 */
+      "v_pk_add_f32 %3, %1, %2\n\t"            /* r3 = s1 = e12 + e13 */
       "v_pk_add_f32 %1, %4, %5\n\t"            /* r1 = o10 = t4 + t5            (e12 is dead) */
-      "v_pk_mul_f32 %3, %3, %9" MDCT_KLO       /* r3 = z1 = (e12 + e13) c707 */
       "v_pk_add_f32 %4, %5, %6\n\t"            /* r4 = o11 = t5 + t6 */
       "v_pk_add_f32 %5, %6, %7\n\t"            /* r5 = o12 = t6 + t7 */
-      "v_pk_add_f32 %6, %2, %3" MDCT_SUB       /* r6 = out6 = e13 - z1 */
-      "v_pk_add_f32 %2, %2, %3\n\t"            /* r2 = out2 = e13 + z1 */
+      "v_pk_fma_f32 %6, %3, %9, %2" MDCT_FKLO_NA /* r6 = out6 = -s1 c707 + e13 */
+      "v_pk_fma_f32 %2, %3, %9, %2" MDCT_FKLO    /* r2 = out2 = s1 c707 + e13 */
       "v_pk_add_f32 %3, %1, %5" MDCT_SUB       /* r3 = o10 - o12 */
-      "v_pk_mul_f32 %4, %4, %9" MDCT_KLO       /* r4 = z3 = o11 c707 */
       "v_pk_mul_f32 %3, %3, %9" MDCT_KHI       /* r3 = z5 = (o10 - o12) c382 */
-      "v_pk_mul_f32 %1, %1, %10" MDCT_KLO      /* r1 = c541 o10 */
-      "v_pk_mul_f32 %5, %5, %10" MDCT_KHI      /* r5 = c1306 o12 */
-      "v_pk_add_f32 %1, %1, %3\n\t"            /* r1 = z2 */
-      "v_pk_add_f32 %5, %5, %3\n\t"            /* r5 = z4 */
-      "v_pk_add_f32 %3, %7, %4\n\t"            /* r3 = z11 = t7 + z3 */
-      "v_pk_add_f32 %7, %7, %4" MDCT_SUB       /* r7 = z13 = t7 - z3 */
+      "v_pk_fma_f32 %1, %1, %10, %3" MDCT_FKLO   /* r1 = z2 = o10 c541 + z5 */
+      "v_pk_fma_f32 %5, %5, %10, %3" MDCT_FKHI   /* r5 = z4 = o12 c1306 + z5 */
+      "v_pk_fma_f32 %3, %4, %9, %7" MDCT_FKLO    /* r3 = z11 = o11 c707 + t7 */
+      "v_pk_fma_f32 %7, %4, %9, %7" MDCT_FKLO_NA /* r7 = z13 = -o11 c707 + t7 */
       "v_pk_add_f32 %4, %7, %1\n\t"            /* r4 = out5 = z13 + z2 */
       "v_pk_add_f32 %7, %7, %1" MDCT_SUB       /* r7 = out3 = z13 - z2 */
       "v_pk_add_f32 %1, %3, %5\n\t"            /* r1 = out1 = z11 + z4 */
@@ -1291,25 +1296,21 @@ __device__ __forceinline__ void aan_inv_v(const AanPk &K, f32x2 (&p)[8])
       "v_pk_add_f32 %6, %2, %6" MDCT_SUB       /* r6 = p2 - p6 */
       "v_pk_add_f32 %2, %5, %3\n\t"            /* r2 = z13 = p5 + p3 */
       "v_pk_add_f32 %3, %5, %3" MDCT_SUB       /* r3 = z10 = p5 - p3 */
-      "v_pk_mul_f32 %6, %6, %9" MDCT_KLO       /* r6 = (p2 - p6) c1414 */
       "v_pk_add_f32 %5, %1, %7\n\t"            /* r5 = z11 = p1 + p7 */
       "v_pk_add_f32 %7, %1, %7" MDCT_SUB       /* r7 = z12 = p1 - p7 */
-      "v_pk_add_f32 %6, %6, %0" MDCT_SUB       /* r6 = e12 = (p2 - p6) c1414 - e13 */
+      "v_pk_fma_f32 %6, %6, %9, %0" MDCT_FKLO_NC /* r6 = e12 = (p2 - p6) c1414 - e13 */
       "v_pk_add_f32 %1, %5, %2\n\t"            /* r1 = t7 = z11 + z13 */
       "v_pk_add_f32 %5, %5, %2" MDCT_SUB       /* r5 = z11 - z13 */
       "v_pk_add_f32 %2, %3, %7\n\t"            /* r2 = z10 + z12 */
-      "v_pk_mul_f32 %5, %5, %9" MDCT_KLO       /* r5 = o11 = (z11 - z13) c1414 */
       "v_pk_mul_f32 %2, %2, %9" MDCT_KHI       /* r2 = z5 = (z10 + z12) c1847 */
-      "v_pk_mul_f32 %7, %7, %10" MDCT_KLO      /* r7 = c1082 z12 */
-      "v_pk_mul_f32 %3, %3, %10" MDCT_KHI      /* r3 = c2613 z10 */
-      "v_pk_add_f32 %7, %7, %2" MDCT_SUB       /* r7 = o10 = c1082 z12 - z5 */
-      "v_pk_add_f32 %3, %2, %3" MDCT_SUB       /* r3 = o12 = z5 - c2613 z10 */
+      "v_pk_fma_f32 %7, %7, %10, %2" MDCT_FKLO_NC /* r7 = o10 = z12 c1082 - z5 */
+      "v_pk_fma_f32 %3, %3, %10, %2" MDCT_FKHI_NA /* r3 = o12 = -z10 c2613 + z5 */
       "v_pk_add_f32 %2, %8, %0\n\t"            /* r2 = t0 = e10 + e13 */
       "v_pk_add_f32 %0, %8, %0" MDCT_SUB       /* r0 = t3 = e10 - e13 */
       "v_pk_add_f32 %3, %3, %1" MDCT_SUB       /* r3 = t6 = o12 - t7 */
       "v_pk_add_f32 %8, %4, %6\n\t"            /* T  = t1 = e11 + e12 */
       "v_pk_add_f32 %6, %4, %6" MDCT_SUB       /* r6 = t2 = e11 - e12 */
-      "v_pk_add_f32 %5, %5, %3" MDCT_SUB       /* r5 = t5 = o11 - t6 */
+      "v_pk_fma_f32 %5, %5, %9, %3" MDCT_FKLO_NC /* r5 = t5 = (z11 - z13) c1414 - t6 */
       "v_pk_add_f32 %4, %2, %1\n\t"            /* r4 = out0 = t0 + t7 */
       "v_pk_add_f32 %2, %2, %1" MDCT_SUB       /* r2 = out7 = t0 - t7 */
       "v_pk_add_f32 %7, %7, %5\n\t"            /* r7 = t4 = o10 + t5 */
@@ -1343,20 +1344,18 @@ __device__ __forceinline__ void aan_fwd_h(const AanPk &K, f32x2 a01, f32x2 a23, 
   const f32x2 t76 = a01, t54 = a23, e32 = a67;
   o04 = T0;
   f32x2 w, o, z5;
-  w.x = e32.y + e32.x;                               // e12 + e13
+  w.x = e32.y + e32.x;                               // s1 = e12 + e13
   w.y = t54.x + t76.y;                               // o11 = t5 + t6
   o.x = t54.y + t54.x;                               // o10 = t4 + t5
   o.y = t76.y + t76.x;                               // o12 = t6 + t7
   z5.x = (o.x - o.y) * K.c707_382.y;                 // z5 = (o10 - o12) * c382
   z5.y = z5.x;
   f32x2 T;
-  asm("v_pk_mul_f32 %0, %0, %8 op_sel:[0,0] op_sel_hi:[1,0]\n\t"              /* w  = (z1, z3) = (e12+e13, o11) c707 */
-      "v_pk_mul_f32 %1, %1, %9 op_sel:[0,0] op_sel_hi:[1,1]\n\t"              /* o  = (c541 o10, c1306 o12) */
-      "v_pk_add_f32 %1, %1, %7 op_sel:[0,0] op_sel_hi:[1,0]\n\t"              /* o  = (z2, z4) = (.. + z5, .. + z5) */
-      "v_pk_add_f32 %2, %5, %0 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t" /* T  = (z11, z13) = (t7+z3, t7-z3) */
-      "v_pk_add_f32 %3, %6, %0 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t" /* o26 = (e13+z1, e13-z1) */
-      "v_pk_add_f32 %4, %2, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]\n\t" /* o53 = (z13+z2, z13-z2) */
-      "v_pk_add_f32 %2, %2, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]"     /* T -> o17 = (z11+z4, z11-z4) */
+  asm("v_pk_fma_f32 %1, %1, %9, %7 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"                  /* o  = (z2, z4) = (o10 c541 + z5, o12 c1306 + z5) */
+      "v_pk_fma_f32 %2, %0, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_hi:[1,0,0]\n\t"   /* T  = (z11, z13) = (o11 c707 + t7, -o11 c707 + t7) */
+      "v_pk_fma_f32 %3, %0, %8, %6 op_sel:[0,0,0] op_sel_hi:[0,0,0] neg_hi:[1,0,0]\n\t"   /* o26 = (s1 c707 + e13, -s1 c707 + e13) */
+      "v_pk_add_f32 %4, %2, %1 op_sel:[1,0] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"             /* o53 = (z13+z2, z13-z2) */
+      "v_pk_add_f32 %2, %2, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]"                 /* T -> o17 = (z11+z4, z11-z4) */
       : "+v"(w), "+v"(o), "=&v"(T), "=&v"(o26), "=&v"(o53)
       : "v"(t76), "v"(e32), "v"(z5), "s"(K.c707_382), "s"(K.c541_1306));
   o17 = T;
@@ -1377,14 +1376,13 @@ __device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, 
       "v_pk_add_f32 %4, %3, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]"      /* td = (t7, z11-z13) */
       : "+v"(i04), "+v"(i26), "+v"(i53), "+v"(i17), "=&v"(td));
   f32x2 f = i26, u;
-  f.y = (f.y * K.c1414_1847.x) - f.x;                    // e12 = (c2-c6)*sqrt2 - e13
-  const float o11 = td.y * K.c1414_1847.x;
+  f.y = __builtin_fmaf(f.y, K.c1414_1847.x, -f.x);       // e12 = (c2-c6)*sqrt2 - e13, fused
   const float z5 = (i53.y + i17.y) * K.c1414_1847.y;     // (z10 + z12) * c1847
-  const float o10 = (K.c1082_2613.x * i17.y) - z5;
-  const float o12 = z5 - (K.c1082_2613.y * i53.y);
+  const float o10 = __builtin_fmaf(K.c1082_2613.x, i17.y, -z5);
+  const float o12 = __builtin_fmaf(-K.c1082_2613.y, i53.y, z5);
   u.x = o12 - td.x;                                      // t6
-  u.y = o11 - u.x;                                       // t5
-  td.y = o10 + u.y;                                      // t4 (o11 is dead: its half of td carries t4 into the block below)
+  u.y = __builtin_fmaf(td.y, K.c1414_1847.x, -u.x);      // t5 = (z11-z13)*sqrt2 - t6, fused
+  td.y = o10 + u.y;                                      // t4 (z11-z13 is dead: its half of td carries t4 into the block below)
   f32x2 t03, t12;
   asm("v_pk_add_f32 %4, %6, %7 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n\t"  /* t03 = (t0, t3) = (e10+e13, e10-e13) */
       "v_pk_add_f32 %5, %6, %7 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"  /* t12 = (t1, t2) = (e11+e12, e11-e12) */

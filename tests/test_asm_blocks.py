@@ -24,6 +24,11 @@ def mul(a, b):
     return ("mul",) + tuple(sorted((a, b), key=repr))
 
 
+def fma(a, b, c, neg_product=False, neg_addend=False):
+    """one rounding of (+-)(a * b) (+-) c: the IEEE fusedMultiplyAdd with exact negations of the product / the addend"""
+    return ("fma", tuple(sorted((a, b), key=repr)), bool(neg_product), c, bool(neg_addend))
+
+
 C = {n: ("c", n) for n in ("c707", "c382", "c541", "c1306", "c1414", "c1847", "c1082", "c2613")}
 
 
@@ -31,34 +36,52 @@ def aan_fwd8(p):  # mdct_kernels.hip: aan_fwd8
     t0, t7, t1, t6 = add(p[0], p[7]), sub(p[0], p[7]), add(p[1], p[6]), sub(p[1], p[6])
     t2, t5, t3, t4 = add(p[2], p[5]), sub(p[2], p[5]), add(p[3], p[4]), sub(p[3], p[4])
     e10, e13, e11, e12 = add(t0, t3), sub(t0, t3), add(t1, t2), sub(t1, t2)
-    z1 = mul(add(e12, e13), C["c707"])
+    s1 = add(e12, e13)
     o10, o11, o12 = add(t4, t5), add(t5, t6), add(t6, t7)
     z5 = mul(sub(o10, o12), C["c382"])
-    z2, z4 = add(mul(C["c541"], o10), z5), add(mul(C["c1306"], o12), z5)
-    z3 = mul(o11, C["c707"])
-    z11, z13 = add(t7, z3), sub(t7, z3)
-    return [add(e10, e11), add(z11, z4), add(e13, z1), sub(z13, z2), sub(e10, e11), add(z13, z2), sub(e13, z1), sub(z11, z4)]
+    z2, z4 = fma(C["c541"], o10, z5), fma(C["c1306"], o12, z5)
+    z11, z13 = fma(o11, C["c707"], t7), fma(o11, C["c707"], t7, neg_product=True)
+    return [add(e10, e11), add(z11, z4), fma(s1, C["c707"], e13), sub(z13, z2), sub(e10, e11), add(z13, z2), fma(s1, C["c707"], e13, neg_product=True), sub(z11, z4)]
 
 
 def aan_inv8(p):  # mdct_kernels.hip: aan_inv8
     e10, e11, e13 = add(p[0], p[4]), sub(p[0], p[4]), add(p[2], p[6])
-    e12 = sub(mul(sub(p[2], p[6]), C["c1414"]), e13)
+    e12 = fma(sub(p[2], p[6]), C["c1414"], e13, neg_addend=True)
     t0, t3, t1, t2 = add(e10, e13), sub(e10, e13), add(e11, e12), sub(e11, e12)
     z13, z10, z11, z12 = add(p[5], p[3]), sub(p[5], p[3]), add(p[1], p[7]), sub(p[1], p[7])
     t7 = add(z11, z13)
-    o11 = mul(sub(z11, z13), C["c1414"])
     z5 = mul(add(z10, z12), C["c1847"])
-    o10 = sub(mul(C["c1082"], z12), z5)
-    o12 = sub(z5, mul(C["c2613"], z10))
+    o10 = fma(C["c1082"], z12, z5, neg_addend=True)
+    o12 = fma(C["c2613"], z10, z5, neg_product=True)
     t6 = sub(o12, t7)
-    t5 = sub(o11, t6)
+    t5 = fma(sub(z11, z13), C["c1414"], t6, neg_addend=True)
     t4 = add(o10, t5)
     return [add(t0, t7), add(t1, t6), add(t2, t5), sub(t3, t4), add(t3, t4), sub(t2, t5), sub(t1, t6), sub(t0, t7)]
 
 
 # ---- the asm blocks of one function, as lists of (op, dst, src0, src1, modifiers)
 MACROS = {"MDCT_SUB": ' neg_lo:[0,1] neg_hi:[0,1]\\n\\t', "MDCT_KLO": ' op_sel:[0,0] op_sel_hi:[1,0]\\n\\t', "MDCT_KHI": ' op_sel:[0,1] op_sel_hi:[1,1]\\n\\t',
-          "MDCT_XSEL": ' op_sel:[0,1] op_sel_hi:[1,0]'}
+          "MDCT_XSEL": ' op_sel:[0,1] op_sel_hi:[1,0]',
+          "MDCT_FKLO": ' op_sel:[0,0,0] op_sel_hi:[1,0,1]\\n\\t', "MDCT_FKHI": ' op_sel:[0,1,0] op_sel_hi:[1,1,1]\\n\\t',
+          "MDCT_FKLO_NA": ' op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\\n\\t',
+          "MDCT_FKHI_NA": ' op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\\n\\t',
+          "MDCT_FKLO_NC": ' op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\\n\\t'}
+
+
+def test_the_macros_above_are_the_source_s():
+    for k, v in MACROS.items():
+        line = next(ln for ln in SRC.splitlines() if ln.startswith("#define %s " % k))
+        text = line[line.index('"') + 1:]
+        assert text[:text.index('"')] == v, k
+
+
+def parse_line(line):
+    mm = re.match(r"(v_pk_add_f32|v_pk_mul_f32) %(\d+), %(\d+), %(\d+)()(.*)$", line) or re.match(r"(v_pk_fma_f32) %(\d+), %(\d+), %(\d+), %(\d+)(.*)$", line)
+    assert mm, line
+    mods = {k: [int(x) for x in v.split(",")] for k, v in re.findall(r"(op_sel|op_sel_hi|neg_lo|neg_hi):\[([0-9,]+)\]", mm.group(6))}
+    n = 3 if mm.group(1) == "v_pk_fma_f32" else 2
+    assert all(len(v) == n for v in mods.values()), line
+    return (mm.group(1), int(mm.group(2)), int(mm.group(3)), int(mm.group(4)), int(mm.group(5)) if mm.group(5) else None, mods)
 
 
 def blocks_of(func):
@@ -76,16 +99,25 @@ def blocks_of(func):
             line = line.strip()
             if not line:
                 continue
-            mm = re.match(r"(v_pk_add_f32|v_pk_mul_f32) %(\d+), %(\d+), %(\d+)(.*)$", line)
-            assert mm, line
-            mods = {k: [int(x) for x in v.split(",")] for k, v in re.findall(r"(op_sel|op_sel_hi|neg_lo|neg_hi):\[([0-9,]+)\]", mm.group(5))}
-            ins.append((mm.group(1), int(mm.group(2)), int(mm.group(3)), int(mm.group(4)), mods))
+            ins.append(parse_line(line))
         out.append(ins)
     return out
 
 
 def run(ins, regs):
-    for op, d, a, b, mods in ins:
+    for op, d, a, b, c, mods in ins:
+        if op == "v_pk_fma_f32":  # d = a * b + c, every source with its own half select and negation (VOP3P)
+            sel, sel_hi = mods.get("op_sel", [0, 0, 0]), mods.get("op_sel_hi", [1, 1, 1])
+            nlo, nhi = mods.get("neg_lo", [0, 0, 0]), mods.get("neg_hi", [0, 0, 0])
+            A, B, Cc = regs[a], regs[b], regs[c]
+            assert A is not None and B is not None and Cc is not None, ("read before write", op, d, a, b, c)
+            halves = []
+            for s3, n3 in ((sel, nlo), (sel_hi, nhi)):
+                x, y, z = A[s3[0]], B[s3[1]], Cc[s3[2]]
+                assert x is not None and y is not None and z is not None, ("undefined half read", op, d)
+                halves.append(fma(x, y, z, neg_product=n3[0] ^ n3[1], neg_addend=n3[2]))
+            regs[d] = tuple(halves)
+            continue
         sel, sel_hi = mods.get("op_sel", [0, 0]), mods.get("op_sel_hi", [1, 1])
         nlo, nhi = mods.get("neg_lo", [0, 0]), mods.get("neg_hi", [0, 0])
         A, B = regs[a], regs[b]
@@ -114,7 +146,8 @@ K3, K4 = (C["c1414"], C["c1847"]), (C["c1082"], C["c2613"])
 def test_column_passes_are_the_scalar_butterflies_on_both_halves():
     for func, defn, ks, perm in (("aan_fwd_v", aan_fwd8, (K1, K2), None), ("aan_inv_v", aan_inv8, (K3, K4), None)):
         (ins,) = blocks_of(func)
-        assert len(ins) == 34  # 29 additions + 5 multiplications per 8 points, none spent on moves
+        assert len(ins) == 30  # 29 additions + 5 multiplications per 8 points, 4 of the multiplications fused into additions, none spent on moves
+        assert sum(1 for i in ins if i[0] == "v_pk_fma_f32") == (6 if func == "aan_fwd_v" else 4) and sum(1 for i in ins if i[0] == "v_pk_mul_f32") == 1
         regs = {i: sym("p%d" % i) for i in range(8)}
         regs[8] = None
         regs[9], regs[10] = ks
@@ -140,12 +173,12 @@ def test_forward_row_pass():
     w = (add(e32[1], e32[0]), add(t54[0], t76[1]))
     o = (add(t54[1], t54[0]), add(t76[1], t76[0]))
     z5 = mul(sub(o[0], o[1]), C["c382"])
-    regs = {0: w, 1: o, 2: None, 3: None, 4: None, 5: t76, 6: e32, 7: (z5, z5), 8: K1, 9: K2}
+    regs = {0: w, 1: o, 2: None, 3: None, 4: None, 5: t76, 6: e32, 7: (z5, None), 8: K1, 9: K2}  # only the low half of z5 may be read
     run(b2, regs)
     o17, o26, o53 = regs[2], regs[3], regs[4]
     y = aan_fwd8(p)
     assert o04 == (y[0], y[4]) and o26 == (y[2], y[6]) and o53 == (y[5], y[3]) and o17 == (y[1], y[7])
-    assert len(b1) + len(b2) == 14  # + 6 scalar operations = 20 instructions per line
+    assert len(b1) + len(b2) == 12  # + 6 scalar operations = 18 instructions per line
 
 
 def test_inverse_row_pass():
@@ -154,19 +187,18 @@ def test_inverse_row_pass():
     regs = {0: (c[0], c[4]), 1: (c[2], c[6]), 2: (c[5], c[3]), 3: (c[1], c[7]), 4: None}
     run(b1, regs)
     e, f, z3, z1, td = regs[0], regs[1], regs[2], regs[3], regs[4]
-    f = (f[0], sub(mul(f[1], C["c1414"]), f[0]))
-    o11 = mul(td[1], C["c1414"])
+    f = (f[0], fma(f[1], C["c1414"], f[0], neg_addend=True))  # the compiler-visible middle of aan_inv_h, as written there
     z5 = mul(add(z3[1], z1[1]), C["c1847"])
-    o10 = sub(mul(C["c1082"], z1[1]), z5)
-    o12 = sub(z5, mul(C["c2613"], z3[1]))
+    o10 = fma(C["c1082"], z1[1], z5, neg_addend=True)
+    o12 = fma(C["c2613"], z3[1], z5, neg_product=True)
     ux = sub(o12, td[0])
-    uy = sub(o11, ux)
+    uy = fma(td[1], C["c1414"], ux, neg_addend=True)
     td = (td[0], add(o10, uy))
     regs = {0: None, 1: None, 2: None, 3: None, 4: None, 5: None, 6: e, 7: f, 8: td, 9: (ux, uy)}
     run(b2, regs)
     x = aan_inv8(c)
     assert regs[0] == (x[0], x[7]) and regs[1] == (x[1], x[6]) and regs[2] == (x[2], x[5]) and regs[3] == (x[4], x[3])
-    assert len(b1) + len(b2) == 11  # + 12 scalar operations = 23 per line
+    assert len(b1) + len(b2) == 11  # + 8 scalar operations (4 of them fused multiply-adds) = 19 per line
 
 
 def test_quantise_dequantise_block():
@@ -197,8 +229,5 @@ def blocks_of_quant():
         line = line.strip()
         if not line:
             continue
-        mm = re.match(r"(v_pk_add_f32|v_pk_mul_f32) %(\d+), %(\d+), %(\d+)(.*)$", line)
-        assert mm, line
-        mods = {k: [int(x) for x in v.split(",")] for k, v in re.findall(r"(op_sel|op_sel_hi|neg_lo|neg_hi):\[([0-9,]+)\]", mm.group(5))}
-        ins.append((mm.group(1), int(mm.group(2)), int(mm.group(3)), int(mm.group(4)), mods))
+        ins.append(parse_line(line))
     return [ins]

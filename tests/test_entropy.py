@@ -74,7 +74,9 @@ def test_libjpeg_decodes_the_checkers_stream():
     img[8:16, 64:96] = (np.indices((8, 32)).sum(0) % 2) * 255
     img[16:24, :] = synth.plane_u8_np(W, 8, "noise")
     k = np.cos((2 * np.arange(8) + 1) * 7 * np.pi / 16)
-    img[24:32, 0:8] = np.rint(128 + 100 * np.outer(k, k)).astype(np.uint8)  # only the (7,7) coefficient: scan position 63
+    img[24:32, 0:8] = np.rint(128 + 100 * np.outer(k, k)).astype(np.uint8)  # mostly the (7,7) coefficient: scan position 63
+    k4 = np.cos((2 * np.arange(8) + 1) * 4 * np.pi / 16)  # +-sqrt(1/2): the outer product is +-1/2, the pixels are exact integers, so
+    img[24:32, 8:16] = np.rint(128 + 100 * np.outer(k4, k4)).astype(np.uint8)  # ONLY DC and (4,4) survive whatever the rounding: a run of 40 zeros
     q1 = np.ones(64, dtype=np.float32)
     coef, comp = _encode_cpu(img, q1)
     assert (comp["seg_bytes"] > 0).all()

@@ -344,3 +344,31 @@ def test_oracle_equals_real_reference_property_based():
         assert np.array_equal(a, b), (beh, W, H, y0, y1, logscale, kind, seed)
 
     check()
+
+
+def test_fma_clone_and_libm_fmaf_build_agree(tmp_path):
+    """The engine-own butterflies fuse 4 multiplies per pass (fmaf).  oracle/dct_oracle.c compiles the functions that reach them twice
+    (an FMA3 clone where fmaf is one instruction, a baseline clone calling libm's exactly rounded fmaf); a build without clones must
+    produce the same bits as whichever clone this host resolves to, on full-range inputs."""
+    import ctypes
+    import subprocess
+
+    so = str(tmp_path / "liboracle_noclones.so")
+    subprocess.run(["gcc", "-std=c11", "-O2", "-ffp-contract=off", "-fPIC", "-msse4.1", "-DORC_NO_CLONES", "-shared", "-pthread", "-o", so,
+                    os.path.join(ROOT, "oracle", "dct_oracle.c"), os.path.join(ROOT, "oracle", "time_mt.c"), "-lm"], check=True)
+    plain = ctypes.CDLL(so)
+    sz, vp, f32p = ctypes.c_size_t, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)
+    W, H = 256, 64
+    rng = np.random.default_rng(6)
+    src = rng.integers(-32768, 32767, size=(H, W), dtype=np.int16)
+    for name in ("orc_fwd_i16", "orc_inv_i16", "orc_roundtrip_i16"):
+        for lib_lut in (None, (QUANTIZE_BASE * np.float32(7)).astype(np.float32)):
+            outs = []
+            for lib in (plain, O.oracle()):
+                fn = getattr(lib, name)
+                fn.argtypes = [vp, vp, sz, sz, f32p, sz, sz, sz, sz]
+                out = np.zeros_like(src)
+                lp = None if lib_lut is None else lib_lut.ctypes.data_as(f32p)
+                assert fn(src.ctypes.data, out.ctypes.data, W, W, lp, W, H, 0, H // 8) == 0
+                outs.append(out)
+            assert np.array_equal(outs[0], outs[1]), name
