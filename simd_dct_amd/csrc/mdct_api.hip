@@ -640,6 +640,13 @@ struct BatchInput
 constexpr int kModeRoundtripU8 = 3, kModeFwdU8 = 4, kModeInvU8 = 5;
 inline bool is_u8_mode(int mode) { return mode >= kModeRoundtripU8 && mode <= kModeInvU8; }
 constexpr int kModeQ32 = 6; // 8-bit planes -> the reference's q32 product (k_q32_batch)
+// k_u8_batch and k_q32_batch tile planes whose rows end in half a tile over PAIRS of block rows (batch_plan.h: kDescPaired); k_i16_batch does not
+// (MDCT_PAIRED_ROWS=0 in the environment: one tile grid per block row as before round 6 -- the A/B knob of tools/experiments/exp_paired_rows.py)
+inline bool pairs_rows(int mode)
+{
+  const char *e = getenv("MDCT_PAIRED_ROWS");
+  return (is_u8_mode(mode) || mode == kModeQ32) && !(e && e[0] == '0');
+}
 
 // what the layout code sees of a plane of the mixed (8-bit pixels <-> int16 coefficients) batches
 struct GenPlane
@@ -826,7 +833,7 @@ int run_batch(int mode, const Plane *planes, int n, int level_shift, void *strea
   for (int i0 = 0; i0 < n;)
   {
     mdct::BatchLayout lay;
-    mdct::batch_layout(planes, in.table_id.data(), in.has_lut.data(), i0, n, mdct::kBatchBlob, sizeof(mdct::OwnTables), lay);
+    mdct::batch_layout(planes, in.table_id.data(), in.has_lut.data(), i0, n, mdct::kBatchBlob, sizeof(mdct::OwnTables), lay, pairs_rows(mode));
     if (lay.consumed == 0)
       return fail(MDCT_NOT_SUPPORTED, "plane %d (%zux%zu) exceeds the limit of 2^26 - 1 tiles per launch; split it", i0, planes[i0].sizeX, planes[i0].sizeY);
     i0 += lay.consumed;
@@ -1190,7 +1197,7 @@ static int batch_create(mdct_batch **out, int mode, const Plane *planes, int n_p
   for (int i0 = 0; i0 < n_planes;)
   {
     mdct::BatchLayout lay;
-    mdct::batch_layout(planes, in.table_id.data(), in.has_lut.data(), i0, n_planes, 0, sizeof(mdct::OwnTables), lay);
+    mdct::batch_layout(planes, in.table_id.data(), in.has_lut.data(), i0, n_planes, 0, sizeof(mdct::OwnTables), lay, pairs_rows(mode));
     if (lay.consumed == 0)
     {
       delete b;

@@ -1626,15 +1626,17 @@ struct BatchTile
 {
   u32x16_s d;      // the plane's BatchDesc
   uint32_t row;    // block row within the plane
-  uint32_t tile;   // 64-block tile within the row (the last one possibly partial)
+  uint32_t tile;   // 64-block tile within the row (the last one possibly partial); b0 / 64 where rows are not paired
+  uint32_t b0, s, straddle; // batch_pos (batch_plan.h): first block within the row, blocks of the tile in this row, lanes >= s start the next row
   kbytes_t tables; // the plane's OwnTables
   __device__ __forceinline__ uint32_t bpr() const { return d[8]; }
-  __device__ __forceinline__ uint32_t has_lut() const { return d[14]; }
+  __device__ __forceinline__ uint32_t has_lut() const { return d[14] & kDescLut; }
   __device__ __forceinline__ uint64_t from() const { return ((uint64_t)d[1] << 32) | d[0]; }
   __device__ __forceinline__ uint64_t to() const { return ((uint64_t)d[3] << 32) | d[2]; }
   __device__ __forceinline__ size_t pitch_in() const { return ((uint64_t)d[5] << 32) | d[4]; }
   __device__ __forceinline__ size_t pitch_out() const { return ((uint64_t)d[7] << 32) | d[6]; }
 };
+template <bool PAIRS = false> // PAIRS: the kernel handles kDescPaired planes (k_u8_batch, k_q32_batch)
 __device__ __forceinline__ BatchTile batch_tile(uint32_t w)
 {
   kbytes_t args = karg_bytes(0);
@@ -1657,8 +1659,17 @@ __device__ __forceinline__ BatchTile batch_tile(uint32_t w)
   BatchTile t;
   t.d = *(const __attribute__((address_space(4))) u32x16_s *)dp;
   const uint32_t lt = w - t.d[12];
-  t.row = magic_apply(lt, t.d[10], t.d[11]);
-  t.tile = lt - t.row * t.d[9];
+  if constexpr (PAIRS)
+  {
+    const BatchPos at = batch_pos(lt, t.d[8], t.d[9], t.d[10], t.d[11], t.d[14], t.d[15]);
+    t.row = at.row, t.b0 = at.b0, t.s = at.s, t.straddle = at.straddle, t.tile = at.b0 >> 6;
+  }
+  else
+  {
+    t.row = magic_apply(lt, t.d[10], t.d[11]);
+    t.tile = lt - t.row * t.d[9];
+    t.b0 = t.tile * 64, t.s = 64, t.straddle = 0; // (unused by the kernels that call this form)
+  }
   t.tables = tables + t.d[13];
   return t;
 }
@@ -1716,14 +1727,16 @@ __device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t v)
 // planes in one launch.  The int16 side is a plane of 16-byte rows per lane (a tile row = 1 KiB), pitch in elements.
 enum { U8_RT = 0, U8_FWD = 1, U8_INV = 2 };
 template <int MODE, bool SAT, int FIN, bool PRIO>
-__device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_magic, const f32x2 lo_hi, const void *src, void *dst, size_t pitch_in, size_t pitch_out, uint32_t lane, kbytes_t tbp)
+// in_off / out_off: the lane's byte offset from src / dst (lane * bytes per block row, plus the hop to the next block row for the upper lanes of a
+// straddling tile of a paired plane)
+__device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_magic, const f32x2 lo_hi, const void *src, void *dst, size_t pitch_in, size_t pitch_out, uint32_t in_off, uint32_t out_off, kbytes_t tbp)
 {
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
   f32x2 P[4][8];
   if constexpr (MODE != U8_INV)
   {
     uint2 rows[8];
-    load_block_rows_g(static_cast<const uint8_t *>(src), pitch_in, lane * 8, rows);
+    load_block_rows_g(static_cast<const uint8_t *>(src), pitch_in, in_off, rows);
     MDCT_PHASE_PRIO(1);
 #pragma unroll
     for (int r = 0; r < 8; r++)
@@ -1735,7 +1748,7 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
   }
   else
   { // coefficient row v of the block: (c0,c1)(c2,c3)(c4,c5)(c6,c7) in four dwords -> the pairs the column pass works on, (v, A[j]) / (v, B[j])
-    const RowsTiled in{static_cast<const int16_t *>(src), nullptr, pitch_in, 0, lane * 16};
+    const RowsTiled in{static_cast<const int16_t *>(src), nullptr, pitch_in, 0, in_off};
     uint4 rows[8];
 #pragma unroll
     for (int v = 0; v < 8; v++)
@@ -1792,7 +1805,7 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
   MDCT_PHASE_PRIO(3);
   if constexpr (MODE == U8_FWD)
   {
-    const RowsTiled out{nullptr, static_cast<int16_t *>(dst), 0, pitch_out, lane * 16};
+    const RowsTiled out{nullptr, static_cast<int16_t *>(dst), 0, pitch_out, out_off};
 #pragma unroll
     for (int v = 0; v < 8; v++)
       out.st(v, pack_lo16(__float_as_uint(P[0][v].x), __float_as_uint(P[3][v].x)), pack_lo16(__float_as_uint(P[1][v].x), __float_as_uint(P[2][v].y)),
@@ -1829,7 +1842,7 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
       w1 = pack4_lo8(__float_as_uint(b43.x), __float_as_uint(b25.y), __float_as_uint(b16.y), __float_as_uint(b07.y));
     }
     const u32x2_unaligned_g w = {w0, w1};
-    __builtin_nontemporal_store(w, reinterpret_cast<u32x2_unaligned_g __attribute__((address_space(1))) *>(sgpr_ptr(static_cast<uint8_t *>(dst) + (size_t)r * pitch_out) + lane * 8));
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x2_unaligned_g __attribute__((address_space(1))) *>(sgpr_ptr(static_cast<uint8_t *>(dst) + (size_t)r * pitch_out) + out_off));
   }
 }
 
@@ -1848,16 +1861,21 @@ template <int MODE, bool GENERAL, bool SMALL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT_U8B_WAVES_SMALL : MDCT_U8B_WAVES, SMALL ? MDCT_U8B_WAVES_SMALL : MDCT_U8B_WAVES))) void k_u8_batch(BatchArgs a)
 {
   static_assert(MODE != U8_INV || GENERAL, "the inverse clamps its output");
-  const BatchTile t = batch_tile(blockIdx.x);
-  if (t.tile * 64 + threadIdx.x >= t.bpr())
+  const BatchTile t = batch_tile<true>(blockIdx.x);
+  const uint32_t lane = threadIdx.x;
+  if (!t.straddle && lane >= t.s) // (wave-uniform first: a partial last tile drops its lanes)
     return;
   const size_t pin = t.pitch_in(), pout = t.pitch_out();
   const f32x2 shift_magic = {a.px[0], a.px[1]}, lo_hi = {a.px[2], a.px[3]};
-  // a tile = 64 blocks of one block row: 512 bytes of every pixel row, 512 elements of every coefficient row
-  constexpr size_t in_el = MODE == U8_INV ? 2 : 1, out_el = MODE == U8_FWD ? 2 : 1;
-  const char *src = (const char *)t.from() + ((size_t)t.row * 8 * pin + (size_t)t.tile * 512) * in_el;
-  char *dst = (char *)t.to() + ((size_t)t.row * 8 * pout + (size_t)t.tile * 512) * out_el;
-  u8_rows<MODE, GENERAL, (GENERAL || MODE != U8_RT) ? FIN_CLAMP : FIN_SATPK, MDCT_U8B_PRIO>(a.consts, shift_magic, lo_hi, src, dst, pin, pout, threadIdx.x, t.tables);
+  // a tile = 64 blocks of one block row: 512 bytes of every pixel row, 512 elements of every coefficient row; in a paired plane's straddling
+  // tile the lanes >= s continue at block 0 of the next block row: 8 rows down and b0 + s = bpr blocks back
+  constexpr uint32_t in_el = MODE == U8_INV ? 2 : 1, out_el = MODE == U8_FWD ? 2 : 1;
+  const char *src = (const char *)t.from() + ((size_t)t.row * 8 * pin + (size_t)t.b0 * 8) * in_el;
+  char *dst = (char *)t.to() + ((size_t)t.row * 8 * pout + (size_t)t.b0 * 8) * out_el;
+  const uint32_t hop = (t.straddle && lane >= t.s) ? 0xFFFFFFFFu : 0u;
+  const uint32_t hop_in = ((uint32_t)pin - t.bpr()) * (8 * in_el), hop_out = ((uint32_t)pout - t.bpr()) * (8 * out_el);
+  u8_rows<MODE, GENERAL, (GENERAL || MODE != U8_RT) ? FIN_CLAMP : FIN_SATPK, MDCT_U8B_PRIO>(a.consts, shift_magic, lo_hi, src, dst, pin, pout, lane * (8 * in_el) + (hop & hop_in),
+                                                                                           lane * (8 * out_el) + (hop & hop_out), t.tables);
 }
 
 // The reference's primary product (B1, simd_dct.cpp:2064-2262: k_q32_tile above) on a plane batch: any list of separately allocated 8-bit planes,
@@ -1876,14 +1894,16 @@ template <bool SAFE>
 __global__ MDCT_Q32B_ATTR void k_q32_batch(BatchArgs a)
 {
   __shared__ __attribute__((aligned(16))) uint8_t wl[64 * kQ32RowStride];
-  const BatchTile t = batch_tile(blockIdx.x);
+  const BatchTile t = batch_tile<true>(blockIdx.x);
   const uint32_t lane = threadIdx.x;
-  const uint32_t nb = min(64u, t.bpr() - t.tile * 64); // blocks of this tile, a multiple of 8
+  const uint32_t nb = t.straddle ? 64u : t.s; // blocks of this tile, a multiple of 8 (t.s: those in block row t.row, a multiple of 16 when the tile straddles)
   const size_t pin = t.pitch_in(), pout = t.pitch_out();
   uint32_t q[64];
   {
     uint2 rows[8];
-    load_block_rows_g((const uint8_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.tile * 512, pin, min(lane, nb - 1) * 8, rows);
+    // a paired plane's straddling tile: lanes >= s continue at block 0 of the next block row, 8 pixel rows down and bpr blocks back
+    const uint32_t hop = (t.straddle && lane >= t.s) ? ((uint32_t)pin - t.bpr()) * 8 : 0u;
+    load_block_rows_g((const uint8_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.b0 * 8, pin, min(lane, nb - 1) * 8 + hop, rows);
     encode_block_avx_pk_t<SAFE>(reinterpret_cast<const PkConsts &>(a.pk), rows, (karg_pairs_t)t.tables, q);
   }
 #pragma unroll
@@ -1893,7 +1913,8 @@ __global__ MDCT_Q32B_ATTR void k_q32_batch(BatchArgs a)
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // the tile's (up to) 4 KiB of output: store k, lane l -> coefficients c2 = 2 (l & 31), c2 + 1 of group 2k + (l >> 5) at group * 512 + c2 * 8
-  const gptr_t outw = sgpr_ptr((uint8_t *)t.to() + (size_t)t.row * pout + (size_t)t.tile * 4096);
+  // (store k = the 16 blocks 16k .. 16k + 15: wholly in row t.row or -- straddling tile, s a multiple of 16 -- wholly in the next one, whose strip starts pout further)
+  uint8_t *const strip = (uint8_t *)t.to() + (size_t)t.row * pout + (size_t)t.b0 * 64;
   const uint32_t rd = (lane & 31) * (2 * kQ32RowStride) + (lane >> 5) * 8;
 #pragma unroll
   for (int k = 0; k < 4; k++)
@@ -1904,6 +1925,7 @@ __global__ MDCT_Q32B_ATTR void k_q32_batch(BatchArgs a)
       u32x4_g v = {lo.x, lo.y, hi.x, hi.y};
       if constexpr (!SAFE)
         v = ~v; // the fast quantiser staged complemented bytes (encode_block_avx_pk)
+      const gptr_t outw = sgpr_ptr((t.straddle && 16u * k >= t.s) ? strip + pout - (size_t)t.bpr() * 64 : strip);
       store16_g(outw + k * 1024 + lane * 16, v);
     }
 }

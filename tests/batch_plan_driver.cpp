@@ -69,24 +69,37 @@ static std::vector<mdct_plane_i16> make_planes(const std::vector<Shape> &shapes)
   return v;
 }
 
-// every tile of every plane exactly once, in plane order; returns the launch's tile count
-static uint32_t walk(const BatchLayout &lay, const std::vector<mdct_plane_i16> &planes)
+// every BLOCK of every plane by exactly one lane of exactly one tile, in plane order; returns the launch's tile count.
+// (block coverage rather than tile coverage: a paired plane's middle tile covers blocks of two rows.)
+template <class Plane>
+static uint32_t walk(const BatchLayout &lay, const std::vector<Plane> &planes)
 {
   std::vector<std::vector<unsigned char>> seen(lay.descs.size());
   for (size_t k = 0; k < lay.descs.size(); k++)
-    seen[k].assign((size_t)lay.descs[k].tiles * lay.descs[k].rows, 0);
+    seen[k].assign((size_t)lay.descs[k].bpr * lay.descs[k].rows, 0);
+  uint32_t last_p = 0;
   for (uint32_t w = 0; w < lay.total; w++)
   {
     const BatchWhere at = batch_locate(lay.descs.data(), (uint32_t)lay.descs.size(), lay.uniform, lay.pp, lay.first8, w);
-    CHECK(at.p < lay.descs.size());
+    CHECK(at.p < lay.descs.size() && at.p >= last_p);
+    last_p = at.p;
     const BatchDesc &d = lay.descs[at.p];
-    CHECK(at.row < d.rows && at.tile < d.tiles);
-    unsigned char &s = seen[at.p][(size_t)at.row * d.tiles + at.tile];
-    CHECK(s == 0);
-    s = 1;
-    const mdct_plane_i16 &pl = planes[lay.plane[at.p]];
+    const bool paired = (d.has_lut & kDescPaired) != 0;
+    CHECK(at.row < d.rows && at.pos.b0 < d.bpr && at.pos.s >= 1 && at.pos.s <= 64 && at.pos.b0 + at.pos.s <= d.bpr);
+    CHECK(at.pos.b0 % 64 == 0 || paired);
+    CHECK(!at.pos.straddle || (paired && at.pos.s % 16 == 0 && at.pos.b0 + at.pos.s == d.bpr && at.row + 1 < d.rows)); // what k_q32_batch's stores rely on
+    CHECK(at.pos.s == 64 || at.pos.b0 + at.pos.s == d.bpr);
+    for (uint32_t lane = 0; lane < (at.pos.straddle ? 64u : at.pos.s); lane++)
+    { // the lane's block as the kernels address it
+      const uint32_t row = lane < at.pos.s ? at.row : at.row + 1, bx = lane < at.pos.s ? at.pos.b0 + lane : lane - at.pos.s;
+      CHECK(row < d.rows && bx < d.bpr);
+      unsigned char &s = seen[at.p][(size_t)row * d.bpr + bx];
+      CHECK(s == 0);
+      s = 1;
+    }
+    const Plane &pl = planes[lay.plane[at.p]];
     CHECK(d.from == pl.from && d.to == pl.to && d.pitch_in == pl.pitch_in && d.pitch_out == pl.pitch_out && d.bpr == pl.sizeX / 8 && d.rows == pl.sizeY / 8);
-    CHECK(d.tiles == (d.bpr + 63) / 64);
+    CHECK(d.tiles == (paired ? d.bpr / 32 : (d.bpr + 63) / 64));
   }
   for (auto &v : seen)
     for (unsigned char s : v)
@@ -199,6 +212,57 @@ int main()
       const BatchWhere at = batch_locate(lay.descs.data(), 3, lay.uniform, lay.pp, lay.first8, w0);
       CHECK(at.p == (w0 < 8100 ? 0u : (w0 < 10260 ? 1u : 2u)) && at.tile < lay.descs[at.p].tiles && at.row < lay.descs[at.p].rows);
     }
+  }
+  { // paired rows (k_u8_batch, k_q32_batch): the 8K 4:2:0 frame takes 12,150 tiles instead of 12,420; odd row counts leave a single last row;
+    // planes that do not end in half a tile, single-row planes and huge pitches stay unpaired; equal paired planes are still `uniform`
+    std::vector<mdct_plane_u8> planes(3);
+    const size_t w[3] = {7680, 3840, 3840}, h[3] = {4320, 2160, 2160};
+    for (int i = 0; i < 3; i++)
+      planes[i] = mdct_plane_u8{reinterpret_cast<const uint8_t *>((uintptr_t)0x1000 * (i + 1)), reinterpret_cast<uint8_t *>((uintptr_t)0x100000 * (i + 1)), w[i] + 16, w[i], w[i], h[i], nullptr};
+    const int ids[] = {0, 1, 1};
+    const unsigned char has[] = {1, 1, 1};
+    BatchLayout lay;
+    batch_layout(planes.data(), ids, has, 0, 3, 3584, 512, lay, true);
+    CHECK(lay.consumed == 3 && lay.total == 15u * 540 + 2 * 15u * 135 && lay.total == 12150u && !lay.uniform);
+    CHECK(!(lay.descs[0].has_lut & kDescPaired) && (lay.descs[1].has_lut & kDescPaired) && (lay.descs[1].has_lut & kDescLut) && lay.descs[1].tiles == 15);
+    CHECK(walk(lay, planes) == 12150u);
+    std::mt19937 rng(11);
+    for (int n : {1, 2, 5, 8, 9, 20})
+    {
+      std::vector<mdct_plane_u8> ps;
+      std::vector<int> id;
+      std::vector<unsigned char> hs;
+      int expect_paired = 0;
+      for (int i = 0; i < n; i++)
+      {
+        const size_t bpr = (i % 3 == 0) ? 32 + 64 * (rng() % 6) : 1 + rng() % 300, rows = 1 + rng() % 9;
+        const size_t pitch = (i % 7 == 6) ? ((size_t)1 << 26) : bpr * 8 + 8 * (rng() % 3);
+        ps.push_back(mdct_plane_u8{reinterpret_cast<const uint8_t *>((uintptr_t)0x10000 * (i + 1)), reinterpret_cast<uint8_t *>((uintptr_t)0x1000000 * (i + 1)), pitch, pitch, bpr * 8, rows * 8, nullptr});
+        id.push_back(i % 2);
+        hs.push_back(1);
+        expect_paired += (bpr % 64 == 32 && rows >= 2 && pitch < ((size_t)1 << 26)) ? 1 : 0;
+      }
+      BatchLayout l2;
+      batch_layout(ps.data(), id.data(), hs.data(), 0, n, 0, 512, l2, true);
+      CHECK(l2.consumed == n);
+      int got_paired = 0;
+      for (auto &d : l2.descs)
+        got_paired += (d.has_lut & kDescPaired) ? 1 : 0;
+      CHECK(got_paired == expect_paired);
+      walk(l2, ps);
+      BatchLayout l3; // the same planes for a kernel that does not pair: one tile grid per row, as before
+      batch_layout(ps.data(), id.data(), hs.data(), 0, n, 0, 512, l3);
+      for (auto &d : l3.descs)
+        CHECK(!(d.has_lut & kDescPaired) && d.tiles == (d.bpr + 63) / 64);
+      walk(l3, ps);
+      CHECK(l3.total >= l2.total);
+    }
+    std::vector<mdct_plane_u8> same(6, mdct_plane_u8{reinterpret_cast<const uint8_t *>((uintptr_t)0x10000), reinterpret_cast<uint8_t *>((uintptr_t)0x1000000), 3840, 3840, 3840, 8 * 7, nullptr});
+    const int ids6[] = {0, 0, 0, 0, 0, 0};
+    const unsigned char has6[] = {1, 1, 1, 1, 1, 1};
+    batch_layout(same.data(), ids6, has6, 0, 6, 0, 512, lay, true);
+    CHECK(lay.uniform && lay.per_plane == 3u * 15 + 8 && lay.total == 6u * 53);
+    walk(lay, same);
   }
   puts("batch plan ok");
   return 0;

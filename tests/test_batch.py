@@ -46,7 +46,9 @@ def test_kernel_and_host_share_the_layout_header():
     kern = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "mdct_kernels.hip")).read()
     assert "batch_plane_of(w, n, uniform" in kern and kern.count("magic_apply(") >= 1
     assert "magic_quot" not in kern and "__umulhi" not in kern  # no device-side restatement of the division or of the search
-    assert kern.count("batch_tile(blockIdx.x)") == 3  # k_i16_batch, k_u8_batch and k_q32_batch: every batch kernel finds its tile through it
+    # k_i16_batch, and -- in the form that also understands paired rows (batch_pos, the same header) -- k_u8_batch and k_q32_batch: every batch kernel finds its tile through it
+    assert kern.count("batch_tile(blockIdx.x)") == 1 and kern.count("batch_tile<true>(blockIdx.x)") == 2 and "batch_pos(lt, t.d[8]" in kern
+    assert "MDCT_HD BatchPos batch_pos(" in hdr
     api_src = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "mdct_api.hip")).read()
     assert "mdct::batch_layout(" in api_src
 

@@ -76,11 +76,12 @@ def _check(srcs, d_out, shapes, luts, what):
 @gpu
 def test_q32_batch_equals_the_checker_and_the_single_plane_call(cuda):
     torch = cuda
-    shapes = [(1920, 32), (64, 8), (3840, 16), (512, 24), (4160, 8), (128, 40), (7680, 8)]
+    # (3840 x 16, 256 x 24, 768 x 40: rows that end in half a tile -- tiled over PAIRS of block rows, kDescPaired, the odd last row alone)
+    shapes = [(1920, 32), (64, 8), (3840, 16), (512, 24), (4160, 8), (128, 40), (7680, 8), (256, 24), (768, 40)]
     wild = np.full(64, 1e-4, dtype=np.float32)  # 255 / (lut * 0.95) beyond 2^17: the exact-convert build for the whole call
     wild[5] = np.float32(np.inf)
-    for luts, pad_in, pad_out in (([_lut(2000)] * 7, 0, 0), ([_lut(2000), _lut(8), _lut(100), -_lut(40), _lut(2000), _lut(1e5), _lut(0.9)], 24, 64),
-                                  ([_lut(2000), wild, _lut(8), _lut(100), wild, _lut(3), _lut(2000)], 8, 16)):
+    for luts, pad_in, pad_out in (([_lut(2000)] * 9, 0, 0), ([_lut(2000), _lut(8), _lut(100), -_lut(40), _lut(2000), _lut(1e5), _lut(0.9), _lut(8), _lut(300)], 24, 64),
+                                  ([_lut(2000), wild, _lut(8), _lut(100), wild, _lut(3), _lut(2000), wild, _lut(50)], 8, 16)):
         for form in ("args", "device"):
             srcs, d_in, d_out, desc = _planes(torch, shapes, luts, pad_in, pad_out, seed0=70)
             if form == "args":

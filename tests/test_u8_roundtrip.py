@@ -218,7 +218,8 @@ def test_u8_batch_mixed_shapes_and_tables(cuda):
     one argument block"""
     torch = cuda
     T = _tables()
-    shapes = [(1920, 64), (8, 8), (72, 24), (520, 16), (512, 8), (200, 40), (3840, 16), (1024, 32)]
+    # (3840 x 16, 256 x 24, 768 x 40: rows ending in half a tile -- k_u8_batch tiles them over pairs of block rows, the odd last row alone)
+    shapes = [(1920, 64), (8, 8), (72, 24), (520, 16), (256, 24), (200, 40), (3840, 16), (768, 40)]
     for luts, pad, shift in (([None] * 8, 0, True), ([JPEG_LUMA, JPEG_CHROMA, JPEG_CHROMA, None, JPEG_LUMA, _lut(10), None, T["edge"]], 24, True),
                              ([JPEG_LUMA, T["tiny"], JPEG_CHROMA, T["huge"], None, T["mixed"], JPEG_LUMA, JPEG_LUMA], 8, False)):
         for form in ("args", "device"):
@@ -389,7 +390,7 @@ def test_u8_i16_batches_equal_the_single_plane_calls_and_the_oracle(cuda):
 
     torch = cuda
     T = _tables()
-    shapes = [(1920, 32), (8, 8), (72, 24), (520, 16), (512, 8), (200, 40), (3840, 16)]
+    shapes = [(1920, 32), (8, 8), (72, 24), (520, 16), (256, 24), (768, 40), (3840, 16)]  # the last three: paired rows (kDescPaired)
     rng = np.random.default_rng(8)
     for luts, pad, shift in (([None] * 7, 0, True), ([JPEG_LUMA, JPEG_CHROMA, JPEG_CHROMA, None, T["tiny"], _lut(10), T["mixed"]], 16, True), ([T["huge"], JPEG_LUMA, T["ones"], T["sixteenth"], None, T["negative"], T["edge"]], 8, False)):
         for form in ("args", "device"):
