@@ -401,7 +401,8 @@ enum
   MDCT_TABLE_STAT_EVICTIONS = 2,      /* uploads that replaced the least recently used table */
   MDCT_TABLE_STAT_FROM_ARGUMENTS = 3, /* tables that travelled in the kernel arguments instead (capturing stream, no free slot, failure) */
   MDCT_TABLE_STAT_STREAM_WAITS = 4,   /* hipStreamWaitEvent on another stream's upload still in flight */
-  MDCT_TABLE_STAT_COUNT = 5
+  MDCT_TABLE_STAT_UNFENCEABLE = 5,    /* eviction candidates passed over because a reader stream could not be fenced (destroyed stream, > 64 streams) */
+  MDCT_TABLE_STAT_COUNT = 6
 };
 int mdct_table_cache_stats(uint64_t *stats, int n);
 

@@ -111,6 +111,16 @@ int mdct_shim_warmup(size_t plane_bytes);
  * buffers with memcpy.  Unpin before freeing it.  Returns 0 / 1 / 2 like every entry point. */
 int mdct_shim_pin(void *p, size_t bytes);
 int mdct_shim_unpin(void *p);
+/* The same without a source change -- OPT-IN through the environment, read once per process:
+ *   MDCT_SHIM_AUTOPIN=1        a host plane passed to the three functions for the THIRD time (same base pointer; the longest extent a
+ *                              call has touched) is page-locked in place by the shim and DMA'd from / to directly from then on: what the
+ *                              reference's harness needs, which reuses its two buffers for every run (main.cpp:510-523).  At most 16
+ *                              ranges per process, least recently used released first; all released by mdct_shim_release(), by a calling
+ *                              thread's exit and at process exit.  THE CALLER'S PART OF THE BARGAIN: a buffer it has passed three times is
+ *                              not freed before one of those -- a range freed and re-allocated at the same address while registered would be
+ *                              read / written through its old pages.  That is why this is not the default.
+ *   MDCT_SHIM_EVENT_WAIT=block the host threads of the pipeline sleep in their event waits (hipEventBlockingSync) instead of spinning:
+ *                              frees up to 3-4 cores per calling thread, costs 5-12 % of the call (profiles/r06_host_pointer_*_ab.log). */
 /* C-linkage handle onto the three C++-linkage functions above for FFI callers that cannot
  * spell mangled names (ctypes, cgo, JNI).  which: 0 = ...32ReorderBuffer (simd_dct.h:31),
  * 1 = ...ReorderStereoBuffer (simd_dct.h:30), 2 = ...EncodeQuantizeBuffer (simd_dct.h:29).

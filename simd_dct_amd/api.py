@@ -619,9 +619,9 @@ def prepare_roundtrip_u8(src, dst, sizeX, sizeY, lut=None, level_shift=True, str
 
 def table_cache_stats():
     """mdct_table_cache_stats of the current device: dict of the MDCT_TABLE_STAT_* counters"""
-    a = (ctypes.c_uint64 * 5)()
-    _check(_lib.load().mdct_table_cache_stats(a, 5))
-    return dict(zip(("hits", "uploads", "evictions", "from_arguments", "stream_waits"), [int(v) for v in a]))
+    a = (ctypes.c_uint64 * 6)()
+    _check(_lib.load().mdct_table_cache_stats(a, 6))
+    return dict(zip(("hits", "uploads", "evictions", "from_arguments", "stream_waits", "unfenceable"), [int(v) for v in a]))
 
 
 def clock_probe(out, ticks_100MHz, waves=8, stream=None):

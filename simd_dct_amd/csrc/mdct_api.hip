@@ -419,17 +419,22 @@ TableRef table_acquire(int device, const mdct::OwnTables &tb, hipStream_t stream
       if (slot_quiesce_for(c, c.slots[v], stream))
         k = v;
       else
+      { // a reader that cannot be fenced any more (its stream was destroyed, or more streams than the cache tracks): the slot stays
         (void)hipGetLastError();
+        c.stat[MDCT_TABLE_STAT_UNFENCEABLE]++;
+      }
     }
   }
   if (k < 0 || mdct::launch_park_table(tb, c.dev + k, stream) != hipSuccess)
   { // nothing was overwritten: every slot keeps what it held
     (void)hipGetLastError();
     c.stat[MDCT_TABLE_STAT_FROM_ARGUMENTS]++;
-    if (k >= 0 && !c.slots[k].used)
+    if ((k >= 0 && !c.slots[k].used) || k == -2)
+    { // the slot appended above never held a table: give its event back with it
+      if (c.slots.back().ready)
+        (void)hipEventDestroy(c.slots.back().ready);
       c.slots.pop_back();
-    else if (k == -2)
-      c.slots.pop_back();
+    }
     return TableRef();
   }
   TableSlot &sl = c.slots[k];
@@ -474,14 +479,11 @@ void table_release(const TableRef &r, hipStream_t stream, bool launched = true)
   std::lock_guard<std::mutex> lk(c.mu);
   TableSlot &sl = c.slots[r.slot];
   sl.pins--;
-  if (!launched || sl.n_readers > kSlotStreams)
+  if (!launched)
     return;
-  for (int i = 0; i < sl.n_readers; i++)
-    if (sl.readers[i] == stream)
-      return;
-  if (sl.n_readers < kSlotStreams)
-    sl.readers[sl.n_readers] = stream;
-  sl.n_readers++;
+  // The cache-wide list FIRST, for every launched read: a slot with more than kSlotStreams readers is fenced against this list, so a
+  // stream whose reads only ever met such slots must be on it too (round 5 returned before this for many-reader slots: a 6th stream
+  // could stay unknown to the cache and an evicting upload could overwrite a table its queued kernels were still reading).
   bool seen = false;
   for (int i = 0; i < c.n_known && !seen; i++)
     seen = c.known[i] == stream;
@@ -492,6 +494,14 @@ void table_release(const TableRef &r, hipStream_t stream, bool launched = true)
     else
       c.known_overflow = true; // slots with many readers stop being victims: 64 streams sharing tables is not this cache's case
   }
+  if (sl.n_readers > kSlotStreams)
+    return;
+  for (int i = 0; i < sl.n_readers; i++)
+    if (sl.readers[i] == stream)
+      return;
+  if (sl.n_readers < kSlotStreams)
+    sl.readers[sl.n_readers] = stream;
+  sl.n_readers++;
 }
 
 int run_i16(int mode, const int16_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream)
@@ -724,6 +734,12 @@ int batch_input(int mode, const Plane *planes, int n, BatchInput &in)
         return fail(MDCT_NOT_SUPPORTED, "plane %zux%zu: width must be a multiple of 64 and height of 8 for the q32 layout", p.sizeX, p.sizeY);
       if (p.pitch_out < 8 * p.sizeX || p.pitch_out % 16 != 0)
         return fail(MDCT_INVALID_PARAMETER, "output strip pitch %zu must be >= 8*sizeX = %zu and a multiple of 16", p.pitch_out, 8 * p.sizeX);
+      // NOT in place (the reference's product is not either: a group's 512 output bytes land over pixels other blocks have not read yet,
+      // simd_dct.cpp:2227-2230 against :2103-2110 -- SURVEY.md 8b): an output strip range that meets the plane's own input is refused
+      const uintptr_t in0 = (uintptr_t)p.from, in1 = in0 + (p.sizeY ? (p.sizeY - 1) * p.pitch_in + p.sizeX : 0);
+      const uintptr_t out0 = (uintptr_t)p.to, out1 = out0 + (p.sizeY >= 8 ? (p.sizeY / 8 - 1) * p.pitch_out + 8 * p.sizeX : 0);
+      if (in0 < out1 && out0 < in1)
+        return fail(MDCT_INVALID_PARAMETER, "plane %d: the q32 product cannot be written over its own input (to overlaps from)", i);
       float q[64];
       q32_pair_table(p.lut, false, q);
       q32_safe = q32_safe || table_needs_safe(q);

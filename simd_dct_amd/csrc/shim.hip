@@ -81,6 +81,42 @@ struct HipDev
     return hipMemcpy2DAsync(host, dpitch, dev, spitch, width, height, hipMemcpyDeviceToHost, s) == hipSuccess;
   }
   int launch(size_t r0, size_t r1, hipStream_t s) { return mdct_fwd_quant_u8(d_in, d_out, sizeX, lut, sizeX, sizeY, r0, r1, layout, profile, s); }
+  bool host_register(void *p, size_t n)
+  {
+    if (hipHostRegister(p, n, hipHostRegisterDefault) == hipSuccess)
+      return true;
+    (void)hipGetLastError();
+    return false;
+  }
+  bool host_unregister(void *p)
+  {
+    if (hipHostUnregister(p) == hipSuccess)
+      return true;
+    (void)hipGetLastError(); // (at process exit the runtime may already be gone)
+    return false;
+  }
+};
+
+// MDCT_SHIM_AUTOPIN=1 (read once): host buffers a caller passes again and again are page-locked in place from their third sighting on
+// (shim_host.h: AutoPin; INTEGRATION.md 1 has the caller's side of the bargain).  Off by default: behaviour unchanged.
+mdct_host::AutoPin<HipDev> g_autopin;
+bool autopin_enabled()
+{
+  static const bool on = [] {
+    const char *e = getenv("MDCT_SHIM_AUTOPIN");
+    return e && e[0] && e[0] != '0';
+  }();
+  return on;
+}
+thread_local bool tl_autopin_off = false; // mdct_shim_warmup's scratch planes are freed right after their calls: never registered
+struct AutoPinHold
+{ // the registrations a call relies on stay until it returns
+  int in = -1, out = -1;
+  ~AutoPinHold()
+  {
+    g_autopin.leave(in);
+    g_autopin.leave(out);
+  }
 };
 
 constexpr int kSlots = mdct_host::kPipeSlots;
@@ -103,6 +139,8 @@ struct Staging
   {
     pool_in.shutdown(); // before their streams, events and buffers go
     pool_out.shutdown();
+    if (autopin_enabled())
+      (void)g_autopin.release_all(hip); // (ranges a call of another thread relies on right now stay until that thread lets go)
     // errors are ignored on purpose: at process exit the runtime may already be shutting down
     if (in)
       (void)hipFree(in);
@@ -143,9 +181,15 @@ bool reserve_pipeline(Staging &s, size_t chunk_bytes)
   for (int i = 0; i < 3; i++)
     if (!s.stream[i] && hipStreamCreateWithFlags(&s.stream[i], hipStreamNonBlocking) != hipSuccess)
       return false;
+  // e_in / e_out are waited for by HOST threads (the caller, the output helpers): MDCT_SHIM_EVENT_WAIT=block makes those waits sleep
+  // (hipEventBlockingSync) instead of spinning on a core each -- see INTEGRATION.md 1 for what either costs
+  static const unsigned host_wait = [] {
+    const char *e = getenv("MDCT_SHIM_EVENT_WAIT");
+    return (e && e[0] == 'b') ? (unsigned)hipEventBlockingSync : 0u;
+  }();
   for (int i = 0; i < kSlots; i++)
     for (hipEvent_t *e : {&s.e_in[i], &s.e_k[i], &s.e_out[i]})
-      if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess)
+      if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming | (e == &s.e_k[i] ? 0u : host_wait)) != hipSuccess)
       {
         *e = nullptr;
         (void)hipGetLastError();
@@ -267,9 +311,17 @@ simdDctResult run(const uint8_t *pFrom, uint8_t *pTo, const float *lut, size_t s
   //                 64 bytes behind the last row -- follows the last chunk
   //   STEREO        a row covers 8 pixel rows of BOTH stacked images (2 pieces, half a plane apart) and 2 * bpr bytes of each of the 64
   //                 coefficient planes (64 pieces, sizeX * sizeY / 64 apart): one 2-D copy each way per chunk
+  AutoPinHold hold; // (function scope: also the plain path below may be copying from / to a range it registered)
   if (!dev_in && !dev_out)
   {
     const bool half_pairs = layout == MDCT_LAYOUT_BLOCK_SSE, stereo = layout == MDCT_LAYOUT_STEREO;
+    if (autopin_enabled() && !tl_autopin_off)
+    { // the bytes of each plane this call can touch, from the plane's base: what gets page-locked on the third sighting
+      const size_t reach_io = stereo ? total : b1 * strip;
+      hold.in = g_autopin.enter(st.hip, pFrom, reach_io);
+      if (!half_pairs) // (the SSE encq tier's output always goes through the bounce buffers: only half of its bytes are the tier's)
+        hold.out = g_autopin.enter(st.hip, pTo, reach_io);
+    }
     const bool pinned_in = classify(pFrom) == PTR_PINNED, pinned_out = !half_pairs && classify(pTo) == PTR_PINNED;
     const mdct_host::Pieces pin{stereo ? (size_t)2 : (size_t)1, sizeX * sizeY / 2, strip}, pout{stereo ? (size_t)64 : (size_t)1, sizeX * sizeY / 64, stereo ? sizeX / 4 : strip};
     const size_t row_bytes = pin.count * pin.row; // == pout.count * pout.row: a block row moves as many bytes out as in
@@ -479,6 +531,7 @@ int mdct_shim_warmup(size_t plane_bytes)
   {
     const ThreadConfig saved = tl_cfg;
     tl_cfg = ThreadConfig(); // synchronous, null stream
+    tl_autopin_off = true;   // (three sightings of a scratch buffer that is about to be freed must not page-lock it)
     // (run() directly: the tier cap and the reference's flag globals stay untouched; block rows as main.cpp's calls cover them)
     simdDctResult q = run(scratch_in, scratch_out, lut, sx, sy, 0, sy / 16, MDCT_LAYOUT_Q32, MDCT_PROFILE_REF_AVX);
     if (q == sdr_Success)
@@ -486,6 +539,7 @@ int mdct_shim_warmup(size_t plane_bytes)
     if (q == sdr_Success)
       q = run(scratch_in, scratch_out, lut, sx, sy, 0, sy / 16, MDCT_LAYOUT_BLOCK_SSE, MDCT_PROFILE_REF_SSE);
     tl_cfg = saved;
+    tl_autopin_off = false;
     r = (int)q;
   }
   free(scratch_in);

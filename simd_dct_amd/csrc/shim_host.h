@@ -16,6 +16,7 @@
 //   bool h2d_async(uint8_t *dev, const uint8_t *host, size_t n, stream_t);
 //   bool d2h_async(uint8_t *host, const uint8_t *dev, size_t n, stream_t);
 //   int  launch(size_t row0, size_t row1, stream_t);             block rows [row0, row1) dev-in -> dev-out; 0 = ok
+//   bool host_register(void *, size_t); bool host_unregister(void *);   (AutoPin only) page-lock / release a range of the caller's memory
 #ifndef MDCT_SHIM_HOST_H
 #define MDCT_SHIM_HOST_H
 
@@ -27,6 +28,7 @@
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 namespace mdct_host
 {
@@ -68,6 +70,134 @@ inline int level_from_flags(int set_level, const bool *sse2, const bool *ssse3, 
   }
   return LEVEL_AVX2;
 }
+
+// Opt-in auto-pinning (MDCT_SHIM_AUTOPIN=1; shim.hip).  A caller like the reference's harness hands the SAME two pageable buffers to every
+// call (main.cpp:510-523 reuses them for all --runs): the third time a host range is seen it is page-locked in place (host_register), and
+// from then on the pipeline DMAs straight from / to it instead of going through memcpy and the bounce buffers -- what mdct_shim_pin() does
+// by hand.  One registry per process (calls on disjoint row ranges of one plane come from many threads): at most kRanges ranges, least
+// recently used released first, never one that a running call relies on (`users`); everything is released by release_all() --
+// mdct_shim_release(), a calling thread's exit, process exit.  The caller's side of the bargain (why this is opt-in): a buffer it has passed
+// three times stays allocated until then -- a range that is freed and re-allocated at the same address while registered would be DMA'd
+// through its old pages.
+template <class Dev>
+struct AutoPin
+{
+  static constexpr int kRanges = 16;
+  static constexpr unsigned kThreshold = 3;
+  struct Range
+  {
+    uintptr_t base = 0;
+    size_t len = 0;      // the longest extent a call has touched from `base`
+    size_t pinned_len = 0; // registered bytes (0: not registered)
+    unsigned seen = 0;
+    int users = 0;       // calls between enter() and leave()
+    bool used = false, dead = false; // dead: registering failed once, never tried again
+    uint64_t tick = 0;
+  };
+  std::mutex mu;
+  Range r[kRanges];
+  uint64_t tick = 0;
+  uint64_t registered = 0, unregistered = 0; // counters (tests, diagnostics)
+
+  // A call is about to touch [p, p + len).  Returns a handle >= 0 when the range is page-locked by this registry and will stay so until
+  // leave(handle); -1 otherwise (not seen often enough yet, could not be registered, or overlaps another registered range).
+  int enter(Dev &dev, const void *p, size_t len)
+  {
+    if (p == nullptr || len == 0)
+      return -1;
+    const uintptr_t base = (uintptr_t)p;
+    std::lock_guard<std::mutex> lk(mu);
+    int k = -1;
+    for (int i = 0; i < kRanges && k < 0; i++)
+      if (r[i].used && r[i].base == base)
+        k = i;
+    if (k < 0)
+    { // a free entry, or the least recently used one nobody relies on
+      int v = -1;
+      for (int i = 0; i < kRanges; i++)
+        if (!r[i].used)
+        {
+          v = i;
+          break;
+        }
+        else if (r[i].users == 0 && (v < 0 || r[i].tick < r[v].tick))
+          v = i;
+      if (v < 0)
+        return -1;
+      if (r[v].used && r[v].pinned_len)
+        drop(dev, r[v]);
+      r[v] = Range();
+      r[v].used = true;
+      r[v].base = base;
+      k = v;
+    }
+    Range &e = r[k];
+    e.tick = ++tick;
+    e.seen++;
+    if (len > e.len)
+      e.len = len;
+    if (e.pinned_len >= len)
+    {
+      e.users++;
+      return k;
+    }
+    if (e.dead || e.seen < kThreshold)
+      return -1;
+    if (e.pinned_len)
+    { // registered, but this call reaches further: once nobody relies on the shorter registration, replace it
+      if (e.users)
+        return -1;
+      drop(dev, e);
+    }
+    for (int i = 0; i < kRanges; i++) // (host_register refuses overlapping ranges; so do we, before asking)
+      if (i != k && r[i].used && r[i].pinned_len && r[i].base < base + e.len && base < r[i].base + r[i].pinned_len)
+        return -1;
+    if (!dev.host_register((void *)base, e.len))
+    {
+      e.dead = true;
+      return -1;
+    }
+    registered++;
+    e.pinned_len = e.len;
+    e.users++;
+    return k;
+  }
+  void leave(int handle)
+  {
+    if (handle < 0)
+      return;
+    std::lock_guard<std::mutex> lk(mu);
+    r[handle].users--;
+  }
+  // releases every registration no running call relies on and forgets the sightings; returns the number still held
+  int release_all(Dev &dev)
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    int held = 0;
+    for (int i = 0; i < kRanges; i++)
+    {
+      if (!r[i].used)
+        continue;
+      if (r[i].users)
+      {
+        held++;
+        continue;
+      }
+      if (r[i].pinned_len)
+        drop(dev, r[i]);
+      r[i] = Range();
+    }
+    return held;
+  }
+
+private:
+  void drop(Dev &dev, Range &e)
+  {
+    (void)dev.host_unregister((void *)e.base);
+    unregistered++;
+    e.pinned_len = 0;
+  }
+};
 
 // `count` pieces of `len` bytes, `dpitch` / `spitch` apart; period != 0: of every `period` bytes of a piece only the first `keep` are copied
 // (the SSE encq tier writes the first 64 bytes of every 128-byte block pair, simd_dct.cpp:1662-1676: the rest stays the caller's)

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <functional>
 #include <memory>
+#include <map>
 #include <vector>
 
 #include "shim_host.h"
@@ -478,8 +479,135 @@ static void test_levels()
   puts("tier choice == the dispatchers: ok");
 }
 
+
+// ---- AutoPin (MDCT_SHIM_AUTOPIN): a back end that models the runtime's rule -- ranges may not overlap, only a registered base can be
+// released -- and fails on request
+struct PinDev
+{
+  std::mutex m;
+  std::map<uintptr_t, size_t> live;
+  int fail_next = 0;
+  int registers = 0, unregisters = 0;
+  bool host_register(void *p, size_t n)
+  {
+    std::lock_guard<std::mutex> lk(m);
+    if (fail_next > 0)
+    {
+      fail_next--;
+      return false;
+    }
+    const uintptr_t b = (uintptr_t)p;
+    for (auto &kv : live)
+      CHECK(!(kv.first < b + n && b < kv.first + kv.second)); // AutoPin must never ask for an overlapping range
+    live[b] = n;
+    registers++;
+    return true;
+  }
+  bool host_unregister(void *p)
+  {
+    std::lock_guard<std::mutex> lk(m);
+    CHECK(live.erase((uintptr_t)p) == 1);
+    unregisters++;
+    return true;
+  }
+};
+
+static void test_autopin()
+{
+  typedef AutoPin<PinDev> AP;
+  std::vector<uint8_t> a(1 << 16), b(1 << 16);
+  { // third sighting registers; later calls ride it; a longer reach re-registers once nobody relies on the shorter one
+    PinDev dev;
+    AP ap;
+    CHECK(ap.enter(dev, a.data(), 4096) == -1 && ap.enter(dev, a.data(), 4096) == -1 && dev.registers == 0);
+    const int h = ap.enter(dev, a.data(), 4096);
+    CHECK(h >= 0 && dev.registers == 1 && dev.live.at((uintptr_t)a.data()) == 4096);
+    const int h2 = ap.enter(dev, a.data(), 1000); // shorter: covered
+    CHECK(h2 == h && dev.registers == 1);
+    CHECK(ap.enter(dev, a.data(), 8192) == -1 && dev.registers == 1); // longer while two calls rely on the registration: left alone
+    ap.leave(h);
+    ap.leave(h2);
+    const int h3 = ap.enter(dev, a.data(), 8192);
+    CHECK(h3 >= 0 && dev.registers == 2 && dev.unregisters == 1 && dev.live.at((uintptr_t)a.data()) == 8192);
+    ap.leave(h3);
+    // an overlapping range from another base is never registered
+    for (int i = 0; i < 5; i++)
+      CHECK(ap.enter(dev, a.data() + 4096, 8192) == -1);
+    CHECK(dev.registers == 2);
+    // null / empty
+    CHECK(ap.enter(dev, nullptr, 10) == -1 && ap.enter(dev, a.data(), 0) == -1);
+    CHECK(ap.release_all(dev) == 0 && dev.live.empty() && dev.unregisters == 2);
+    CHECK(ap.enter(dev, a.data(), 64) == -1); // forgotten: three sightings again
+  }
+  { // a failed registration is not retried; release_all keeps what a running call relies on
+    PinDev dev;
+    AP ap;
+    dev.fail_next = 1;
+    for (int i = 0; i < 6; i++)
+      CHECK(ap.enter(dev, a.data(), 4096) == -1);
+    CHECK(dev.registers == 0);
+    int h = -1;
+    for (int i = 0; i < 3; i++)
+      h = ap.enter(dev, b.data(), 4096);
+    CHECK(h >= 0);
+    CHECK(ap.release_all(dev) == 1 && dev.live.size() == 1); // in use
+    ap.leave(h);
+    CHECK(ap.release_all(dev) == 0 && dev.live.empty());
+  }
+  { // more ranges than entries: the least recently used registration goes, never one in use
+    PinDev dev;
+    AP ap;
+    std::vector<std::vector<uint8_t>> bufs(AP::kRanges + 4, std::vector<uint8_t>(256));
+    int held = -1;
+    for (int i = 0; i < 3; i++)
+      held = ap.enter(dev, bufs[0].data(), 256);
+    CHECK(held >= 0); // stays in use throughout
+    for (size_t k = 1; k < bufs.size(); k++)
+      for (int i = 0; i < 3; i++)
+        ap.leave(ap.enter(dev, bufs[k].data(), 256));
+    CHECK(dev.live.count((uintptr_t)bufs[0].data()) == 1 && (int)dev.live.size() <= AP::kRanges && dev.unregisters >= 4);
+    ap.leave(held);
+    CHECK(ap.release_all(dev) == 0 && dev.live.empty() && dev.registers == dev.unregisters);
+  }
+  { // 8 threads on disjoint row ranges of the same two planes (the reference's startY/endY use), a ninth releasing now and then
+    PinDev dev;
+    AP ap;
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> ts;
+    for (int t = 0; t < 8; t++)
+      ts.emplace_back([&, t] {
+        for (int i = 0; i < 400; i++)
+        {
+          const size_t reach = 4096 * (size_t)(t + 1);
+          const int hi = ap.enter(dev, a.data(), reach), ho = ap.enter(dev, b.data(), reach);
+          if (hi >= 0)
+          {
+            std::lock_guard<std::mutex> lk(dev.m);
+            auto it = dev.live.find((uintptr_t)a.data());
+            CHECK(it != dev.live.end() && it->second >= reach); // what the call relies on is really there
+          }
+          ap.leave(hi);
+          ap.leave(ho);
+        }
+      });
+    std::thread rel([&] {
+      while (!stop)
+      {
+        (void)ap.release_all(dev);
+        std::this_thread::yield();
+      }
+    });
+    for (auto &t : ts)
+      t.join();
+    stop = true;
+    rel.join();
+    CHECK(ap.release_all(dev) == 0 && dev.live.empty() && dev.registers == dev.unregisters);
+  }
+}
+
 int main()
 {
+  test_autopin();
   test_ref_range();
   test_levels();
   test_single_caller();

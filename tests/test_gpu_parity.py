@@ -1186,6 +1186,34 @@ def test_reference_harness_relinked_against_the_engine(tmp_path):
         assert np.array_equal(got[:written], want[:written]), mode
 
 
+@pytest.mark.parametrize("autopin", ["1", ""])
+def test_shim_autopin_is_opt_in_and_pins_from_the_third_sighting(autopin):
+    """MDCT_SHIM_AUTOPIN=1: a host range passed for the third time is page-locked in place and DMA'd from / to directly
+    (what the reference's harness gets without a source change: main.cpp:510-523 reuses its two buffers for every run); the SSE encq
+    tier's output -- half of every block pair is not the tier's -- always goes through the bounce buffers; mdct_shim_release() lets go.
+    Without the variable nothing is ever registered.  Outputs are the oracle's either way."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MDCT_SHIM_AUTOPIN=autopin)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_autopin_child.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    HOST = 1  # hipMemoryTypeHost
+    for beh in ("q32_avx", "stereo_sse", "encq_sse"):
+        e = rep[beh]
+        assert e["ok"] and e["ok_after_release"], (beh, e)
+        types = [tuple(t) for t in e["types"]]
+        if autopin:
+            assert types[0] == (0, 0) and types[1] == (0, 0), (beh, types)  # first and second sighting: pageable
+            want_out = 0 if beh == "encq_sse" else HOST
+            assert all(t == (HOST, want_out) for t in types[2:]), (beh, types)
+        else:
+            assert all(t == (0, 0) for t in types), (beh, types)
+        assert tuple(e["after_release"]) == (0, 0), (beh, e)
+
+
 def test_shim_pinned_host_buffers_dma_in_place():
     """mdct_shim_pin: page-locked caller buffers are DMA'd in place by the host-pointer pipeline
     (no bounce memcpy); results unchanged, pin/unpin status codes"""

@@ -193,3 +193,43 @@ def test_captured_launch_never_depends_on_the_cache(cuda):
     g.replay()
     torch.cuda.synchronize()
     assert np.array_equal(out_g.cpu().numpy(), want)
+
+
+@gpu
+def test_seventh_stream_reading_a_many_reader_table_is_fenced_before_eviction(cuda):
+    """A table read by more streams than a slot remembers (kSlotStreams = 4) is fenced against the cache-wide stream list, so EVERY stream
+    that launches a read must be on that list -- also one whose reads only ever met such slots (round 5 returned early for them: ADVICE r5).
+    Stream 6 queues 25 ms of other work, then a launch that reads the shared table; stream 0 then pushes 300 new tables through the cache,
+    evicting the shared one: its upload must queue behind stream 6's read, or that read sees somebody else's multipliers."""
+    torch = cuda
+    W, H = 1024, 64
+    src = synth.plane_i16_np(W, H, "photo", seed=5, bits=12)
+    d = torch.from_numpy(src).cuda()
+    rng = np.random.default_rng(77)
+    shared = rng.uniform(9.0, 80.0, 64).astype(np.float32)
+    want = torch.empty_like(d)
+    b = api.Batch("roundtrip", [(d, want, W, H, shared)])  # owns its table: independent of the cache
+    b.run()
+    torch.cuda.synchronize()
+    b.close()
+    big = synth.plane_i16_torch(8192, 8192, "photo", seed=1)
+    big_out = torch.empty_like(big)
+    streams = [torch.cuda.Stream() for _ in range(7)]
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+    s0 = api.table_cache_stats()
+    outs = [torch.full_like(d, CANARY) for _ in range(7)]
+    for i in range(1, 6):  # five reader streams: one more than the slot remembers
+        api.roundtrip_i16(d, outs[i], W, H, lut=shared, stream=streams[i].cuda_stream)
+    blocker = api.prepare_plane_i16("roundtrip", big, big_out, 8192, 8192, stream=streams[6].cuda_stream)
+    for _ in range(600):  # ~25 ms of queue in front of stream 6's read
+        blocker()
+    api.roundtrip_i16(d, outs[6], W, H, lut=shared, stream=streams[6].cuda_stream)
+    scratch = torch.empty_like(d)
+    for k in range(300):  # stream 0 evicts everything, the shared table included
+        api.fwd_i16(d, scratch, W, H, lut=rng.uniform(8.5, 200.0, 64).astype(np.float32), stream=streams[0].cuda_stream)
+    torch.cuda.synchronize()
+    dl = _delta(s0, api.table_cache_stats())
+    assert dl["uploads"] == 301 and dl["from_arguments"] == 0 and dl["unfenceable"] == 0, dl
+    for i in range(1, 7):
+        assert torch.equal(outs[i], want), i
