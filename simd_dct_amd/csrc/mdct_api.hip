@@ -650,12 +650,12 @@ struct BatchInput
 constexpr int kModeRoundtripU8 = 3, kModeFwdU8 = 4, kModeInvU8 = 5;
 inline bool is_u8_mode(int mode) { return mode >= kModeRoundtripU8 && mode <= kModeInvU8; }
 constexpr int kModeQ32 = 6; // 8-bit planes -> the reference's q32 product (k_q32_batch)
-// k_u8_batch and k_q32_batch tile planes whose rows end in half a tile over PAIRS of block rows (batch_plan.h: kDescPaired); k_i16_batch does not
+// every batch kernel (k_i16_batch, k_u8_batch, k_q32_batch) tiles planes whose rows end in half a tile over PAIRS of block rows (batch_plan.h: kDescPaired)
 // (MDCT_PAIRED_ROWS=0 in the environment: one tile grid per block row as before round 6 -- the A/B knob of tools/experiments/exp_paired_rows.py)
-inline bool pairs_rows(int mode)
+inline bool pairs_rows(int)
 {
   const char *e = getenv("MDCT_PAIRED_ROWS");
-  return (is_u8_mode(mode) || mode == kModeQ32) && !(e && e[0] == '0');
+  return !(e && e[0] == '0');
 }
 
 // what the layout code sees of a plane of the mixed (8-bit pixels <-> int16 coefficients) batches

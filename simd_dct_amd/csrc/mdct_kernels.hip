@@ -1002,13 +1002,14 @@ struct RowsTiled
   const int16_t *src;
   int16_t *dst;
   size_t pitch_in, pitch_out; // elements
-  uint32_t lane_off;          // bytes
+  uint32_t lane_off;          // bytes from src
+  uint32_t lane_off_out;      // bytes from dst (== lane_off except for the upper lanes of a paired plane's straddling tile when the pitches differ)
   __device__ __forceinline__ uint4 ld(int r) const
   {
     const u32x4_g v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_g __attribute__((address_space(1))) *>(sgpr_ptr(src + (size_t)r * pitch_in) + lane_off));
     return make_uint4(v.x, v.y, v.z, v.w);
   }
-  __device__ __forceinline__ void st(int r, uint32_t x, uint32_t y, uint32_t z, uint32_t w) const { store16_g(sgpr_ptr(dst + (size_t)r * pitch_out) + lane_off, u32x4_g{x, y, z, w}); }
+  __device__ __forceinline__ void st(int r, uint32_t x, uint32_t y, uint32_t z, uint32_t w) const { store16_g(sgpr_ptr(dst + (size_t)r * pitch_out) + lane_off_out, u32x4_g{x, y, z, w}); }
 };
 
 __device__ __forceinline__ void unpack_i16x8(const uint4 v, float (&row)[8])
@@ -1595,7 +1596,7 @@ template <int MODE, bool HAS_LUT, bool SAT = true, int WAVES = 2>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_i16_tile(I16Args a)
 {
   const size_t by = a.by0 + blockIdx.y;
-  const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16};
+  const RowsTiled rows{a.from + by * 8 * a.pitch_in + (size_t)blockIdx.x * 512, a.to + by * 8 * a.pitch_out + (size_t)blockIdx.x * 512, a.pitch_in, a.pitch_out, threadIdx.x * 16, threadIdx.x * 16};
   const kbytes_t tbp = i16_tables(a);
   if constexpr (MODE == MODE_ROUNDTRIP)
     i16_roundtrip_rows<HAS_LUT, RowsTiled, true, SAT>(a.consts, rows, tbp); // with phase priorities
@@ -1682,11 +1683,14 @@ constexpr int batch_waves(int mode) { return mode == MODE_ROUNDTRIP ? 3 : 2; }
 template <int MODE, int LUTMODE, bool SAT = true, bool SMALL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? 4 : batch_waves(MODE), SMALL ? 4 : batch_waves(MODE)))) void k_i16_batch(BatchArgs a)
 {
-  const BatchTile t = batch_tile(blockIdx.x);
-  if (t.tile * 64 + threadIdx.x >= t.bpr())
+  const BatchTile t = batch_tile<true>(blockIdx.x);
+  if (!t.straddle && threadIdx.x >= t.s) // (a partial last tile drops its lanes)
     return;
   const size_t pin = t.pitch_in(), pout = t.pitch_out();
-  const RowsTiled rows{(const int16_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.tile * 512, (int16_t *)t.to() + (size_t)t.row * 8 * pout + (size_t)t.tile * 512, pin, pout, threadIdx.x * 16};
+  // a paired plane's straddling tile: lanes >= s continue at block 0 of the next block row -- 8 rows down, b0 + s = bpr blocks back
+  const uint32_t hop = (t.straddle && threadIdx.x >= t.s) ? 0xFFFFFFFFu : 0u;
+  const RowsTiled rows{(const int16_t *)t.from() + (size_t)t.row * 8 * pin + (size_t)t.b0 * 8, (int16_t *)t.to() + (size_t)t.row * 8 * pout + (size_t)t.b0 * 8, pin, pout,
+                       threadIdx.x * 16 + (hop & (((uint32_t)pin - t.bpr()) * 16)), threadIdx.x * 16 + (hop & (((uint32_t)pout - t.bpr()) * 16))};
   if constexpr (MODE == MODE_ROUNDTRIP)
   {
     if (LUTMODE == BATCH_ALL_LUT || (LUTMODE == BATCH_MIXED && t.has_lut()))
@@ -1748,7 +1752,7 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
   }
   else
   { // coefficient row v of the block: (c0,c1)(c2,c3)(c4,c5)(c6,c7) in four dwords -> the pairs the column pass works on, (v, A[j]) / (v, B[j])
-    const RowsTiled in{static_cast<const int16_t *>(src), nullptr, pitch_in, 0, in_off};
+    const RowsTiled in{static_cast<const int16_t *>(src), nullptr, pitch_in, 0, in_off, 0};
     uint4 rows[8];
 #pragma unroll
     for (int v = 0; v < 8; v++)
@@ -1805,7 +1809,7 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
   MDCT_PHASE_PRIO(3);
   if constexpr (MODE == U8_FWD)
   {
-    const RowsTiled out{nullptr, static_cast<int16_t *>(dst), 0, pitch_out, out_off};
+    const RowsTiled out{nullptr, static_cast<int16_t *>(dst), 0, pitch_out, 0, out_off};
 #pragma unroll
     for (int v = 0; v < 8; v++)
       out.st(v, pack_lo16(__float_as_uint(P[0][v].x), __float_as_uint(P[3][v].x)), pack_lo16(__float_as_uint(P[1][v].x), __float_as_uint(P[2][v].y)),

@@ -46,8 +46,8 @@ def test_kernel_and_host_share_the_layout_header():
     kern = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "mdct_kernels.hip")).read()
     assert "batch_plane_of(w, n, uniform" in kern and kern.count("magic_apply(") >= 1
     assert "magic_quot" not in kern and "__umulhi" not in kern  # no device-side restatement of the division or of the search
-    # k_i16_batch, and -- in the form that also understands paired rows (batch_pos, the same header) -- k_u8_batch and k_q32_batch: every batch kernel finds its tile through it
-    assert kern.count("batch_tile(blockIdx.x)") == 1 and kern.count("batch_tile<true>(blockIdx.x)") == 2 and "batch_pos(lt, t.d[8]" in kern
+    # k_i16_batch, k_u8_batch and k_q32_batch: every batch kernel finds its tile through it, in the form that understands paired rows (batch_pos, the same header)
+    assert kern.count("batch_tile<true>(blockIdx.x)") == 3 and "batch_pos(lt, t.d[8]" in kern
     assert "MDCT_HD BatchPos batch_pos(" in hdr
     api_src = open(os.path.join(ROOT, "simd_dct_amd", "csrc", "mdct_api.hip")).read()
     assert "mdct::batch_layout(" in api_src
@@ -110,8 +110,8 @@ def _planes(torch, shapes, luts, pad=0, seed0=0):
             s = full
         srcs.append(s)
         d_in.append(torch.from_numpy(s).cuda())
-        d_out.append(torch.full((h, w + pad), CANARY, dtype=torch.int16, device="cuda"))
-    desc = [(a, b, w, h, l, w + pad, w + pad) for a, b, (w, h), l in zip(d_in, d_out, shapes, luts)]
+        d_out.append(torch.full((h, w + pad + (8 if pad else 0)), CANARY, dtype=torch.int16, device="cuda"))  # (the two pitches differ)
+    desc = [(a, b, w, h, l, w + pad, w + pad + (8 if pad else 0)) for a, b, (w, h), l in zip(d_in, d_out, shapes, luts)]
     return srcs, d_in, d_out, desc
 
 
@@ -132,7 +132,7 @@ def test_batch_mixed_shapes_match_oracle(cuda, mode):
     """widths that are not multiples of 512 px (partial last tile), one-block planes, shared / distinct / no tables, pitched rows:
     the no-allocation call and the device-table batch give the oracle's planes and leave everything else alone"""
     torch = cuda
-    shapes = [(1920, 64), (8, 8), (72, 24), (520, 16), (512, 8), (200, 40), (3840, 16), (1024, 32)]
+    shapes = [(1920, 64), (8, 8), (72, 24), (520, 16), (256, 24), (200, 40), (3840, 16), (768, 40)]  # the last two and (256, 24): rows ending in half a tile, tiled in pairs
     l30, l60 = _lut(30), _lut(60)
     for luts, pad in (([None] * 8, 0), ([l30, l60, l60, None, l30, _lut(10), None, l60], 24), ([l30] * 8, 8)):
         for form in ("args", "device"):

@@ -27,20 +27,32 @@ ql = [(M.QUANTIZE_BASE * np.float32(s)).astype(np.float32) for s in (2000, 1200,
 qo = [[torch.empty(w * h, dtype=torch.uint8, device="cuda") for (_, _, w, h, _) in f] for f in frames]
 
 
+def mk16(w, h, s):
+    a = synth.plane_i16_torch(w, h, "photo", seed=s)
+    return a, torch.empty_like(a)
+
+
+f16 = []
+for i in range(4):
+    y, cb, cr = mk16(7680, 4320, i), mk16(3840, 2160, 10 + i), mk16(3840, 2160, 20 + i)
+    f16.append([(y[0], y[1], 7680, 4320, jl), (cb[0], cb[1], 3840, 2160, jc), (cr[0], cr[1], 3840, 2160, jc)])
+
+
 def build(paired):
     os.environ["MDCT_PAIRED_ROWS"] = "1" if paired else "0"
     u8 = [M.Batch("roundtrip_u8", f) for f in frames]
     q = [M.Batch("q32", [(a, o, w, h, l) for (a, b, w, h, _), o, l in zip(f, os_, ql)]) for f, os_ in zip(frames, qo)]
-    return u8, q
+    i16 = [M.Batch("roundtrip", f) for f in f16]
+    return u8, q, i16
 
 
 variants = {"rows paired": build(True), "one grid per row": build(False)}
 # same bytes either way
 outs = {}
-for name, (u8, q) in variants.items():
-    u8[0].run(); q[0].run()
+for name, (u8, q, i16) in variants.items():
+    u8[0].run(); q[0].run(); i16[0].run()
     torch.cuda.synchronize()
-    outs[name] = [x[1].clone() for x in frames[0]] + [o.clone() for o in qo[0]]
+    outs[name] = [x[1].clone() for x in frames[0]] + [o.clone() for o in qo[0]] + [x[1].clone() for x in f16[0]]
 a, b = outs.values()
 print("outputs equal:", all(torch.equal(x, y) for x, y in zip(a, b)), flush=True)
 
@@ -60,7 +72,8 @@ def med(calls, reps=100):
 
 
 for rnd in range(3):
-    for name, (u8, q) in variants.items():
+    for name, (u8, q, i16) in variants.items():
         mu, lu = med([b.prepared() for b in u8])
         mq, lq = med([b.prepared() for b in q])
-        print(f"round {rnd}  {name:18s}  k_u8_batch frame {mu:6.2f} us (min {lu:6.2f})   k_q32_batch frame {mq:6.2f} us (min {lq:6.2f})", flush=True)
+        mi, li = med([b.prepared() for b in i16])
+        print(f"round {rnd}  {name:18s}  k_u8_batch frame {mu:6.2f} us (min {lu:6.2f})   k_q32_batch frame {mq:6.2f} us (min {lq:6.2f})   k_i16_batch frame (int16, 4 B/px) {mi:6.2f} us (min {li:6.2f})", flush=True)
