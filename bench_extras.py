@@ -398,7 +398,7 @@ def roofline_blocks(extras, synth, W, H, isa_file="isa_classes.json"):
                 "issue_cycles_per_wave": round(cyc, 0), "issue_cycles_per_instruction": costs["cycles"], "clock_GHz_under_this_kernel": clock_ghz,
                 "valu_floor_ms": round(floor_ms, 4), "frac_of_valu_floor": round(floor_ms / avg_ms, 3), "simds": 1024,
                 "how": "valu_floor_ms = waves x sum(class count x measured issue cycles) / (1024 SIMDs x measured clock); counts: tools/isa_classes.py (static; "
-                       "valu_insts_per_wave is the PMC's SQ_INSTS_VALU / SQ_WAVES of tools/profile_round5.sh), cycles: tools/valubench2, clock: mdct_clock_probe beside the timed kernel"}
+                       "valu_insts_per_wave is the PMC's SQ_INSTS_VALU / SQ_WAVES of tools/profile_round.sh), cycles: tools/valubench2, clock: mdct_clock_probe beside the timed kernel"}
 
     ISA_NAME = {"k_q32_avx": "mdct::k_q32_tile(mdct::U8Args)", "k_stereo_sse": "void mdct::k_fwd_quant_u8<1, 1, false, true>(mdct::U8Args)",
                 "k_stereo_scalar": "void mdct::k_fwd_quant_u8<2, 1, false, true>(mdct::U8Args)", "k_encq_sse": "void mdct::k_fwd_quant_u8<1, 3, false, true>(mdct::U8Args)",

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Counters of the round's PMC passes -> profiles/r05_pmc_raw.txt (every counter of every kernel, mean per dispatch) and
+"""Counters of the round's PMC passes -> profiles/rNN_pmc_raw.txt (every counter of every kernel, mean per dispatch) and
 profiles/traffic.json (what bench.py attaches to its roofline blocks).
 
-    python3 tools/pmc_round5.py <dir with pmc_FETCH_SIZE/ pmc_WRITE_SIZE/ pmc_SQ/ pmc_SQ2/> <out dir>
+    python3 tools/pmc_round.py <dir with pmc_FETCH_SIZE/ pmc_WRITE_SIZE/ pmc_SQ/ pmc_SQ2/> <out dir> <round number>
 
 Kernels are told apart by name AND grid size (the stream copy that replicates inputs is the same kernel as the measured copy).
 traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE counts 64 bytes per 128-byte request (MI355X_MICROARCH.md, HBM),
@@ -10,6 +10,8 @@ WRITE_SIZE is exact; FETCH_SIZE and WRITE_SIZE come from separate passes (they d
 import collections, csv, glob, json, os, sys
 
 src, out = sys.argv[1], sys.argv[2]
+ROUND = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+TAG = "r%02d" % ROUND
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -34,7 +36,7 @@ WANT = {
     "k_u8_batch_420": ("k_u8_batch<0, false, false>", None, 2 * FR),
     "k_q32_batch_420": ("k_q32_batch<false>", None, 2 * FR),
     "k_u8_batch_420_fwd": ("k_u8_batch<1, false, false>", None, 3 * FR),
-    "k_u8_batch_420_inv": ("k_u8_batch<2, true, false>", 12420 * 64, 3 * FR),
+    "k_u8_batch_420_inv": ("k_u8_batch<2, true, false>", 12150 * 64, 3 * FR),  # (12,150 tiles: the chroma planes' rows are tiled in pairs)
     "k_i16_batch_fwd_256": ("k_i16_batch<0, 1, true, false>", 256 * 4096 * 64, 4 * 256 * 4096 * 4096),
     "k_u8_i16_fwd": ("k_u8_i16_fwd", None, 3 * W * H),
     "k_u8_i16_inv": ("k_u8_batch<2, true, false>", (W // 8) * (H // 8), 3 * W * H),  # mdct_inv_i16_u8 = a batch of one
@@ -56,8 +58,8 @@ def find(sub, grid):
     return max(hits, key=lambda k: sum(len(v) for v in acc[k].values()))  # (several grids: the one launched most)
 
 
-lines, traffic = [], {"traffic_round": 5,
-                      "source": "profiles/r05_pmc_raw.txt (round 5, tools/profile_round5.sh on the round's final build): separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; two SQ sets) "
+lines, traffic = [], {"traffic_round": ROUND,
+                      "source": f"profiles/{TAG}_pmc_raw.txt (round {ROUND}, tools/profile_round.sh on the round's final build): separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; two SQ sets) "
                                 "of tools/run_kernel.py all -- every input uploaded or replicated by the library's own copy kernel, no torch kernels, the 256-plane batch at its real size; "
                                 "bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB per dispatch (gfx950: FETCH_SIZE tallies 128-byte requests at 64)",
                       "kernels": {}}
@@ -87,7 +89,7 @@ for name, (sub, grid, alg) in WANT.items():
     traffic["kernels"][name] = e
     traffic[name + "_bytes_per_launch"] = e.get("bytes_per_launch")  # (flat keys: what earlier rounds' bench.py read)
 os.makedirs(out, exist_ok=True)
-open(os.path.join(out, "r05_pmc_raw.txt"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(out, TAG + "_pmc_raw.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 for name, e in traffic["kernels"].items():
     print(f"{name:24s} bytes {e.get('bytes_per_launch')}  x{e.get('traffic_over_algorithmic')}  valu/wave {e.get('valu_insts_per_wave')}  waves {e.get('waves')}")

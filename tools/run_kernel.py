@@ -1,11 +1,11 @@
-"""Launch engine kernels on the bench workloads -- the target of the rocprofv3 --pmc passes (tools/profile_round5.sh):
+"""Launch engine kernels on the bench workloads -- the target of the rocprofv3 --pmc passes (tools/profile_round.sh):
 
     python3 tools/run_kernel.py <name>[,<name>...] | all  [launches = 6]
 
 Every input is built on the HOST (numpy, simd_dct_amd.synth) and uploaded, or replicated on the device with the library's own stream
 copy: no torch kernel runs, so a counter pass costs what the engine's launches cost (round 4 could not finish the 256-plane batch under
 --pmc because torch's input builders ran under the counters too).  torch is used for allocation (torch.empty) and copies only.
-One process can run all kernels in turn (`all`): a counter pass is then ONE rocprofv3 run; tools/pmc_round5.py tells the kernels apart
+One process can run all kernels in turn (`all`): a counter pass is then ONE rocprofv3 run; tools/pmc_round.py tells the kernels apart
 by name and grid size.
 
     roundtrip roundtrip_lut fwd inv copy        8192^2 int16 (k_i16_tile<...>, k_stream_copy)
