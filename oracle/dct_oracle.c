@@ -475,15 +475,29 @@ int orc_encq_scalar(const uint8_t *from, uint8_t *to, const float *lut, size_t W
 /* ------------------------------------------------- engine-own [unpinned] -- */
 /* Definition of the engine's own transforms (what simd_dct_amd/csrc implements):
  *   raw forward  R = AANcols(AANrows(x))                      (no scaling inside)
- *   fwd  i16 : c[i] = sat_i16(rne(R[i] * QF[i])),  QF[i] = fwdtab[i]            (no table)
+ *   fwd  i16 : c[i] = quant_i16(R[i], QF[i]) = sat_i16(rne(R[i] * QF[i])) with one rounding,  QF[i] = fwdtab[i]  (no table)
  *                                                   QF[i] = (1.0f/lut[i]) * fwdtab[i]  (table)
  *   inv  i16 : z[i] = (float)c[i] * DQ[i],          DQ[i] = invtab[i] | lut[i] * invtab[i]
  *              x = sat_i16(rne(AANrows^-1(AANcols^-1(z))))
  *   roundtrip, no table : x' = sat_i16(rne(AANinv(R) * (1/64)))   (fwdtab*invtab == 1/64; a power
  *              of two commutes with every rounding, so it is applied once at the end)
- *   roundtrip, table    : z[i] = (float)sat_i16(rne(R[i]*QF[i])) * DQ[i], then as inv
+ *   roundtrip, table    : z[i] = (float)quant_i16(R[i], QF[i]) * DQ[i], then as inv
  *   f32      : fwd out = R[i]*fwdtab[i];  inv z = in[i]*invtab[i]
  */
+/* The engine-own QUANTISER (round 6): c = sat_i16(rne(y * qf)) with ONE rounding.  fmaf(y, qf, 1.5 * 2^23) is the exact product rounded
+ * to nearest-even in units of 1 (for |y qf| < 2^22; beyond that the clamp decides); the clamp works on the biased value, whose bounds
+ * 1.5 * 2^23 - 32768 and + 32767 are exact floats.  The engine's kernels perform the same three operations (mdct_kernels.hip:
+ * quant_i16_bits).  Rounds 1-5 rounded the product to a float first and that float to an integer (two roundings). */
+static inline __attribute__((always_inline)) int16_t quant_i16(float y, float qf)
+{
+  const float magic = 12582912.0f, lo = 12582912.0f - 32768.0f, hi = 12582912.0f + 32767.0f;
+  float t = fmaf(y, qf, magic);
+  if (t != t)
+    return 0;
+  t = t < lo ? lo : (t > hi ? hi : t);
+  return (int16_t)(t - magic);
+}
+
 static int16_t sat_i16_rne(float v)
 {
   const float r = rintf(v);
@@ -551,7 +565,7 @@ ORC_FMA_CLONES int orc_fwd_i16(const int16_t *from, int16_t *to, size_t pi, size
     LOAD_I16(blk);
     raw_fwd(blk);
     for (int i = 0; i < 64; i++)
-      AT(i >> 3, i & 7) = sat_i16_rne(blk[i] * qf[i]);
+      AT(i >> 3, i & 7) = quant_i16(blk[i], qf[i]);
   }
   return 0;
 }
@@ -590,7 +604,7 @@ ORC_FMA_CLONES int orc_roundtrip_i16(const int16_t *from, int16_t *to, size_t pi
     raw_fwd(blk);
     if (lut)
       for (int i = 0; i < 64; i++)
-        blk[i] = (float)sat_i16_rne(blk[i] * qf[i]) * dq[i];
+        blk[i] = (float)quant_i16(blk[i], qf[i]) * dq[i];
     raw_inv(blk);
     for (int i = 0; i < 64; i++)
       AT(i >> 3, i & 7) = sat_i16_rne(lut ? blk[i] : blk[i] * 0.015625f);
@@ -616,7 +630,7 @@ ORC_FMA_CLONES int orc_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pi, s
         blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c] - (level_shift ? 128.0f : 0.0f);
     raw_fwd(blk);
     for (int i = 0; i < 64; i++)
-      AT(i >> 3, i & 7) = sat_i16_rne(blk[i] * qf[i]);
+      AT(i >> 3, i & 7) = quant_i16(blk[i], qf[i]);
   }
   return 0;
 }
@@ -663,7 +677,7 @@ ORC_FMA_CLONES int orc_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pi,
         blk[r * 8 + c] = (float)from[(by * 8 + r) * pi + bx * 8 + c] - (level_shift ? 128.0f : 0.0f);
     raw_fwd(blk);
     for (int i = 0; i < 64; i++)
-      blk[i] = (float)sat_i16_rne(blk[i] * qf[i]) * dq[i];
+      blk[i] = (float)quant_i16(blk[i], qf[i]) * dq[i];
     raw_inv(blk);
     for (int i = 0; i < 64; i++)
     {

@@ -1034,11 +1034,20 @@ __device__ __forceinline__ uint32_t rne_i16_bits(const DctConsts &C, float v)
   return __float_as_uint(m + (SHIFT == 0 ? C.magic23 : C.magic29));
 }
 
-// the same rounding, result as a float integer (for quantise -> dequantise in registers)
-__device__ __forceinline__ float rne_i16_float(const DctConsts &C, float v)
+// The engine-own QUANTISER (round 6): c = sat_i16(rne(y * qf)) with ONE rounding -- fma(y, qf, 1.5 * 2^23) is the exact product rounded to
+// nearest-even in units of 1 (for |y qf| < 2^22; beyond, the clamp decides), where rounds 1-5 rounded the product to a float first and that
+// float to an integer.  One operation fewer per coefficient pair in the packed forms, and the quantised value is the correctly rounded one.
+// The clamp works on the biased value: its bounds 1.5 * 2^23 - 32768 and + 32767 are exact floats.  Same operations as the CPU checker
+// (its quant_i16).  Low 16 bits of the result = the two's-complement int16.
+constexpr float kMagic23 = 12582912.0f, kQLo = kMagic23 - 32768.0f, kQHi = kMagic23 + 32767.0f;
+__device__ __forceinline__ uint32_t quant_i16_bits(const DctConsts &C, float y, float qf)
 {
-  const float m = __builtin_amdgcn_fmed3f(v, -32768.0f, 32767.0f);
-  return (m + C.magic23) - C.magic23;
+  return __float_as_uint(__builtin_amdgcn_fmed3f(__builtin_fmaf(y, qf, C.magic23), kQLo, kQHi));
+}
+// the same, result as a float integer (for quantise -> dequantise in registers)
+__device__ __forceinline__ float quant_i16_float(const DctConsts &C, float y, float qf)
+{
+  return __builtin_amdgcn_fmed3f(__builtin_fmaf(y, qf, C.magic23), kQLo, kQHi) - C.magic23;
 }
 
 __device__ __forceinline__ uint32_t pack_lo16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }
@@ -1051,6 +1060,16 @@ __device__ __forceinline__ void store_i16x8(const DctConsts &C, int16_t *dst, co
 #pragma unroll
   for (int c = 0; c < 8; c++)
     t[c] = rne_i16_bits<SHIFT>(C, row[c]);
+  st_stream16(dst, pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
+}
+
+// a row of raw forward outputs quantised on the way out (quant_i16_bits)
+__device__ __forceinline__ void store_q_i16x8(const DctConsts &C, int16_t *dst, const float (&row)[8], const float *qf)
+{
+  uint32_t t[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++)
+    t[c] = quant_i16_bits(C, row[c], qf[c]);
   st_stream16(dst, pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
 }
 
@@ -1071,19 +1090,13 @@ __device__ __forceinline__ void i16_block(const DctConsts &C, const Rows rows, c
   else
     raw_fwd(C, b);
 
-  if constexpr (MODE == MODE_FWD)
-  {
-#pragma unroll
-    for (int i = 0; i < 64; i++)
-      b[i >> 3][i & 7] = b[i >> 3][i & 7] * tb.qf[i];
-  }
-  else
+  if constexpr (MODE != MODE_FWD)
   {
     if constexpr (MODE == MODE_ROUNDTRIP && HAS_LUT)
     {
 #pragma unroll
       for (int i = 0; i < 64; i++)
-        b[i >> 3][i & 7] = rne_i16_float(C, b[i >> 3][i & 7] * tb.qf[i]) * tb.dq[i];
+        b[i >> 3][i & 7] = quant_i16_float(C, b[i >> 3][i & 7], tb.qf[i]) * tb.dq[i];
     }
     raw_inv(C, b);
   }
@@ -1096,7 +1109,7 @@ __device__ __forceinline__ void i16_block(const DctConsts &C, const Rows rows, c
     uint32_t t[8];
 #pragma unroll
     for (int c = 0; c < 8; c++)
-      t[c] = rne_i16_bits<SHIFT>(C, b[r][c]);
+      t[c] = MODE == MODE_FWD ? quant_i16_bits(C, b[r][c], tb.qf[r * 8 + c]) : rne_i16_bits<SHIFT>(C, b[r][c]); // forward: the quantiser is the output stage
     rows.st(r, pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
   }
 }
@@ -1396,20 +1409,18 @@ __device__ __forceinline__ void aan_inv_h(const AanPk &K, f32x2 i04, f32x2 i26, 
 #endif
 }
 
-// quantise -> dequantise of the eight pairs of one column pair, SAT-free: c = rne(y qf) by the magic add and subtract, z = c dq
+// quantise -> dequantise of the eight pairs of one column pair, SAT-free: c = rne(y qf) by the fused magic add (quant_i16_bits) and the subtract, z = c dq
 __device__ __forceinline__ void quant_dequant8(const AanPk &K, f32x2 (&p)[8], const f32x2 (&qf)[8], const f32x2 (&dq)[8])
 {
 #define MDCT_Q8(OP, A, B, MOD) OP " %0, %0, " A "0" B MOD OP " %1, %1, " A "1" B MOD OP " %2, %2, " A "2" B MOD OP " %3, %3, " A "3" B MOD OP " %4, %4, " A "4" B MOD OP " %5, %5, " A "5" B MOD OP " %6, %6, " A "6" B MOD OP " %7, %7, " A "7" B MOD
-  asm("v_pk_mul_f32 %0, %0, %8 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
-      "v_pk_mul_f32 %1, %1, %9 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
-      "v_pk_mul_f32 %2, %2, %10 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
-      "v_pk_mul_f32 %3, %3, %11 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
-      "v_pk_mul_f32 %4, %4, %12 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
-      "v_pk_mul_f32 %5, %5, %13 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
-      "v_pk_mul_f32 %6, %6, %14 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
-      "v_pk_mul_f32 %7, %7, %15 op_sel:[0,0] op_sel_hi:[1,1]\n\t"
-      "v_pk_add_f32 %0, %0, %24" MDCT_KLO "v_pk_add_f32 %1, %1, %24" MDCT_KLO "v_pk_add_f32 %2, %2, %24" MDCT_KLO "v_pk_add_f32 %3, %3, %24" MDCT_KLO
-      "v_pk_add_f32 %4, %4, %24" MDCT_KLO "v_pk_add_f32 %5, %5, %24" MDCT_KLO "v_pk_add_f32 %6, %6, %24" MDCT_KLO "v_pk_add_f32 %7, %7, %24" MDCT_KLO
+  asm("v_pk_fma_f32 %0, %0, %8, %24 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t" /* y qf + 1.5 2^23, one rounding: rne of the exact product */
+      "v_pk_fma_f32 %1, %1, %9, %24 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %2, %2, %10, %24 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %3, %3, %11, %24 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %4, %4, %12, %24 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %5, %5, %13, %24 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %6, %6, %14, %24 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
+      "v_pk_fma_f32 %7, %7, %15, %24 op_sel:[0,0,0] op_sel_hi:[1,1,0]\n\t"
       "v_pk_add_f32 %0, %0, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %1, %1, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
       "v_pk_add_f32 %2, %2, %24 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
@@ -1472,18 +1483,18 @@ __device__ __forceinline__ void quant_dequant_pairs(const AanPk &K, f32x2 (&p)[8
   }
   else
   {
+    const f32x2 magic_v = K.magic; // (the fused add's third source must be a VGPR: one SGPR operand per instruction on gfx9)
 #pragma unroll
     for (int v = 0; v < 8; v++)
     {
       const f32x2 qf = tq[v], dq = td[v];
       f32x2 m;
-      MDCT_PKM(m, p[v], qf, MDCT_K_LH);
+      MDCT_PKF(m, p[v], qf, magic_v, "op_sel:[0,0,0] op_sel_hi:[1,1,0]"); // quant_i16_bits on both halves
       if constexpr (SAT)
       {
-        m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
-        m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
+        m.x = __builtin_amdgcn_fmed3f(m.x, kQLo, kQHi);
+        m.y = __builtin_amdgcn_fmed3f(m.y, kQLo, kQHi);
       }
-      MDCT_PKA(m, m, K.magic, MDCT_K_LL);
       MDCT_PKA(m, m, K.magic, MDCT_K_LL " " MDCT_NEG_B);
       MDCT_PKM(p[v], m, dq, MDCT_K_LH);
     }
@@ -1783,18 +1794,19 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
     if constexpr (MODE == U8_RT)
       quant_dequant_pairs<SAT>(K, P[j], tq, td);
     else if constexpr (MODE == U8_FWD)
-    { // c = sat_i16(rne(y * qf)): clamp (SAT), then the magic add leaves the int16 in the low half of the word (store_i16x8<0>)
+    { // c = sat_i16(rne(y * qf)), quant_i16_bits on both halves: the fused magic add leaves the int16 in the low half of the word, the clamp (SAT) works on the biased value
+      const f32x2 magic_v = K.magic;
 #pragma unroll
       for (int v = 0; v < 8; v++)
       {
         f32x2 m;
-        MDCT_PKM(m, P[j][v], tq[v], MDCT_K_LH);
+        MDCT_PKF(m, P[j][v], tq[v], magic_v, "op_sel:[0,0,0] op_sel_hi:[1,1,0]");
         if constexpr (SAT)
         {
-          m.x = __builtin_amdgcn_fmed3f(m.x, -32768.0f, 32767.0f);
-          m.y = __builtin_amdgcn_fmed3f(m.y, -32768.0f, 32767.0f);
+          m.x = __builtin_amdgcn_fmed3f(m.x, kQLo, kQHi);
+          m.y = __builtin_amdgcn_fmed3f(m.y, kQLo, kQHi);
         }
-        MDCT_PKA(P[j][v], m, K.magic, MDCT_K_LL);
+        P[j][v] = m;
       }
     }
     else
@@ -1968,11 +1980,8 @@ __global__ __launch_bounds__(kWG) __attribute__((amdgpu_waves_per_eu(MDCT_U8I16_
   raw_fwd(C, b);
   b[0][0] = b[0][0] - a.dc_shift; // 8192 or 0
 #pragma unroll
-  for (int i = 0; i < 64; i++)
-    b[i >> 3][i & 7] = b[i >> 3][i & 7] * a.tb.qf[i];
-#pragma unroll
   for (int r = 0; r < 8; r++)
-    store_i16x8<0>(C, dst + (size_t)r * a.pitch_coef, b[r]);
+    store_q_i16x8(C, dst + (size_t)r * a.pitch_coef, b[r], a.tb.qf + r * 8);
 }
 
 // Pixels (or an int16 plane, I16_IN) -> records in one pass (the encoder's front half): the forward
@@ -2031,6 +2040,7 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
   }
   int val[64];
   constexpr int kA[4] = {0, 2, 5, 1}, kB[4] = {4, 6, 3, 7};
+  const f32x2 magic_v = K.magic;
 #pragma unroll
   for (int j = 0; j < 4; j++)
   {
@@ -2039,21 +2049,16 @@ __global__ __launch_bounds__(64) void k_u8_records(U8RecArgs a)
       P[0][0].x = P[0][0].x - a.dc_shift; // the level shift is exactly "raw DC minus 64 * 128"
 #pragma unroll
     for (int v = 0; v < 8; v++)
-    { // the int16 the plane would have held (store_i16x8<0>), sign-extended
-      f32x2 m;
-      MDCT_PKM(m, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[j * 8 + v], MDCT_K_LH);
+    { // the int16 the plane would have held (quant_i16_bits), sign-extended
+      f32x2 t;
+      MDCT_PKF(t, P[j][v], reinterpret_cast<const f32x2 *>(a.tb.qf)[j * 8 + v], magic_v, "op_sel:[0,0,0] op_sel_hi:[1,1,0]");
       if constexpr (CLAMP)
       {
-        val[v * 8 + kA[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.x) & 0xFFFFu);
-        val[v * 8 + kB[j]] = (int)(int16_t)(rne_i16_bits<0>(C, m.y) & 0xFFFFu);
+        t.x = __builtin_amdgcn_fmed3f(t.x, kQLo, kQHi);
+        t.y = __builtin_amdgcn_fmed3f(t.y, kQLo, kQHi);
       }
-      else
-      {
-        f32x2 t;
-        MDCT_PKA(t, m, K.magic, MDCT_K_LL);
-        val[v * 8 + kA[j]] = (int)(int16_t)(__float_as_uint(t.x) & 0xFFFFu);
-        val[v * 8 + kB[j]] = (int)(int16_t)(__float_as_uint(t.y) & 0xFFFFu);
-      }
+      val[v * 8 + kA[j]] = (int)(int16_t)(__float_as_uint(t.x) & 0xFFFFu);
+      val[v * 8 + kB[j]] = (int)(int16_t)(__float_as_uint(t.y) & 0xFFFFu);
     }
   }
   scan_emit<true>(val, lv, rn, lane, nvalid, valid, (size_t)a.by0 * a.bpr + wave_t0, a.levels, a.runs, a.counts);
@@ -2179,6 +2184,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
     // saturated to the +-1023 of baseline categories 1..10 -- exactly what the staged coder does to an int16 record at token time
     uint32_t val[64];
     constexpr int kA[4] = {0, 2, 5, 1}, kB[4] = {4, 6, 3, 7};
+    const f32x2 magic_v = K.magic;
 #pragma unroll
     for (int j = 0; j < 4; j++)
     {
@@ -2191,13 +2197,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_px_huffman_rows(PxHuffArgs a)
 #pragma unroll
       for (int v = 0; v < 8; v++)
       {
-        f32x2 m;
-        MDCT_PKM(m, P[j][v], tq[v], MDCT_K_LH);
+        f32x2 c;
+        MDCT_PKF(c, P[j][v], tq[v], magic_v, "op_sel:[0,0,0] op_sel_hi:[1,1,0]"); // quant_i16_bits; the clamps (baseline JPEG: AC to +-1023) on the biased value
         const bool is_dc = j == 0 && v == 0;
-        f32x2 c = m;
         if constexpr (CLAMP)
-          c = f32x2{__builtin_amdgcn_fmed3f(m.x, is_dc ? -32768.0f : -1023.0f, is_dc ? 32767.0f : 1023.0f), __builtin_amdgcn_fmed3f(m.y, -1023.0f, 1023.0f)};
-        MDCT_PKA(c, c, K.magic, MDCT_K_LL);
+          c = f32x2{__builtin_amdgcn_fmed3f(c.x, is_dc ? kQLo : kMagic23 - 1023.0f, is_dc ? kQHi : kMagic23 + 1023.0f), __builtin_amdgcn_fmed3f(c.y, kMagic23 - 1023.0f, kMagic23 + 1023.0f)};
         val[v * 8 + kA[j]] = __float_as_uint(c.x);
         val[v * 8 + kB[j]] = __float_as_uint(c.y);
       }

@@ -212,8 +212,8 @@ def test_quantise_dequantise_block():
     for i in range(8):
         for h in (0, 1):
             y, qf, dq = sym("y%d" % i)[h], sym("qf%d" % i)[h], sym("dq%d" % i)[h]
-            assert regs[i][h] == mul(sub(add(mul(y, qf), ("magic23",)), ("magic23",)), dq), (i, h)  # ((y qf + 1.5 2^23) - 1.5 2^23) dq
-    assert len(ins) == 32
+            assert regs[i][h] == mul(sub(fma(y, qf, ("magic23",)), ("magic23",)), dq), (i, h)  # (fma(y, qf, 1.5 2^23) - 1.5 2^23) dq: quant_i16 then dequantise
+    assert len(ins) == 24 and sum(1 for i in ins if i[0] == "v_pk_fma_f32") == 8
 
 
 def blocks_of_quant():
