@@ -103,9 +103,11 @@ int mdct_fwd_quant_u8_pitched(const uint8_t *from, uint8_t *to, size_t pitch_in,
 /* ---- engine-own variants (no reference counterpart; BASELINE.json configs 2-5) --------
  * Planes are row-major, pitches in ELEMENTS, coefficient (v,u) of block (by,bx) lives
  * at (by*8+v, bx*8+u); coefficients are those of the orthonormal 2-D DCT-II.
- * Arithmetic: float32, scaled Arai-Agui-Nakajima butterflies (5 mul + 29 add per 8 points),
- * every operation individually rounded, no FMA; scale factors folded into the (de)quantiser
- * multipliers.  Exact definition: DESIGN.md 4.2 (and the CPU checker under oracle/).
+ * Arithmetic: float32, scaled Arai-Agui-Nakajima butterflies (5 mul + 29 add per 8 points, 4 of the
+ * multiplies fused into the additions they feed: 30 operations per pass, each rounded once); scale
+ * factors folded into the (de)quantiser multipliers; rne(dct / lut) is ONE rounding of the exact product
+ * (a fused multiply-add against 1.5 * 2^23).  Exact definition: DESIGN.md 4.2 (and the CPU checker under oracle/).
+ * (The reference-pinned uint8 tiers above never fuse anything.)
  * `lut` (HOST, 64 floats, finite and non-zero) may be NULL = no quantisation:
  *   fwd:       coef = sat_i16(rne(dct / lut[i]))
  *   inv:       x    = sat_i16(rne(idct(coef * lut[i])))
@@ -128,7 +130,8 @@ int mdct_roundtrip_i16(const int16_t *from, int16_t *to, size_t pitch_in, size_t
                        size_t sizeX, size_t sizeY, size_t by0, size_t by1, void *stream);
 /* 8-bit pixels <-> int16 coefficients, the JPEG-style pair (3 algorithmic bytes per pixel):
  *   fwd: coef = sat_i16(rne(dct(px - (level_shift ? 128 : 0)) / lut[i]))
- *   inv: px   = clamp(rne(idct(coef * lut[i])) + (level_shift ? 128 : 0), 0, 255)
+ *   inv: px   = sat_u8(rne(idct(coef * lut[i] [+ 128 on the DC term when level_shift])))   -- the output's level shift rides in the
+ *               DC term (a constant plane IS the DC term), so the shifted value takes part in the inverse's roundings
  * pitch of the u8 plane in bytes, of the int16 plane in elements; coefficient rows 16-byte
  * aligned, no alignment requirement on the pixel plane.  lut may be NULL. */
 int mdct_fwd_u8_i16(const uint8_t *from, int16_t *to, size_t pitch_in, size_t pitch_out, const float *lut, int level_shift,
@@ -189,7 +192,7 @@ int mdct_batch_destroy(mdct_batch *batch);
  * pass over HBM, bit for bit
  *     mdct_fwd_u8_i16(from -> coef, lut, level_shift)  followed by  mdct_inv_i16_u8(coef -> to, lut, level_shift)
  * without the int16 plane in between:
- *     c = sat_i16(rne(dct(px - shift) / lut[i])),  px' = clamp(rne(idct(c * lut[i])) + shift, 0, 255),  shift = level_shift ? 128 : 0.
+ *     c = sat_i16(rne(dct(px - shift) / lut[i])),  px' = sat_u8(rne(idct(c * lut[i], DC term + shift))),  shift = level_shift ? 128 : 0.
  * lut == NULL: no quantisation table (the coefficients are still rounded to int16, as the two calls would).
  * Pitches in BYTES; no alignment requirement on the planes (like the reference, simd_dct.cpp:2109); sizeX, sizeY multiples of 8.
  * One 64-block tile of one block row per wave, the last tile of a row may be partial (any sizeX % 8 == 0).

@@ -498,6 +498,18 @@ static inline __attribute__((always_inline)) int16_t quant_i16(float y, float qf
   return (int16_t)(t - magic);
 }
 
+/* The 8-bit output stage (round 6): px = sat_u8(rne(x)) -- round to nearest even, saturate to [0, 255], NaN -> 0, which is what the
+ * engine's one-instruction-per-pixel convert does.  The level shift of the OUTPUT (+ 128) is not added to the rounded pixel any more: it
+ * rides in the DC term, z00 + shift before the inverse transform (a constant plane is exactly the DC term of the AAN inverse), so the
+ * shifted value takes part in the butterflies' roundings. */
+static inline __attribute__((always_inline)) uint8_t sat_u8_rne(float x)
+{
+  const float r = rintf(x);
+  if (r != r)
+    return 0;
+  return (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+}
+
 static int16_t sat_i16_rne(float v)
 {
   const float r = rintf(v);
@@ -648,13 +660,10 @@ ORC_FMA_CLONES int orc_inv_i16_u8(const int16_t *from, uint8_t *to, size_t pi, s
     LOAD_I16(blk);
     for (int i = 0; i < 64; i++)
       blk[i] = blk[i] * dq[i];
+    blk[0] = blk[0] + (level_shift ? 128.0f : 0.0f); /* the output's level shift rides in the DC term (sat_u8_rne above) */
     raw_inv(blk);
     for (int i = 0; i < 64; i++)
-    {
-      float r = rintf(blk[i]);
-      r = r + (level_shift ? 128.0f : 0.0f); /* exact: integers well below 2^24 */
-      AT(i >> 3, i & 7) = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
-    }
+      AT(i >> 3, i & 7) = sat_u8_rne(blk[i]);
   }
   return 0;
 }
@@ -678,13 +687,10 @@ ORC_FMA_CLONES int orc_roundtrip_u8(const uint8_t *from, uint8_t *to, size_t pi,
     raw_fwd(blk);
     for (int i = 0; i < 64; i++)
       blk[i] = (float)quant_i16(blk[i], qf[i]) * dq[i];
+    blk[0] = blk[0] + (level_shift ? 128.0f : 0.0f);
     raw_inv(blk);
     for (int i = 0; i < 64; i++)
-    {
-      float r = rintf(blk[i]);
-      r = r + (level_shift ? 128.0f : 0.0f);
-      AT(i >> 3, i & 7) = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
-    }
+      AT(i >> 3, i & 7) = sat_u8_rne(blk[i]);
   }
   return 0;
 }

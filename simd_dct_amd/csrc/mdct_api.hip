@@ -822,10 +822,9 @@ void batch_header(const mdct::BatchLayout &lay, const BatchInput &in, BatchLaunc
 void u8_px_consts(int level_shift, float (&px)[4])
 {
   const float shift = level_shift ? 128.0f : 0.0f;
-  px[0] = 64.0f * shift;       // forward: the level shift is "raw DC - 64 * shift"
-  px[1] = 12582912.0f + shift; // 1.5 * 2^23 + shift: even, so ties still round to even; the low bits of x + this are rne(x) + shift
-  px[2] = 0.0f - shift;        // rne(x) + shift in [0, 255]  <=>  x clamped to [-shift, 255 - shift]
-  px[3] = 255.0f - shift;
+  px[0] = 64.0f * shift; // forward: the level shift is "raw DC - 64 * shift"
+  px[1] = shift;         // inverse: it comes back as "z00 + shift" before the transform (a constant plane is the DC term)
+  px[2] = px[3] = 0.0f;
 }
 
 hipError_t launch_batch(const BatchLaunch &l, int mode, hipStream_t s)

@@ -175,7 +175,7 @@ struct BatchArgs
   const BatchDesc *descs;  // device memory, or nullptr: embedded
   const OwnTables *tables; // device memory, or nullptr: embedded (blob)
   DctConsts consts;
-  alignas(8) float px[4];  // k_u8_batch only: (64 * shift, 1.5 * 2^23 + shift, -shift, 255 - shift), shift = 128 with the level shift, else 0
+  alignas(8) float px[4];  // k_u8_batch only: (64 * shift, shift, 0, 0), shift = 128 with the level shift, else 0
   PkConstsArg pk;          // k_q32_batch only: the reference's AVX2-tier constants as register pairs (U8Args::pk)
   alignas(64) unsigned char blob[kBatchBlob]; // [tables][descriptors]
 };

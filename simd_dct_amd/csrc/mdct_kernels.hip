@@ -1723,28 +1723,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? 4 : 
 //   quantiser    c = sat_i16(rne(y * qf)), z = c * dq on register pairs; SAT = false (host: every table entry >= 1/16 in
 //                magnitude, so |y / lut| <= 16 * 2040 stays inside int16) leaves the saturations out
 //   inverse      aan_inv_v, aan_inv_h
-//   rows out     clamp(rne(x) + shift, 0, 255): the magic add (1.5 * 2^23 + shift is even: ties as rne, low bits = rne(x) + shift), then
-//                FIN_SATPK  low halves paired by v_perm_b32, v_sat_pk_u8_i16 saturates both to bytes: 14 instructions per row.  Needs
-//                           |rne(x) + shift| < 2^15, which the host guarantees from the table (Parseval: |x| <= 2040 + |lut|_2 / 2)
-//                FIN_CLAMP  v_med3_f32 before the add, 3 x v_perm_b32 per 4 bytes: 18 per row, any finite x
+//   rows out     sat_u8(rne(x)): ONE v_cvt_pk_u8_f32 per pixel (round to nearest even, saturate to [0, 255], NaN -> 0; probed on gfx950,
+//                tools/probe_cvt_pk_u8.hip; it issues like any convert, tools/valubench2) -- 8 instructions per row where the magic add, the
+//                int16 pairing and v_sat_pk_u8_i16 took 14 (rounds 5: 18 with the clamp).  The level shift of the output (+ 128) rides in the
+//                DC term: z00 + shift before the inverse transform (a constant plane is exactly the DC term of the AAN inverse), round 6.
 // No LDS, nothing crosses lanes: a partial last tile just drops its lanes.
 // ---------------------------------------------------------------------------------------
-enum { FIN_CLAMP = 0, FIN_SATPK = 1 };
-#define MDCT_PKAK(d, a, k, mods) asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(d) : "v"(a), "s"(k))
-__device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t v)
+// four pixels -> one dword of bytes: sat_u8(rne(x)) each (v_cvt_pk_u8_f32 inserts byte `sel` into the dword it is given)
+__device__ __forceinline__ uint32_t pack4_sat_u8(float x0, float x1, float x2, float x3)
 {
-  uint32_t r;
-  asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(v));
-  return r;
+  uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(x0, 0, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(x1, 1, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(x2, 2, w);
+  return __builtin_amdgcn_cvt_pk_u8_f32(x3, 3, w);
 }
 // MODE: the fused round trip (pixels in, pixels out), or one half of it on the same tiles -- U8_FWD pixels -> quantised int16 coefficients
 // (bit for bit k_u8_i16_fwd), U8_INV int16 coefficients -> pixels: what an encoder / a decoder runs on a frame's
 // planes in one launch.  The int16 side is a plane of 16-byte rows per lane (a tile row = 1 KiB), pitch in elements.
 enum { U8_RT = 0, U8_FWD = 1, U8_INV = 2 };
-template <int MODE, bool SAT, int FIN, bool PRIO>
+template <int MODE, bool SAT, bool PRIO>
 // in_off / out_off: the lane's byte offset from src / dst (lane * bytes per block row, plus the hop to the next block row for the upper lanes of a
 // straddling tile of a paired plane)
-__device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_magic, const f32x2 lo_hi, const void *src, void *dst, size_t pitch_in, size_t pitch_out, uint32_t in_off, uint32_t out_off, kbytes_t tbp)
+// shifts = (64 * shift, shift): the level shift leaves with the forward DC ("raw DC - 64 * shift") and comes back with the inverse's (z00 + shift)
+__device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shifts, const void *src, void *dst, size_t pitch_in, size_t pitch_out, uint32_t in_off, uint32_t out_off, kbytes_t tbp)
 {
   const AanPk &K = reinterpret_cast<const AanPk &>(C);
   f32x2 P[4][8];
@@ -1789,7 +1790,7 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
     {
       aan_fwd_v(K, P[j]);
       if (j == 0)
-        P[0][0].x = P[0][0].x - shift_magic.x; // the level shift is exactly "raw DC minus 64 * 128"
+        P[0][0].x = P[0][0].x - shifts.x; // the level shift is exactly "raw DC minus 64 * 128"
     }
     if constexpr (MODE == U8_RT)
       quant_dequant_pairs<SAT>(K, P[j], tq, td);
@@ -1816,7 +1817,11 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
         MDCT_PKM(P[j][v], P[j][v], td[v], MDCT_K_LH); // z = c * dq
     }
     if constexpr (MODE != U8_FWD)
+    {
+      if (j == 0)
+        P[0][0].x = P[0][0].x + shifts.y; // the output's level shift: every pixel + shift == the DC term + shift, before the inverse
       aan_inv_v(K, P[j]);
+    }
   }
   MDCT_PHASE_PRIO(3);
   if constexpr (MODE == U8_FWD)
@@ -1833,30 +1838,8 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
   {
     f32x2 o07, o16, o25, o43;
     aan_inv_h(K, P[0][r], P[1][r], P[2][r], P[3][r], o07, o16, o25, o43);
-    auto fin = [&](f32x2 v) {
-      f32x2 t;
-      if constexpr (FIN == FIN_CLAMP)
-      { // so that rne(x) + shift lands in [0, 255]
-        v.x = __builtin_amdgcn_fmed3f(v.x, lo_hi.x, lo_hi.y);
-        v.y = __builtin_amdgcn_fmed3f(v.y, lo_hi.x, lo_hi.y);
-      }
-      MDCT_PKAK(t, v, shift_magic, MDCT_K_HH);
-      return t;
-    };
-    const f32x2 b07 = fin(o07), b16 = fin(o16), b25 = fin(o25), b43 = fin(o43);
-    uint32_t w0, w1;
-    if constexpr (FIN == FIN_SATPK)
-    { // (x1:x0) (x3:x2) (x5:x4) (x7:x6) as int16 pairs -> saturated byte pairs -> two dwords
-      const uint32_t p10 = sat_pk_u8_i16(pack_lo16(__float_as_uint(b07.x), __float_as_uint(b16.x))), p32 = sat_pk_u8_i16(pack_lo16(__float_as_uint(b25.x), __float_as_uint(b43.y)));
-      const uint32_t p54 = sat_pk_u8_i16(pack_lo16(__float_as_uint(b43.x), __float_as_uint(b25.y))), p76 = sat_pk_u8_i16(pack_lo16(__float_as_uint(b16.y), __float_as_uint(b07.y)));
-      w0 = pack_lo16(p10, p32);
-      w1 = pack_lo16(p54, p76);
-    }
-    else
-    {
-      w0 = pack4_lo8(__float_as_uint(b07.x), __float_as_uint(b16.x), __float_as_uint(b25.x), __float_as_uint(b43.y));
-      w1 = pack4_lo8(__float_as_uint(b43.x), __float_as_uint(b25.y), __float_as_uint(b16.y), __float_as_uint(b07.y));
-    }
+    // x0..x7 = o07.x o16.x o25.x o43.y o43.x o25.y o16.y o07.y
+    const uint32_t w0 = pack4_sat_u8(o07.x, o16.x, o25.x, o43.y), w1 = pack4_sat_u8(o43.x, o25.y, o16.y, o07.y);
     const u32x2_unaligned_g w = {w0, w1};
     __builtin_nontemporal_store(w, reinterpret_cast<u32x2_unaligned_g __attribute__((address_space(1))) *>(sgpr_ptr(static_cast<uint8_t *>(dst) + (size_t)r * pitch_out) + out_off));
   }
@@ -1871,8 +1854,8 @@ __device__ __forceinline__ void u8_rows(const DctConsts &C, const f32x2 shift_ma
 #ifndef MDCT_U8B_PRIO
 #define MDCT_U8B_PRIO true
 #endif
-// GENERAL = false: every plane's table is tame (mdct_api.hip: u8_table_is_tame / u8_table_is_bounded): no saturations in the quantiser and,
-// for the round trip, the v_sat_pk_u8_i16 output stage.  U8_INV is always GENERAL: its coefficients are the caller's, not a transform's.
+// GENERAL = false: every plane's table is tame (mdct_api.hip: u8_table_is_tame / u8_table_is_bounded): no saturations in the quantiser.
+// (The output stage saturates by itself in every build.)  U8_INV is always GENERAL: its coefficients are the caller's, not a transform's.
 template <int MODE, bool GENERAL, bool SMALL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT_U8B_WAVES_SMALL : MDCT_U8B_WAVES, SMALL ? MDCT_U8B_WAVES_SMALL : MDCT_U8B_WAVES))) void k_u8_batch(BatchArgs a)
 {
@@ -1882,7 +1865,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT
   if (!t.straddle && lane >= t.s) // (wave-uniform first: a partial last tile drops its lanes)
     return;
   const size_t pin = t.pitch_in(), pout = t.pitch_out();
-  const f32x2 shift_magic = {a.px[0], a.px[1]}, lo_hi = {a.px[2], a.px[3]};
+  const f32x2 shifts = {a.px[0], a.px[1]};
   // a tile = 64 blocks of one block row: 512 bytes of every pixel row, 512 elements of every coefficient row; in a paired plane's straddling
   // tile the lanes >= s continue at block 0 of the next block row: 8 rows down and b0 + s = bpr blocks back
   constexpr uint32_t in_el = MODE == U8_INV ? 2 : 1, out_el = MODE == U8_FWD ? 2 : 1;
@@ -1890,7 +1873,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMALL ? MDCT
   char *dst = (char *)t.to() + ((size_t)t.row * 8 * pout + (size_t)t.b0 * 8) * out_el;
   const uint32_t hop = (t.straddle && lane >= t.s) ? 0xFFFFFFFFu : 0u;
   const uint32_t hop_in = ((uint32_t)pin - t.bpr()) * (8 * in_el), hop_out = ((uint32_t)pout - t.bpr()) * (8 * out_el);
-  u8_rows<MODE, GENERAL, (GENERAL || MODE != U8_RT) ? FIN_CLAMP : FIN_SATPK, MDCT_U8B_PRIO>(a.consts, shift_magic, lo_hi, src, dst, pin, pout, lane * (8 * in_el) + (hop & hop_in),
+  u8_rows<MODE, GENERAL, MDCT_U8B_PRIO>(a.consts, shifts, src, dst, pin, pout, lane * (8 * in_el) + (hop & hop_in),
                                                                                            lane * (8 * out_el) + (hop & hop_out), t.tables);
 }
 

@@ -363,7 +363,7 @@ def test_split420_matches_the_checker_and_feeds_config3():
 def test_split420_into_8bit_planes_feeds_the_8bit_config3_path():
     """mdct_split420_u8_planes: the 4:2:0 split into unshifted 8-bit planes == the checker's int16 split + 128, any pitches / alignment with
     canaries; BASELINE.json configs[2] as SURVEY.md 8(d) states it end to end: interleaved 7680x4320 frame -> split -> the three 8-bit planes
-    through mdct_roundtrip_u8_batch in one launch == the int16 route's reconstruction (split420_u8 -> roundtrip_i16_planes) + 128, clamped"""
+    through mdct_roundtrip_u8_batch in one launch against the int16 route's reconstruction (split420_u8 -> roundtrip_i16_planes) + 128, clamped"""
     api.init(0)
     for (W, H, py, pc) in ((16, 16, 16, 8), (64, 32, 67, 35), (1008, 48, 1011, 505), (1920, 1088, 1920, 960)):
         ycc = _ycc(W, H, seed=W + 1)
@@ -390,5 +390,9 @@ def test_split420_into_8bit_planes_feeds_the_8bit_config3_path():
     o16 = [torch.empty_like(t) for t in p16]
     api.roundtrip_u8_batch([(a, o, w, h, l) for a, o, (w, h), l in zip(p8, o8, dims, luts)])
     api.roundtrip_i16_planes([(a, o, w, h, l) for a, o, (w, h), l in zip(p16, o16, dims, luts)])
-    for a, b in zip(o8, o16):  # the same transform, quantiser and inverse on the same (shifted) samples: only the output clamp differs
-        assert torch.equal(a.to(torch.int16), (b + 128).clamp(0, 255))
+    # the same transform and quantiser on the same (shifted) samples.  Since round 6 the 8-bit inverse carries the output's + 128 in its DC term
+    # (sat_u8(rne(idct(z, DC + 128))), one convert per pixel) where the int16 route adds it to the rounded sample: the two agree except where a
+    # sample sits within the butterflies' rounding error of a .5 tie -- never by more than one grey level, and rarely
+    for a, b in zip(o8, o16):
+        d = (a.to(torch.int16) - (b + 128).clamp(0, 255)).abs()
+        assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-3, (int(d.max()), float((d != 0).float().mean()))

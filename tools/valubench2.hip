@@ -81,6 +81,8 @@ DEFP(k_pk_fma, T8("v_pk_fma_f32"))
 DEFP(k_pk_add_opsel, PX8)
 DEF(k_sat_pk_u8_i16, U8("v_sat_pk_u8_i16"))
 DEF(k_cvt_u32_f32, U8("v_cvt_u32_f32"))
+#define C8 "v_cvt_pk_u8_f32 %0, %0, 1, %0\n v_cvt_pk_u8_f32 %1, %1, 1, %1\n v_cvt_pk_u8_f32 %2, %2, 1, %2\n v_cvt_pk_u8_f32 %3, %3, 1, %3\n v_cvt_pk_u8_f32 %4, %4, 1, %4\n v_cvt_pk_u8_f32 %5, %5, 1, %5\n v_cvt_pk_u8_f32 %6, %6, 1, %6\n v_cvt_pk_u8_f32 %7, %7, 1, %7\n"
+DEF(k_cvt_pk_u8_f32, C8) // float -> byte (RNE, saturating), inserted into a dword: the one-instruction output stage measured for the 8-bit round trip
 
 // the clock the chip holds while a benchmark kernel runs: one wave spins for `ticks` of the constant 100 MHz counter and reports the
 // shader cycles (s_memtime) that passed meanwhile; launched just before the benchmark kernel on a second stream
@@ -163,13 +165,13 @@ int main()
   RUN(k_add); RUN(k_mul); RUN(k_sub); RUN(k_fma); RUN(k_addu32); RUN(k_addu16); RUN(k_med3f); RUN(k_med3i); RUN(k_perm);
   RUN(k_cvt_f32_i32); RUN(k_cvt_f32_i32_sdwa); RUN(k_cvt_f32_ubyte0); RUN(k_cvt_f32_ubyte2); RUN(k_cvt_i32_f32); RUN(k_rndne);
   RUN(k_mov); RUN(k_lshl_or); RUN(k_and_or); RUN(k_bfe); RUN(k_dpp_mov); RUN(k_ds_write_b8); RUN(k_ds_write_b32);
-  RUN(k_pk_add); RUN(k_pk_mul); RUN(k_pk_fma); RUN(k_pk_add_opsel); RUN(k_sat_pk_u8_i16); RUN(k_cvt_u32_f32);
+  RUN(k_pk_add); RUN(k_pk_mul); RUN(k_pk_fma); RUN(k_pk_add_opsel); RUN(k_sat_pk_u8_i16); RUN(k_cvt_u32_f32); RUN(k_cvt_pk_u8_f32);
   // the classes bench.py's vector-issue floor is built from (tools/isa_classes.py sorts a kernel's instructions into them), at the
   // occupancy the product kernels run at as well
   for (int w : {4, 3, 2})
   {
     g_waves = w;
-    RUN(k_add); RUN(k_pk_add); RUN(k_pk_mul); RUN(k_perm); RUN(k_cvt_f32_ubyte0); RUN(k_med3f);
+    RUN(k_add); RUN(k_pk_add); RUN(k_pk_mul); RUN(k_perm); RUN(k_cvt_f32_ubyte0); RUN(k_med3f); RUN(k_cvt_pk_u8_f32); RUN(k_sat_pk_u8_i16);
   }
   auto cost = [&](const char *n, bool cyc) {
     for (int i = 0; i < g_ncosts; i++)
