@@ -112,6 +112,20 @@ struct Shared
   std::atomic<int> arrived[8]; // barriers between the phases of the batch run (one counter per barrier)
 };
 
+
+// the device of a rank: its own GPU.  MDCT_CLI_SHARE_DEVICES=1 (rehearsals on a box with fewer GPUs than ranks, tests/test_two_rank_gpu.py):
+// rank modulo the number of devices -- RCCL itself may still refuse two ranks on one device, which the run then reports like any other failure
+static int rank_device(int rank)
+{
+  const char *e = getenv("MDCT_CLI_SHARE_DEVICES");
+  if (!(e && e[0] == '1'))
+    return rank;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+    return rank;
+  return rank % n;
+}
+
 int run_rank_body(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file);
 
 // whatever goes wrong in a rank, the others learn of it before their next collective (and the parent ends those that
@@ -126,9 +140,9 @@ int run_rank(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, si
 
 int run_rank_body(Shared *sh, int rank, int world, const std::vector<uint8_t> &in, size_t X, size_t Y, const float *table, bool stereo, size_t runs, const char *out_file)
 {
-  if (mdct_init(rank) != MDCT_SUCCESS)
+  if (mdct_init(rank_device(rank)) != MDCT_SUCCESS)
   {
-    printf("rank %d: mdct_init(%d) failed: %s\n", rank, rank, mdct_last_error());
+    printf("rank %d: mdct_init(%d) failed: %s\n", rank, rank_device(rank), mdct_last_error());
     return 2;
   }
   if (rank == 0)
@@ -287,9 +301,9 @@ void synth_i16(std::vector<int16_t> &pl, size_t W, size_t H, uint32_t seed)
 
 int comm_setup(Shared *sh, int rank, int world, mdct_comm **comm)
 {
-  if (mdct_init(rank) != MDCT_SUCCESS)
+  if (mdct_init(rank_device(rank)) != MDCT_SUCCESS)
   {
-    printf("rank %d: mdct_init(%d) failed: %s\n", rank, rank, mdct_last_error());
+    printf("rank %d: mdct_init(%d) failed: %s\n", rank, rank_device(rank), mdct_last_error());
     return 2;
   }
   if (rank == 0)
@@ -442,6 +456,7 @@ int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y,
   std::vector<pid_t> kids;
   for (int r = 0; r < world; r++)
   {
+    fflush(stdout); // (nothing buffered may be inherited twice)
     const pid_t p = fork(); // nothing has touched HIP yet in this process
     if (p == 0)
     {
@@ -454,6 +469,7 @@ int run_multi_gpu(int world, const std::vector<uint8_t> &in, size_t X, size_t Y,
       }
       else
         code = run_rank(sh, r, world, in, X, Y, table, stereo, runs, out_file);
+      fflush(stdout); // (_exit does not flush: a rank's messages would be lost whenever stdout is a pipe or a file)
       _exit(code);
     }
     kids.push_back(p);
