@@ -185,6 +185,10 @@ def test_roundtrip_u8_pitches_ranges_and_alignment(cuda):
             assert (got[mask] == CANARY).all(), ("bytes outside the range were written", off_in, off_out, by0, by1)
 
 
+def _out_pad(pad):
+    return pad + 5 if pad else 0  # the output pitch differs from the input's (a paired plane's straddling tile hops by each side's own pitch)
+
+
 def _u8_planes(torch, shapes, luts, pad=0, seed0=0):
     srcs, d_in, d_out = [], [], []
     for i, (w, h) in enumerate(shapes):
@@ -195,8 +199,8 @@ def _u8_planes(torch, shapes, luts, pad=0, seed0=0):
             s = full
         srcs.append(s)
         d_in.append(torch.from_numpy(s).cuda())
-        d_out.append(torch.full((h, w + pad), CANARY, dtype=torch.uint8, device="cuda"))
-    desc = [(a, b, w, h, l, w + pad, w + pad) for a, b, (w, h), l in zip(d_in, d_out, shapes, luts)]
+        d_out.append(torch.full((h, w + _out_pad(pad)), CANARY, dtype=torch.uint8, device="cuda"))
+    desc = [(a, b, w, h, l, w + pad, w + _out_pad(pad)) for a, b, (w, h), l in zip(d_in, d_out, shapes, luts)]
     return srcs, d_in, d_out, desc
 
 
