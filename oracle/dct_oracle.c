@@ -510,6 +510,18 @@ static inline __attribute__((always_inline)) uint8_t sat_u8_rne(float x)
   return (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
 }
 
+/* the two definitions above, exported for the tests that hold them against exact arithmetic (tests/test_oracle.py) */
+void orc_quant_i16(const float *y, const float *qf, int16_t *out, size_t n)
+{
+  for (size_t i = 0; i < n; i++)
+    out[i] = quant_i16(y[i], qf[i]);
+}
+void orc_sat_u8_rne(const float *x, uint8_t *out, size_t n)
+{
+  for (size_t i = 0; i < n; i++)
+    out[i] = sat_u8_rne(x[i]);
+}
+
 static int16_t sat_i16_rne(float v)
 {
   const float r = rintf(v);

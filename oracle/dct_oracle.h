@@ -85,6 +85,10 @@ int orc_inv_f32(const float *from, float *to, size_t pitch_in, size_t pitch_out,
 int orc_fwd_f64ref(const float *from, double *to, size_t pitch_in, size_t pitch_out,
                    size_t sizeX, size_t sizeY, size_t by0, size_t by1);
 
+/* the engine-own quantiser c = sat_i16(rne(y * qf)) -- ONE rounding of the exact product -- and the 8-bit output stage sat_u8(rne(x)), element-wise [unpinned] */
+void orc_quant_i16(const float *y, const float *qf, int16_t *out, size_t n);
+void orc_sat_u8_rne(const float *x, uint8_t *out, size_t n);
+
 /* u8 forward+quantise with the engine's full-plane, half-open block-row range and
  * explicit pitches -- same arithmetic as B1 (profile 0) -- used to check the native
  * C-ABI (mdct_fwd_quant_u8) rather than the reference-semantics shim. */

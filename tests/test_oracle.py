@@ -372,3 +372,39 @@ def test_fma_clone_and_libm_fmaf_build_agree(tmp_path):
                 assert fn(src.ctypes.data, out.ctypes.data, W, W, lp, W, H, 0, H // 8) == 0
                 outs.append(out)
             assert np.array_equal(outs[0], outs[1]), name
+
+
+def test_engine_own_quantiser_is_one_rounding_of_the_exact_product():
+    """c = sat_i16(rne(y * qf)) (round 6): the product of two floats is exact in double, so rint of it is THE correctly rounded quantised
+    value -- the checker's fused form must equal it everywhere, ties (y * qf = k + 1/2 exactly) and the saturating range included, where
+    rounds 1-5's mul-then-round form differs on the products that round up to a tie.  Same for the 8-bit output stage."""
+    import ctypes
+
+    lib = O.oracle()
+    f32p = ctypes.POINTER(ctypes.c_float)
+    lib.orc_quant_i16.argtypes = [f32p, f32p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.orc_sat_u8_rne.argtypes = [f32p, ctypes.c_void_p, ctypes.c_size_t]
+    rng = np.random.default_rng(66)
+    n = 1 << 20
+    y = (rng.integers(-200000, 200000, n) / 8.0).astype(np.float32)  # raw AAN outputs are multiples of small powers of two
+    qf = rng.uniform(1e-3, 0.9, n).astype(np.float32)
+    # exact ties: qf = 2^-k, y = (2 m + 1) 2^(k-1)
+    k = rng.integers(1, 6, 4096)
+    y[:4096] = ((2 * rng.integers(-3000, 3000, 4096) + 1) * 2.0 ** (k - 1)).astype(np.float32)
+    qf[:4096] = (2.0 ** -k.astype(np.float64)).astype(np.float32)
+    # far outside int16, both signs, and products near 2^22 where the magic add runs out of unit resolution
+    y[4096:8192] = rng.uniform(-3e6, 3e6, 4096).astype(np.float32)
+    qf[4096:8192] = rng.uniform(0.5, 4.0, 4096).astype(np.float32)
+    got = np.zeros(n, dtype=np.int16)
+    lib.orc_quant_i16(y.ctypes.data_as(f32p), qf.ctypes.data_as(f32p), got.ctypes.data, n)
+    want = np.clip(np.rint(y.astype(np.float64) * qf.astype(np.float64)), -32768, 32767).astype(np.int16)
+    assert np.array_equal(got, want)
+    old = np.clip(np.rint((y * qf).astype(np.float32)), -32768, 32767).astype(np.int16)  # two roundings
+    assert (old != want).sum() > 0  # the distinction is real on this sample
+    x = rng.uniform(-40, 300, n).astype(np.float32)
+    x[:512] = (np.arange(512) - 128) + 0.5  # ties
+    x[512:516] = [np.nan, np.inf, -np.inf, -0.0]
+    gu = np.zeros(n, dtype=np.uint8)
+    lib.orc_sat_u8_rne(x.ctypes.data_as(f32p), gu.ctypes.data, n)
+    wu = np.clip(np.rint(np.nan_to_num(x.astype(np.float64), nan=0.0, posinf=255.0, neginf=0.0)), 0, 255).astype(np.uint8)
+    assert np.array_equal(gu, wu)
