@@ -227,7 +227,8 @@ int mdct_batch_create_u8(mdct_batch **batch, const mdct_plane_u8 *planes, int n_
  * Kernel-argument form (no allocation, capture-safe) and device-resident form (run with mdct_batch_run) as for the other batches.
  * (Every block row of every plane is transformed: a caller that wants what ONE reference call does to its buffer -- the top sizeY / 2 rows
  * only, simd_dct.cpp:2245 -- describes that half as the plane, sizeY / 2 high; a row sub-range is a plane that starts further down.)
- * NOT in place (to != from, like the reference: a group's 512 output bytes cover pixels other lanes still have to read, simd_dct.cpp:2227-2230). */
+ * NOT in place (like the reference: a group's 512 output bytes cover pixels other lanes still have to read, simd_dct.cpp:2227-2230): a plane whose
+ * output strips overlap its own input is refused with MDCT_INVALID_PARAMETER. */
 int mdct_fwd_quant32_u8_batch(const mdct_plane_u8 *planes, int n_planes, void *stream);
 int mdct_batch_create_q32(mdct_batch **batch, const mdct_plane_u8 *planes, int n_planes);
 

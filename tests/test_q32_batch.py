@@ -46,6 +46,11 @@ def test_q32_batch_status_codes_without_device():
     assert api.fwd_quant32_u8_batch([(px, out, 128, 16, lut, 128, 8 * 128 - 16)], check=False) == 1 and "strip pitch" in api.last_error()
     assert api.fwd_quant32_u8_batch([(px, out, 128, 16, lut, 128, 8 * 128 + 8)], check=False) == 1  # not a multiple of 16
     assert api.fwd_quant32_u8_batch([(px, out, 128, 16, lut, 120, None)], check=False) == 1  # input pitch below the width
+    # not in place: an output that meets the plane's own input is refused -- the same buffer, and a partial overlap
+    assert api.fwd_quant32_u8_batch([ok, (px, px, 128, 16, lut)], check=False) == 1 and "overlaps" in api.last_error()
+    both = np.zeros(2 * 128 * 16, dtype=np.uint8)
+    assert api.fwd_quant32_u8_batch([(both[:2048], both[1024:3072], 128, 16, lut)], check=False) == 1 and "overlaps" in api.last_error()
+    assert api.fwd_quant32_u8_batch([(both[:2048], both[2048:], 128, 16, lut)], check=False) != 1 or "overlaps" not in api.last_error()  # adjacent is fine
     assert lib.mdct_fwd_quant32_u8_batch(None, 1, None) == 1
     h = ctypes.c_void_p()
     assert lib.mdct_batch_create_q32(None, None, 0) == 1
