@@ -65,7 +65,9 @@ typedef struct mdct_device_info
 /* Replaces _DetectCPUFeatures() (simd_platform.c:68-178): selects the HIP device for the
  * calling thread and probes it.  Idempotent.  Unlike the reference's CPU flags
  * (simd_dct.cpp:78-85 read them, nobody sets them), every entry point below calls this
- * lazily with the current device, so forgetting it cannot downgrade the path. */
+ * lazily with the current device, so forgetting it cannot downgrade the path.  It is where
+ * the one-time costs belong: it also loads the library's code objects onto the device, ~1.5 ms
+ * that the caller's first transform would pay otherwise (first launch after mdct_init: 0.08 ms). */
 int mdct_init(int device);
 int mdct_get_device_info(mdct_device_info *info);
 /* Thread-local detail for the last non-zero return in this thread ("" if none). */

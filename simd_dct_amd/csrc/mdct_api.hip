@@ -893,7 +893,14 @@ int mdct_init(int device)
   if (e != hipSuccess)
     return hip_fail(e, "hipSetDevice");
   const mdct_device_info *di;
-  return current(&di);
+  const int r = current(&di);
+  if (r != MDCT_SUCCESS)
+    return r;
+  // one-time costs belong here: load both code objects onto this device now (otherwise the caller's first transform pays ~1.5 ms for it).
+  // Failure is not fatal -- the first launch would load them anyway.
+  (void)mdct::preload_kernels();
+  (void)mdct::preload_stage_kernels();
+  return MDCT_SUCCESS;
 }
 
 int mdct_get_device_info(mdct_device_info *info)

@@ -201,6 +201,8 @@ hipError_t launch_px_huffman(const PxHuffArgs &a, bool i16_in, bool pack, bool c
 hipError_t launch_f32(const F32Args &a, int mode, hipStream_t s);
 hipError_t launch_park_table(const OwnTables &tb, OwnTables *slot, hipStream_t s); // table cache upload (mdct_api.hip)
 hipError_t launch_clock_probe(unsigned long long *out, unsigned int ticks, unsigned int waves, hipStream_t s); // diagnostics
+hipError_t preload_kernels();        // mdct_init: load this file's code object now (mdct_kernels.hip)
+hipError_t preload_stage_kernels();  // the same for stages.hip
 hipError_t launch_stream_copy(const void *from, void *to, size_t bytes, int cus, hipStream_t s);
 
 } // namespace mdct

@@ -2688,6 +2688,17 @@ hipError_t launch_u8_batch(const BatchArgs &a, uint32_t total, int mode, bool ge
   return hipErrorInvalidValue;
 }
 
+// mdct_init: the first use of any kernel of a code object loads it onto the device (~1.5 ms for this file's); asking for a kernel's attributes
+// does the same without launching anything, so the cost sits in mdct_init instead of in the caller's first transform
+hipError_t preload_kernels()
+{
+  hipFuncAttributes attr;
+  const hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_clock_probe));
+  if (e != hipSuccess)
+    (void)hipGetLastError();
+  return e;
+}
+
 hipError_t launch_clock_probe(unsigned long long *out, unsigned int ticks, unsigned int waves, hipStream_t s)
 {
   hipLaunchKernelGGL(k_clock_probe, dim3(waves), dim3(64), 0, s, out, ticks);

@@ -440,6 +440,16 @@ __global__ __launch_bounds__(256) void k_pack_write(PackArgs a)
   row.finish(a.out + base, r + 1 < a.n_rows, (a.first_rst + r) & 7, stage, wave_tot);
 }
 
+// mdct_init: load this file's code object now rather than at the first stage call (mdct_kernels.hip: preload_kernels)
+hipError_t preload_stage_kernels()
+{
+  hipFuncAttributes attr;
+  const hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_pack_count));
+  if (e != hipSuccess)
+    (void)hipGetLastError();
+  return e;
+}
+
 } // namespace mdct
 
 namespace
