@@ -51,7 +51,7 @@ enum { K_AVX = 0, K_SSE = 1, K_TRUE = 2 }; // the reference's three 1-D kernels 
 // Explicit __builtin_fmaf only: contraction stays off, the compiler fuses nothing on its own.
 // The scale factors live in 64-entry tables applied where a multiply exists anyway (quantise / dequantise),
 // and for the fused round trip they cancel to exactly 1/64, which the final rounding step
-// absorbs (see store_i16x8).  Same operations on the same operands as the CPU checker (orc_aan_*).
+// absorbs (see rne_i16_bits).  Same operations on the same operands as the CPU checker (orc_aan_*).
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void aan_fwd8(const DctConsts &C, float &p0, float &p1, float &p2, float &p3, float &p4, float &p5, float &p6, float &p7)
 {
@@ -1052,17 +1052,6 @@ __device__ __forceinline__ float quant_i16_float(const DctConsts &C, float y, fl
 
 __device__ __forceinline__ uint32_t pack_lo16(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_perm(hi, lo, 0x05040100u); }
 
-template <int SHIFT>
-__device__ __forceinline__ void store_i16x8(const DctConsts &C, int16_t *dst, const float (&row)[8])
-{
-  static_assert(SHIFT == 0 || SHIFT == 6, "magic constants exist for 2^0 and 2^6 only");
-  uint32_t t[8];
-#pragma unroll
-  for (int c = 0; c < 8; c++)
-    t[c] = rne_i16_bits<SHIFT>(C, row[c]);
-  st_stream16(dst, pack_lo16(t[0], t[1]), pack_lo16(t[2], t[3]), pack_lo16(t[4], t[5]), pack_lo16(t[6], t[7]));
-}
-
 // a row of raw forward outputs quantised on the way out (quant_i16_bits)
 __device__ __forceinline__ void store_q_i16x8(const DctConsts &C, int16_t *dst, const float (&row)[8], const float *qf)
 {
@@ -1529,7 +1518,7 @@ __device__ __forceinline__ void i16_roundtrip_rows(const DctConsts &C, const Row
   {
     aan_fwd_v(K, P[j]);
     if constexpr (HAS_LUT)
-    { // c = sat_i16(rne(y * qf)); z = c * dq  (rne_i16_float), on both halves
+    { // c = sat_i16(rne(y * qf)); z = c * dq  (quant_i16_float), on both halves
       karg_pairs_t tq = (karg_pairs_t)(tbp + offsetof(OwnTables, qf)) + j * 8, td = (karg_pairs_t)(tbp + offsetof(OwnTables, dq)) + j * 8;
       asm volatile("" : "+s"(tq), "+s"(td));
       quant_dequant_pairs<SAT>(K, P[j], tq, td);
